@@ -1,0 +1,244 @@
+/*
+ * mrt_abi.h — C ABI of the MI355X-native path tracer (libmrt_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of JaapWijnen/metal-raytracing: everything
+ * `Renderer.draw(in:)` binds to `raytracingKernel` (Renderer.swift:302-329), the data contract
+ * of the bridging header (ShaderTypes.h:60-107) and the acceleration-structure build
+ * (Renderer.swift:184-214, Utilities.swift:29-85).  The reference has no FFI of its own; each
+ * entry point below cites the reference interface it replaces.  Plain pointers and sizes only:
+ * no C++ types, no torch types.  Every call returns an int status (MRT_OK == 0) and never
+ * throws or aborts across the boundary; mrt_last_error() gives the thread-local message.
+ *
+ * Threading: one thread drives a renderer at a time (the reference drives Renderer from the
+ * main thread only, Renderer.swift:284).  The library never calls back into the caller.
+ */
+#ifndef MRT_ABI_H
+#define MRT_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRT_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- status codes */
+enum {
+    MRT_OK = 0,
+    MRT_ERR_INVALID_ARGUMENT = 1,
+    MRT_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime failure at context creation   */
+    MRT_ERR_HIP = 3,            /* a HIP call failed; message carries hipGetErrorString       */
+    MRT_ERR_IO = 4,             /* OBJ/MTL file could not be read                             */
+    MRT_ERR_STATE = 5,          /* call order violated (e.g. render before scene commit)      */
+    MRT_ERR_OUT_OF_MEMORY = 6,
+    MRT_ERR_UNSUPPORTED = 7
+};
+
+/* ---------------------------------------------------------------- data contract
+ * Bit layout of ShaderTypes.h:60-107.  `vector_float3` is 16-byte sized and aligned, hence the
+ * explicit pad word.  Offsets are static_assert-ed in csrc/abi_check.h and tested in
+ * tests/test_abi_layout.py.                                                                    */
+typedef struct { float x, y, z, _pad; } MRTFloat3;                    /* simd vector_float3     */
+
+typedef struct {                                                      /* ShaderTypes.h:60-65    */
+    MRTFloat3 position, right, up, forward;
+} MRTCamera;                                                          /* 64 B                   */
+
+typedef enum {                                                        /* ShaderTypes.h:67-74    */
+    MRTLightTypeUnused = 0, MRTLightTypeSunlight = 1, MRTLightTypeSpotlight = 2,
+    MRTLightTypePointlight = 3, MRTLightTypeAreaLight = 4
+} MRTLightType;
+
+typedef struct {                                                      /* ShaderTypes.h:76-87    */
+    int32_t   type;            /* @0   (NSInteger on the Swift side: low 32 bits, LE)          */
+    int32_t   _pad0[3];
+    MRTFloat3 position;        /* @16                                                          */
+    MRTFloat3 color;           /* @32                                                          */
+    MRTFloat3 forward;         /* @48  area light                                              */
+    MRTFloat3 right;           /* @64                                                          */
+    MRTFloat3 up;              /* @80                                                          */
+    float     coneAngle;       /* @96  spot light                                              */
+    float     _pad1[3];
+    MRTFloat3 direction;       /* @112                                                         */
+} MRTLight;                                                           /* 128 B                  */
+
+typedef struct {                                                      /* ShaderTypes.h:89-97    */
+    int32_t   width, height, blocksWide;
+    uint32_t  frameIndex;
+    int32_t   lightCount;
+    int32_t   _pad[3];
+    MRTCamera camera;          /* @32                                                          */
+} MRTUniforms;                                                        /* 96 B                   */
+
+typedef struct {                                                      /* ShaderTypes.h:99-107   */
+    MRTFloat3 baseColor;       /* @0  — the only field raytracingKernel reads (:269)           */
+    MRTFloat3 specular;        /* @16                                                          */
+    MRTFloat3 emission;        /* @32                                                          */
+    float     specularExponent;/* @48                                                          */
+    float     refractionIndex; /* @52                                                          */
+    float     dissolve;        /* @56                                                          */
+    float     _pad;
+} MRTMaterial;                                                        /* 64 B                   */
+
+/* One ray / one intersector result, as `metal::raytracing::ray` and
+ * `intersector<triangle_data, instancing>::result_type` present them (Raytracing.metal:214-221,
+ * :230-247).  Used by the query entry points (parity tests, brute-force cross-checks).         */
+typedef struct {
+    float origin[3];    float min_distance;
+    float direction[3]; float max_distance;
+} MRTRay;                                                             /* 32 B                   */
+
+typedef struct {
+    int32_t type;              /* 0 = none, 1 = triangle                                       */
+    float   distance;
+    int32_t instance_id;       /* mesh index in scene order (Renderer.swift:193-195)           */
+    int32_t geometry_id;       /* submesh index within the mesh (Mesh.swift:39-48)             */
+    int32_t primitive_id;      /* triangle index within the submesh                            */
+    float   u, v;              /* triangle_barycentric_coord: weights of vertices 1 and 2      */
+    int32_t _pad;
+} MRTIntersection;                                                    /* 32 B                   */
+
+typedef struct {
+    uint64_t triangles;        /* T: triangles in the committed scene                          */
+    uint64_t vertices;         /* V                                                            */
+    uint64_t bvh_nodes;        /* nodes in the traversal layout                                */
+    uint64_t bvh_leaves;
+    uint64_t scene_bytes;      /* device bytes of nodes + triangle packets + shading tables    */
+    float    build_ms;         /* device time of the last mrt_scene_commit                     */
+    float    sah_cost;         /* SAH cost of the emitted tree (Ct=1, Ci=1)                    */
+    int32_t  instances;
+    int32_t  max_submeshes;    /* resource-table stride (Renderer.swift:128-139)               */
+    int32_t  max_leaf_tris;
+    int32_t  max_depth;
+} MRTSceneStats;
+
+typedef struct {
+    uint64_t frames;           /* frames rendered since create/resize                          */
+    uint64_t closest_rays;     /* R_closest summed over those frames                           */
+    uint64_t shadow_rays;      /* R_shadow (shadow rays actually cast, Raytracing.metal:341)   */
+    uint64_t primary_rays;     /* w*h (this shard's pixels) per frame, summed                  */
+    uint64_t bytes_alg;        /* SURVEY §8(d) algorithmic bytes, summed                       */
+    float    ms_gpu_last;      /* device ms of the last mrt_renderer_render batch (HIP events) */
+    float    ms_extend_last;   /* device ms spent in the closest-hit kernel within that batch  */
+    uint32_t extend_launches_last;
+    uint32_t _pad;
+} MRTRenderStats;
+
+typedef struct MRTContext_  *MRTContext;
+typedef struct MRTScene_    *MRTScene;
+typedef struct MRTRenderer_ *MRTRenderer;
+
+/* ---------------------------------------------------------------- errors */
+/* Message of the last failing call on this thread ("" if none).                               */
+const char *mrt_last_error(void);
+int         mrt_abi_version(void);
+
+/* ---------------------------------------------------------------- context
+ * replaces MTLCreateSystemDefaultDevice + makeCommandQueue (Renderer.swift:46-59).
+ * Fails with MRT_ERR_NO_DEVICE when there is no HIP device — there is no CPU fallback.         */
+int mrt_context_create(int device_id, MRTContext *out);
+int mrt_context_destroy(MRTContext ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int mrt_context_set_stream(MRTContext ctx, void *hip_stream);
+int mrt_context_device_name(MRTContext ctx, char *buf, size_t buflen);
+
+/* ---------------------------------------------------------------- scene / geometry
+ * replaces Model.init / Mesh.init / Submesh.init (Model.swift:13-24, Mesh.swift:18-33,
+ * SubMesh.swift:23-33).  The library copies caller arrays (as MTKMeshBufferAllocator does).   */
+int mrt_scene_create(MRTContext ctx, MRTScene *out);
+int mrt_scene_destroy(MRTScene scene);
+
+/* One Mesh = one instance (Renderer.swift:193-200).  positions/normals: nverts vectors with the
+ * given byte stride (16 for the reference's float3 buffers, 12 for packed).  transform: 16
+ * floats, column-major 4x4 object→world (Mesh.swift:21-24); the last row is ignored exactly as
+ * matrix4x4_drop_last_row does (Utilities.swift:92-101).  Returns the instance id in *mesh_id. */
+int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride_bytes,
+                       const float *normals, size_t nrm_stride_bytes, size_t nverts,
+                       const float *transform_colmajor_4x4, int32_t *mesh_id);
+/* One Submesh = one geometry of that mesh's primitive AS (Mesh.swift:39-48).  indices: 3*ntris
+ * uint32 into the mesh's vertex arrays.  Returns the geometry id in *geometry_id.              */
+int mrt_mesh_add_submesh(MRTScene scene, int32_t mesh_id, const uint32_t *indices, size_t ntris,
+                         const MRTMaterial *material, int32_t *geometry_id);
+/* Convenience = Model(name:position:rotation:scale:) (Model.swift:13): read OBJ+MTL with the
+ * library's reader, build T*R*S (Mesh.swift:21-24, Utilities.swift:113-166), add mesh+submeshes. */
+int mrt_scene_add_obj(MRTScene scene, const char *obj_path, const float position[3],
+                      const float rotation[3], float scale, int32_t *mesh_id);
+/* Scene.lights → lightBuffer (Scene.swift:15-33).                                              */
+int mrt_scene_set_lights(MRTScene scene, const MRTLight *lights, int32_t count);
+/* createAccelerationStructures (Renderer.swift:184-214): on-device BVH build; blocking, like the
+ * reference's waitUntilCompleted (Utilities.swift:63,83).  builder: 0 = default.               */
+int mrt_scene_commit(MRTScene scene);
+int mrt_scene_set_option(MRTScene scene, const char *key, double value);
+int mrt_scene_stats(MRTScene scene, MRTSceneStats *out);
+/* 4x3 packed instance transform as the reference stores it (Renderer.swift:193-203).          */
+int mrt_scene_instance_transform(MRTScene scene, int32_t mesh_id, float out_colmajor_4x3[12]);
+
+/* Intersector queries against the committed scene: the two uses of `intersector.intersect`
+ * (Raytracing.metal:244 closest, :367 any).  Host arrays in, host arrays out.                  */
+int mrt_scene_intersect_closest(MRTScene scene, const MRTRay *rays, size_t n, MRTIntersection *out);
+int mrt_scene_intersect_any(MRTScene scene, const MRTRay *rays, size_t n, int32_t *occluded);
+
+/* ---------------------------------------------------------------- host-side geometry helpers
+ * (no GPU needed) — the library's OBJ/MTL reader standing in for ModelIO (Model.swift:16-21,
+ * SubMesh.swift:37-54) and the procedural dragon proxy (dragon.obj is absent upstream).        */
+typedef struct MRTMeshData_ *MRTMeshData;
+int mrt_obj_load(const char *obj_path, MRTMeshData *out);
+int mrt_dragon_proxy(MRTMeshData *out);             /* exactly 871 414 triangles               */
+int mrt_bunny_proxy(MRTMeshData *out);              /* exactly  69 451 triangles               */
+int mrt_meshdata_free(MRTMeshData m);
+int mrt_meshdata_counts(MRTMeshData m, size_t *nverts, int32_t *nsubmeshes);
+/* positions / normals: nverts*3 packed floats */
+int mrt_meshdata_vertices(MRTMeshData m, float *positions, float *normals);
+int mrt_meshdata_submesh(MRTMeshData m, int32_t submesh, size_t *ntris, uint32_t *indices /* may be NULL */,
+                         MRTMaterial *material /* may be NULL */, char *name_buf, size_t name_buflen);
+/* T*R*S with R = Rx*Ry*Rz (Mesh.swift:21-24; Utilities.swift:104-166), column-major 4x4.       */
+int mrt_make_transform(const float position[3], const float rotation[3], float scale, float out16[16]);
+/* Scene.setupCamera(size:) (Scene.swift:40-57).                                                */
+int mrt_default_camera(int32_t width, int32_t height, MRTCamera *out);
+
+/* ---------------------------------------------------------------- renderer
+ * replaces Renderer.init / createTextures / createBuffers (Renderer.swift:45-71, :107-182,
+ * :231-275).  seed drives the per-pixel Halton offsets (the reference uses arc4random, :259).
+ * max_bounces: the literal 3 of Raytracing.metal:237.                                         */
+int mrt_renderer_create(MRTContext ctx, MRTScene scene, int32_t width, int32_t height,
+                        uint32_t seed, int32_t max_bounces, MRTRenderer *out);
+int mrt_renderer_destroy(MRTRenderer r);
+/* mtkView(_:drawableSizeWillChange:) (Renderer.swift:353-356): new targets, new seeds, frameIndex=0 */
+int mrt_renderer_resize(MRTRenderer r, int32_t width, int32_t height);
+/* Default camera = Scene.setupCamera(size) recomputed from the size (Scene.swift:36-57).       */
+int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
+int mrt_renderer_set_option(MRTRenderer r, const char *key, double value);
+/* Screen-tile shard for multi-GPU: this renderer owns 8x8 tiles with (tile_id % world) == rank;
+ * other pixels stay 0 in its targets so that a sum-reduce assembles the frame.                 */
+int mrt_renderer_set_shard(MRTRenderer r, int32_t rank, int32_t world);
+/* Restart accumulation at a given frame index (sample-index sharding; resume).                 */
+int mrt_renderer_set_frame_index(MRTRenderer r, uint32_t frame_index);
+int mrt_renderer_frame_index(MRTRenderer r, uint32_t *frame_index);
+/* draw(in:) (Renderer.swift:284-351) n_frames times: enqueue on the stream and return.         */
+int mrt_renderer_render(MRTRenderer r, int32_t n_frames);
+/* commandBuffer completion (Renderer.swift:285-287).                                           */
+int mrt_renderer_wait(MRTRenderer r);
+/* accumulationTargets[0] after the swap (Renderer.swift:332-334): w*h RGBA32F, row 0 = bottom of
+ * the image as the kernel writes it (Raytracing.metal:206-207; the blit flips, Shaders.metal:35). */
+int mrt_renderer_read_accum(MRTRenderer r, float *rgba, size_t nbytes);
+/* Same data copied device→device into caller memory (e.g. a torch tensor for the RCCL reduce). */
+int mrt_renderer_copy_accum_to_device(MRTRenderer r, void *device_ptr, size_t nbytes);
+int mrt_renderer_write_accum_from_device(MRTRenderer r, const void *device_ptr, size_t nbytes);
+/* fragmentShader (Shaders.metal:39-52): Reinhard c/(1+c), top row first (flipped), RGBA8.      */
+int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbytes);
+int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out);
+int mrt_renderer_reset_stats(MRTRenderer r);
+
+/* ---------------------------------------------------------------- device-function probes
+ * Evaluate the kernel's helper functions on the device for known-answer tests
+ * (Raytracing.metal:41-56 halton, :78-88 hemisphere, :132-147 align).                         */
+int mrt_debug_halton(MRTContext ctx, const int32_t *i, const int32_t *d, size_t n, float *out);
+int mrt_debug_hemisphere(MRTContext ctx, const float *u2, const float *normal3, size_t n, float *out3);
+int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRT_ABI_H */

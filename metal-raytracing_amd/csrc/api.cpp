@@ -1,0 +1,431 @@
+// api.cpp — implementation of include/mrt_abi.h.  Every entry point validates its arguments,
+// catches C++ exceptions and returns a status code; nothing throws or aborts across the ABI.
+// There is no CPU fallback: without a HIP device mrt_context_create fails (MRT_ERR_NO_DEVICE).
+#include "renderer.h"
+#include <cstring>
+#include <cstdio>
+#include <memory>
+#include <new>
+
+struct MRTContext_ {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char name[256] = {0};
+};
+struct MRTScene_ {
+    MRTContext ctx = nullptr;
+    std::vector<mrt::HostMesh> meshes;
+    std::vector<MRTLight> lights;
+    mrt::BuildOptions opt;
+    mrt::DeviceScene dev;
+    bool committed = false;
+};
+struct MRTRenderer_ {
+    MRTContext ctx = nullptr;
+    MRTScene scene = nullptr;
+    mrt::Renderer r;
+};
+struct MRTMeshData_ { mrt::MeshData m; };
+
+namespace mrt {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_err = buf;
+    return e == hipErrorOutOfMemory ? MRT_ERR_OUT_OF_MEMORY : MRT_ERR_HIP;
+}
+}  // namespace mrt
+
+#define MRT_TRY try {
+#define MRT_CATCH                                                                      \
+    } catch (const std::bad_alloc &) { mrt::set_error("out of host memory"); return MRT_ERR_OUT_OF_MEMORY; } \
+    catch (const std::exception &e) { mrt::set_error(std::string("exception: ") + e.what()); return MRT_ERR_INVALID_ARGUMENT; } \
+    catch (...) { mrt::set_error("unknown exception"); return MRT_ERR_INVALID_ARGUMENT; }
+#define REQUIRE(cond, msg) do { if (!(cond)) { mrt::set_error(msg); return MRT_ERR_INVALID_ARGUMENT; } } while (0)
+
+static int bind_device(MRTContext ctx) { MRT_HIP(hipSetDevice(ctx->device)); return MRT_OK; }
+
+extern "C" {
+
+const char *mrt_last_error(void) { return mrt::g_err.c_str(); }
+int mrt_abi_version(void) { return MRT_ABI_VERSION; }
+
+// ---------------------------------------------------------------- context
+int mrt_context_create(int device_id, MRTContext *out) {
+    MRT_TRY
+    REQUIRE(out, "mrt_context_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { mrt::set_error("no HIP device available (GPU not available — there is no CPU fallback)"); return MRT_ERR_NO_DEVICE; }
+    REQUIRE(device_id >= 0 && device_id < count, "mrt_context_create: device_id out of range");
+    std::unique_ptr<MRTContext_> c(new MRTContext_());
+    c->device = device_id;
+    MRT_HIP(hipSetDevice(device_id));
+    MRT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    hipDeviceProp_t prop;
+    MRT_HIP(hipGetDeviceProperties(&prop, device_id));
+    snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    *out = c.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_context_destroy(MRTContext ctx) {
+    if (!ctx) return MRT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+    return MRT_OK;
+}
+int mrt_context_set_stream(MRTContext ctx, void *hip_stream) {
+    MRT_TRY
+    REQUIRE(ctx, "mrt_context_set_stream: ctx is NULL");
+    int rc = bind_device(ctx); if (rc) return rc;
+    if (ctx->own_stream && ctx->stream) { MRT_HIP(hipStreamSynchronize(ctx->stream)); MRT_HIP(hipStreamDestroy(ctx->stream)); }
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+    else { MRT_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_context_device_name(MRTContext ctx, char *buf, size_t buflen) {
+    REQUIRE(ctx && buf && buflen, "mrt_context_device_name: bad argument");
+    snprintf(buf, buflen, "%s", ctx->name);
+    return MRT_OK;
+}
+
+// ---------------------------------------------------------------- scene
+int mrt_scene_create(MRTContext ctx, MRTScene *out) {
+    MRT_TRY
+    REQUIRE(ctx && out, "mrt_scene_create: bad argument");
+    MRTScene s = new MRTScene_(); s->ctx = ctx; *out = s;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_destroy(MRTScene scene) {
+    if (!scene) return MRT_OK;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    delete scene;
+    return MRT_OK;
+}
+int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride, const float *normals, size_t nrm_stride,
+                       size_t nverts, const float *xf, int32_t *mesh_id) {
+    MRT_TRY
+    REQUIRE(scene && xf, "mrt_scene_add_mesh: bad argument");
+    REQUIRE(nverts == 0 || (positions && normals), "mrt_scene_add_mesh: NULL vertex arrays");
+    REQUIRE(pos_stride >= 12 && nrm_stride >= 12 && pos_stride % 4 == 0 && nrm_stride % 4 == 0, "mrt_scene_add_mesh: strides must be multiples of 4 and >= 12");
+    REQUIRE(scene->meshes.size() < 65535, "mrt_scene_add_mesh: too many meshes");
+    mrt::HostMesh m;
+    m.positions.resize(nverts * 3); m.normals.resize(nverts * 3);
+    for (size_t i = 0; i < nverts; i++) {
+        const float *p = (const float *)((const char *)positions + i * pos_stride);
+        const float *n = (const float *)((const char *)normals + i * nrm_stride);
+        for (int k = 0; k < 3; k++) { m.positions[i * 3 + k] = p[k]; m.normals[i * 3 + k] = n[k]; }
+    }
+    memcpy(m.xf, xf, 64);
+    m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;              // matrix4x4_drop_last_row (Utilities.swift:92-101)
+    scene->meshes.push_back(std::move(m));
+    scene->committed = false;
+    if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_mesh_add_submesh(MRTScene scene, int32_t mesh_id, const uint32_t *indices, size_t ntris, const MRTMaterial *material, int32_t *geometry_id) {
+    MRT_TRY
+    REQUIRE(scene && material, "mrt_mesh_add_submesh: bad argument");
+    REQUIRE(mesh_id >= 0 && (size_t)mesh_id < scene->meshes.size(), "mrt_mesh_add_submesh: mesh_id out of range");
+    REQUIRE(ntris == 0 || indices, "mrt_mesh_add_submesh: NULL indices");
+    mrt::HostMesh &m = scene->meshes[mesh_id];
+    REQUIRE(m.sub_indices.size() < 65535, "mrt_mesh_add_submesh: too many submeshes");
+    size_t nv = m.positions.size() / 3;
+    for (size_t i = 0; i < ntris * 3; i++) REQUIRE(indices[i] < nv, "mrt_mesh_add_submesh: vertex index out of range");
+    m.sub_indices.emplace_back(indices, indices + ntris * 3);
+    m.sub_materials.push_back(*material);
+    scene->committed = false;
+    if (geometry_id) *geometry_id = (int32_t)m.sub_indices.size() - 1;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_add_obj(MRTScene scene, const char *obj_path, const float position[3], const float rotation[3], float scale, int32_t *mesh_id) {
+    MRT_TRY
+    REQUIRE(scene && obj_path && position && rotation, "mrt_scene_add_obj: bad argument");
+    mrt::MeshData md;
+    if (!mrt::load_obj(obj_path, md)) return MRT_ERR_IO;
+    float xf[16];
+    mrt::make_transform(position, rotation, scale, xf);
+    int32_t id = -1;
+    int rc = mrt_scene_add_mesh(scene, md.positions.data(), 12, md.normals.data(), 12, md.positions.size() / 3, xf, &id);
+    if (rc) return rc;
+    for (auto &s : md.submeshes) { rc = mrt_mesh_add_submesh(scene, id, s.indices.data(), s.indices.size() / 3, &s.material, nullptr); if (rc) return rc; }
+    if (mesh_id) *mesh_id = id;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_set_lights(MRTScene scene, const MRTLight *lights, int32_t count) {
+    MRT_TRY
+    REQUIRE(scene && count >= 0 && (count == 0 || lights), "mrt_scene_set_lights: bad argument");
+    scene->lights.assign(lights, lights + count);
+    if (scene->committed) { int rc = bind_device(scene->ctx); if (rc) return rc; return mrt::upload_lights(scene->lights.data(), count, scene->ctx->stream, scene->dev); }
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
+    MRT_TRY
+    REQUIRE(scene && key, "mrt_scene_set_option: bad argument");
+    std::string k(key);
+    if (k == "builder") scene->opt.builder = (int)value;
+    else if (k == "max_leaf") { REQUIRE(value >= 1 && value <= 16, "max_leaf must be in [1,16]"); scene->opt.max_leaf = (int)value; }
+    else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
+    else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
+    else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
+    else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    scene->committed = false;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_commit(MRTScene scene) {
+    MRT_TRY
+    REQUIRE(scene, "mrt_scene_commit: scene is NULL");
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev); if (rc) return rc;
+    rc = mrt::upload_lights(scene->lights.data(), (int)scene->lights.size(), scene->ctx->stream, scene->dev); if (rc) return rc;
+    scene->committed = true;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_stats(MRTScene scene, MRTSceneStats *out) {
+    REQUIRE(scene && out, "mrt_scene_stats: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_scene_stats: scene not committed"); return MRT_ERR_STATE; }
+    *out = scene->dev.stats;
+    return MRT_OK;
+}
+int mrt_scene_instance_transform(MRTScene scene, int32_t mesh_id, float out[12]) {
+    REQUIRE(scene && out, "mrt_scene_instance_transform: bad argument");
+    REQUIRE(mesh_id >= 0 && (size_t)mesh_id < scene->meshes.size(), "mrt_scene_instance_transform: mesh_id out of range");
+    const float *m = scene->meshes[mesh_id].xf;
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) out[c * 3 + r] = m[c * 4 + r];
+    return MRT_OK;
+}
+int mrt_scene_intersect_closest(MRTScene scene, const MRTRay *rays, size_t n, MRTIntersection *out) {
+    MRT_TRY
+    REQUIRE(scene && (n == 0 || (rays && out)), "mrt_scene_intersect_closest: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_scene_intersect_closest: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::query_closest(scene->dev, scene->ctx->stream, rays, n, out);
+    MRT_CATCH
+}
+int mrt_scene_intersect_any(MRTScene scene, const MRTRay *rays, size_t n, int32_t *occluded) {
+    MRT_TRY
+    REQUIRE(scene && (n == 0 || (rays && occluded)), "mrt_scene_intersect_any: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_scene_intersect_any: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::query_any(scene->dev, scene->ctx->stream, rays, n, occluded);
+    MRT_CATCH
+}
+
+// ---------------------------------------------------------------- host geometry helpers
+int mrt_obj_load(const char *obj_path, MRTMeshData *out) {
+    MRT_TRY
+    REQUIRE(obj_path && out, "mrt_obj_load: bad argument");
+    std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
+    if (!mrt::load_obj(obj_path, m->m)) return MRT_ERR_IO;
+    *out = m.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_dragon_proxy(MRTMeshData *out) {
+    MRT_TRY
+    REQUIRE(out, "mrt_dragon_proxy: out is NULL");
+    std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
+    mrt::make_dragon_proxy(m->m);
+    *out = m.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_bunny_proxy(MRTMeshData *out) {
+    MRT_TRY
+    REQUIRE(out, "mrt_bunny_proxy: out is NULL");
+    std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
+    mrt::make_bunny_proxy(m->m);
+    *out = m.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_meshdata_free(MRTMeshData m) { delete m; return MRT_OK; }
+int mrt_meshdata_counts(MRTMeshData m, size_t *nverts, int32_t *nsub) {
+    REQUIRE(m, "mrt_meshdata_counts: NULL");
+    if (nverts) *nverts = m->m.positions.size() / 3;
+    if (nsub) *nsub = (int32_t)m->m.submeshes.size();
+    return MRT_OK;
+}
+int mrt_meshdata_vertices(MRTMeshData m, float *positions, float *normals) {
+    REQUIRE(m, "mrt_meshdata_vertices: NULL");
+    if (positions) memcpy(positions, m->m.positions.data(), m->m.positions.size() * 4);
+    if (normals) memcpy(normals, m->m.normals.data(), m->m.normals.size() * 4);
+    return MRT_OK;
+}
+int mrt_meshdata_submesh(MRTMeshData m, int32_t sub, size_t *ntris, uint32_t *indices, MRTMaterial *material, char *name_buf, size_t name_buflen) {
+    REQUIRE(m, "mrt_meshdata_submesh: NULL");
+    REQUIRE(sub >= 0 && (size_t)sub < m->m.submeshes.size(), "mrt_meshdata_submesh: submesh out of range");
+    const mrt::Submesh &s = m->m.submeshes[sub];
+    if (ntris) *ntris = s.indices.size() / 3;
+    if (indices) memcpy(indices, s.indices.data(), s.indices.size() * 4);
+    if (material) *material = s.material;
+    if (name_buf && name_buflen) snprintf(name_buf, name_buflen, "%s", s.name.c_str());
+    return MRT_OK;
+}
+int mrt_make_transform(const float position[3], const float rotation[3], float scale, float out16[16]) {
+    REQUIRE(position && rotation && out16, "mrt_make_transform: bad argument");
+    mrt::make_transform(position, rotation, scale, out16);
+    return MRT_OK;
+}
+int mrt_default_camera(int32_t width, int32_t height, MRTCamera *out) {
+    REQUIRE(out && width > 0 && height > 0, "mrt_default_camera: bad argument");
+    mrt::default_camera(width, height, out);
+    return MRT_OK;
+}
+
+// ---------------------------------------------------------------- renderer
+int mrt_renderer_create(MRTContext ctx, MRTScene scene, int32_t width, int32_t height, uint32_t seed, int32_t max_bounces, MRTRenderer *out) {
+    MRT_TRY
+    REQUIRE(ctx && scene && out, "mrt_renderer_create: bad argument");
+    REQUIRE(width > 0 && height > 0 && (int64_t)width * height < (1ll << 30), "mrt_renderer_create: bad size");
+    REQUIRE(max_bounces >= 1 && max_bounces <= 19, "mrt_renderer_create: max_bounces must be in [1,19] (Halton prime table holds 100 primes)");
+    REQUIRE(scene->ctx == ctx, "mrt_renderer_create: scene belongs to another context");
+    if (!scene->committed) { mrt::set_error("mrt_renderer_create: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(ctx); if (rc) return rc;
+    std::unique_ptr<MRTRenderer_> r(new MRTRenderer_());
+    r->ctx = ctx; r->scene = scene;
+    rc = r->r.init(ctx->stream, &scene->dev, width, height, seed, max_bounces); if (rc) return rc;
+    *out = r.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_renderer_destroy(MRTRenderer r) {
+    if (!r) return MRT_OK;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    delete r;
+    return MRT_OK;
+}
+#define RENDERER_PROLOGUE(name)                                     \
+    REQUIRE(r, name ": renderer is NULL");                          \
+    { int rc_ = bind_device(r->ctx); if (rc_) return rc_; }         \
+    r->r.stream = r->ctx->stream;
+
+int mrt_renderer_resize(MRTRenderer r, int32_t width, int32_t height) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_resize")
+    REQUIRE(width > 0 && height > 0 && (int64_t)width * height < (1ll << 30), "mrt_renderer_resize: bad size");
+    MRT_HIP(hipStreamSynchronize(r->r.stream));
+    return r->r.resize(width, height);
+    MRT_CATCH
+}
+int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera) {
+    REQUIRE(r && camera, "mrt_renderer_set_camera: bad argument");
+    r->r.camera = *camera;
+    return MRT_OK;
+}
+int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
+    MRT_TRY
+    REQUIRE(r && key, "mrt_renderer_set_option: bad argument");
+    std::string k(key);
+    if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
+    else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_renderer_set_shard(MRTRenderer r, int32_t rank, int32_t world) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_set_shard")
+    return r->r.set_shard(rank, world);
+    MRT_CATCH
+}
+int mrt_renderer_set_frame_index(MRTRenderer r, uint32_t fi) { REQUIRE(r, "mrt_renderer_set_frame_index: NULL"); r->r.frame_index = fi; return MRT_OK; }
+int mrt_renderer_frame_index(MRTRenderer r, uint32_t *fi) { REQUIRE(r && fi, "mrt_renderer_frame_index: bad argument"); *fi = r->r.frame_index; return MRT_OK; }
+int mrt_renderer_render(MRTRenderer r, int32_t n_frames) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_render")
+    REQUIRE(n_frames >= 0, "mrt_renderer_render: n_frames < 0");
+    if (!r->scene->committed) { mrt::set_error("mrt_renderer_render: scene was modified and not re-committed"); return MRT_ERR_STATE; }
+    if (n_frames == 0) return MRT_OK;
+    return r->r.render(n_frames);
+    MRT_CATCH
+}
+int mrt_renderer_wait(MRTRenderer r) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_wait")
+    return r->r.wait();
+    MRT_CATCH
+}
+int mrt_renderer_read_accum(MRTRenderer r, float *rgba, size_t nbytes) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_read_accum")
+    REQUIRE(rgba, "mrt_renderer_read_accum: NULL buffer");
+    return r->r.read_accum(rgba, nbytes);
+    MRT_CATCH
+}
+int mrt_renderer_copy_accum_to_device(MRTRenderer r, void *dptr, size_t nbytes) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_copy_accum_to_device")
+    REQUIRE(dptr, "mrt_renderer_copy_accum_to_device: NULL pointer");
+    return r->r.copy_accum_to_device(dptr, nbytes);
+    MRT_CATCH
+}
+int mrt_renderer_write_accum_from_device(MRTRenderer r, const void *dptr, size_t nbytes) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_write_accum_from_device")
+    REQUIRE(dptr, "mrt_renderer_write_accum_from_device: NULL pointer");
+    return r->r.write_accum_from_device(dptr, nbytes);
+    MRT_CATCH
+}
+int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbytes) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_read_tonemapped_rgba8")
+    REQUIRE(rgba, "mrt_renderer_read_tonemapped_rgba8: NULL buffer");
+    return r->r.read_tonemapped(rgba, nbytes);
+    MRT_CATCH
+}
+int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_stats")
+    REQUIRE(out, "mrt_renderer_stats: NULL");
+    return r->r.stats(out);
+    MRT_CATCH
+}
+int mrt_renderer_reset_stats(MRTRenderer r) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_reset_stats")
+    return r->r.reset_stats();
+    MRT_CATCH
+}
+
+// ---------------------------------------------------------------- probes
+int mrt_debug_halton(MRTContext ctx, const int32_t *i, const int32_t *d, size_t n, float *out) {
+    MRT_TRY
+    REQUIRE(ctx && (n == 0 || (i && d && out)), "mrt_debug_halton: bad argument");
+    for (size_t k = 0; k < n; k++) REQUIRE(d[k] >= 0 && d[k] < 100 && i[k] >= 0, "mrt_debug_halton: i >= 0 and 0 <= d < 100 required");
+    int rc = bind_device(ctx); if (rc) return rc;
+    return mrt::probe_halton(ctx->stream, i, d, n, out);
+    MRT_CATCH
+}
+int mrt_debug_hemisphere(MRTContext ctx, const float *u2, const float *n3, size_t n, float *out3) {
+    MRT_TRY
+    REQUIRE(ctx && (n == 0 || (u2 && n3 && out3)), "mrt_debug_hemisphere: bad argument");
+    int rc = bind_device(ctx); if (rc) return rc;
+    return mrt::probe_hemisphere(ctx->stream, u2, n3, n, out3);
+    MRT_CATCH
+}
+int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height, uint32_t *out) {
+    MRT_TRY
+    REQUIRE(ctx && out && width > 0 && height > 0, "mrt_debug_seeds: bad argument");
+    int rc = bind_device(ctx); if (rc) return rc;
+    return mrt::probe_seeds(ctx->stream, seed, width, height, out);
+    MRT_CATCH
+}
+
+}  // extern "C"

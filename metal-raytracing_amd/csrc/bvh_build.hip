@@ -1,0 +1,671 @@
+// bvh_build.hip — on-device acceleration-structure build for gfx950.
+//
+// Replaces createAccelerationStructures + buildCompactedAccelerationStructures
+// (Renderer.swift:184-214, Utilities.swift:29-85), for which the reference holds no code at all
+// (Apple's MTLAccelerationStructure is an opaque driver object).  Instances are flattened into one
+// world-space triangle soup — the reference never shares a primitive AS between instances
+// (Renderer.swift:193-195), so this is semantically identical.
+//
+// Pipeline (all kernels on the caller's stream, no host round trips until the final stats read):
+//   flatten   object-space vertices -> world-space Möller–Trumbore triangles, padded AABBs, centroid bounds
+//   morton    63-bit Morton code of the AABB centre (21 bits per axis over the centroid bounds)
+//   sort      hand-written LSD radix sort, 8-bit digits, 64-bit keys + 32-bit payload, stable
+//   topology  builder 0: Karras 2012 binary radix tree (plain LBVH)
+//             builder 1: PLOC (Meister & Bittner 2018): surface-area nearest-neighbour agglomeration in
+//                        a window over the Morton order — the SAH-driven refinement of the LBVH order
+//   refit     bottom-up AABBs, SAH cost, SAH leaf collapse (<= max_leaf triangles), near-child masks
+//   emit      preorder node numbering, 8-octant escape ("rope") links, leaf-contiguous triangle packets
+#include "scene_device.h"
+#include "device_math.h"
+#include <algorithm>
+#include <cstring>
+#include <cmath>
+
+namespace mrt {
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct SubRec { uint32_t tri_begin, tri_count, index_offset, vbase, inst, geom; };
+
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ __forceinline__ float ord2f(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+// ------------------------------------------------------------------ flatten
+__global__ void k_flatten(const SubRec *__restrict__ recs, int nrec, const float *__restrict__ pos,
+                          const uint32_t *__restrict__ indices, const float4 *__restrict__ inst_cols, uint32_t T,
+                          float4 *__restrict__ tri_world, uint4 *__restrict__ tri_shade,
+                          float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi, uint32_t *__restrict__ cbounds) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    float c[3] = {0, 0, 0};
+    bool valid = gid < T;
+    if (valid) {
+        int lo = 0, hi = nrec - 1;                       // last record with tri_begin <= gid
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (recs[mid].tri_begin <= gid) lo = mid; else hi = mid - 1; }
+        SubRec r = recs[lo];
+        uint32_t p = gid - r.tri_begin;
+        const uint32_t *ix = indices + r.index_offset + 3 * (size_t)p;
+        uint32_t i0 = ix[0] + r.vbase, i1 = ix[1] + r.vbase, i2 = ix[2] + r.vbase;
+        float4 c0 = inst_cols[r.inst * 4 + 0], c1 = inst_cols[r.inst * 4 + 1], c2 = inst_cols[r.inst * 4 + 2], c3 = inst_cols[r.inst * 4 + 3];
+        f3 w[3];
+        uint32_t vi[3] = {i0, i1, i2};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float x = pos[3 * (size_t)vi[k]], y = pos[3 * (size_t)vi[k] + 1], z = pos[3 * (size_t)vi[k] + 2];
+            // world = M * (p,1), fused form of mrt-math v1
+            w[k].x = __builtin_fmaf(c2.x, z, __builtin_fmaf(c1.x, y, c0.x * x)) + c3.x;
+            w[k].y = __builtin_fmaf(c2.y, z, __builtin_fmaf(c1.y, y, c0.y * x)) + c3.y;
+            w[k].z = __builtin_fmaf(c2.z, z, __builtin_fmaf(c1.z, y, c0.z * x)) + c3.z;
+        }
+        f3 e1 = w[1] - w[0], e2 = w[2] - w[0];
+        tri_world[3 * (size_t)gid + 0] = make_float4(w[0].x, w[0].y, w[0].z, __uint_as_float(gid));
+        tri_world[3 * (size_t)gid + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+        tri_world[3 * (size_t)gid + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        tri_shade[gid] = make_uint4(i0, i1, i2, (r.inst << 16) | r.geom);
+        float blo[3], bhi[3];
+        blo[0] = fminf(w[0].x, fminf(w[1].x, w[2].x)); bhi[0] = fmaxf(w[0].x, fmaxf(w[1].x, w[2].x));
+        blo[1] = fminf(w[0].y, fminf(w[1].y, w[2].y)); bhi[1] = fmaxf(w[0].y, fmaxf(w[1].y, w[2].y));
+        blo[2] = fminf(w[0].z, fminf(w[1].z, w[2].z)); bhi[2] = fmaxf(w[0].z, fmaxf(w[1].z, w[2].z));
+#pragma unroll
+        for (int k = 0; k < 3; k++) {   // pad: the slab test must never reject what the triangle test accepts
+            float m = fmaxf(fabsf(blo[k]), fabsf(bhi[k]));
+            float e = 1e-5f * m + 1e-6f;
+            blo[k] -= e; bhi[k] += e;
+            c[k] = 0.5f * (blo[k] + bhi[k]);
+        }
+        leaf_lo[gid] = make_float4(blo[0], blo[1], blo[2], 0.0f);
+        leaf_hi[gid] = make_float4(bhi[0], bhi[1], bhi[2], 0.0f);
+    }
+    const float BIG = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float mn = wave_min(valid ? c[k] : BIG), mx = wave_max(valid ? c[k] : -BIG);
+        if ((threadIdx.x & 63) == 0 && mn <= mx) { atomicMin(&cbounds[k], f2ord(mn)); atomicMax(&cbounds[3 + k], f2ord(mx)); }
+    }
+}
+
+// ------------------------------------------------------------------ morton
+__device__ __forceinline__ uint64_t spread21(uint64_t x) {
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void k_morton(const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi, const uint32_t *__restrict__ cbounds,
+                         uint32_t T, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= T) return;
+    float4 lo = leaf_lo[gid], hi = leaf_hi[gid];
+    float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    uint64_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float mn = ord2f(cbounds[k]), mx = ord2f(cbounds[3 + k]);
+        float ext = mx - mn;
+        float n = ext > 0.0f ? (c[k] - mn) / ext : 0.0f;
+        float s = n * 2097152.0f;
+        s = fminf(fmaxf(s, 0.0f), 2097151.0f);
+        q[k] = (uint64_t)s;
+    }
+    keys[gid] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[gid] = gid;
+}
+
+// ------------------------------------------------------------------ LSD radix sort (8-bit digits)
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;                      // per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_hist(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t nblocks, uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * SORT_TILE;
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        uint32_t i = base + r * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    ghist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `count` uint32 in place, single workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan_exclusive(uint32_t *__restrict__ data, uint32_t count) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < count; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < count ? data[i] : 0;
+        uint32_t x = v;
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < w; k++) woff += wsum[k];
+        uint32_t carry = carry_s;
+        if (i < count) data[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                               uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
+                                                               const uint32_t *__restrict__ gofs, uint32_t n, int shift, uint32_t nblocks) {
+    __shared__ uint32_t wcnt[4][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = 0; k < 4; k++) wcnt[k][tid] = 0;
+    __syncthreads();
+    const uint32_t wave_base = blockIdx.x * SORT_TILE + w * (SORT_ITEMS * 64);   // each wave owns a contiguous run: stable order = (wave, round, lane)
+    uint64_t key[SORT_ITEMS];
+    uint32_t off[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        uint32_t i = wave_base + r * 64 + lane;
+        bool valid = i < n;
+        key[r] = valid ? kin[i] : 0ull;
+        uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        uint32_t cnt = __popcll(peers);
+        int leader = valid ? (__ffsll((long long)peers) - 1) : (int)lane;
+        uint32_t base = 0;
+        if (valid && (int)lane == leader) base = atomicAdd(&wcnt[w][d], cnt);
+        base = __shfl(base, leader);
+        off[r] = base + rank;
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 4 waves, per digit
+        uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid];
+        wcnt[0][tid] = 0; wcnt[1][tid] = c0; wcnt[2][tid] = c0 + c1; wcnt[3][tid] = c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        uint32_t i = wave_base + r * 64 + lane;
+        if (i < n) {
+            uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            uint32_t pos = gofs[d * nblocks + blockIdx.x] + wcnt[w][d] + off[r];
+            kout[pos] = key[r];
+            vout[pos] = vin[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Karras 2012 radix tree
+__device__ __forceinline__ int delta_kr(const uint64_t *__restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ b));
+}
+// node ids: internal i -> i (0..n-2), leaf j -> (n-1)+j
+__global__ void k_karras(const uint64_t *__restrict__ keys, int n, uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta_kr(keys, n, i, i + 1) - delta_kr(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta_kr(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta_kr(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta_kr(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta_kr(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta_kr(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + (d < 0 ? -1 : 0);
+    uint32_t lc = (min(i, j) == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+    uint32_t rc = (max(i, j) == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    left[i] = lc; right[i] = rc;
+    parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
+    if (i == 0) parent[0] = NONE;
+}
+
+// ------------------------------------------------------------------ refit + SAH collapse
+struct TreeArrays {
+    float4 *lo, *hi;          // per node (2n-1)
+    uint32_t *parent;         // per node
+    uint32_t *left, *right;   // per internal node id (size n-1, indexed by node id < n-1 for Karras; PLOC uses ids too)
+    uint32_t *flags;          // per node, zeroed
+    float *cost;              // per node
+    uint32_t *ntri, *size;    // per node: triangles below, surviving nodes below (incl. self)
+    uint8_t *collapsed;       // per node: 1 = becomes a leaf of the emitted tree
+    uint8_t *mask;            // per node: near-child mask
+};
+
+__device__ __forceinline__ float box_area(float4 lo, float4 hi) {
+    float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+__global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi,
+                        uint32_t n, uint32_t leaf_base, int max_leaf, float ct, float ci, int have_boxes) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t node = leaf_base + j;
+    uint32_t gid = vals[j];
+    float4 lo = leaf_lo[gid], hi = leaf_hi[gid];
+    t.lo[node] = lo; t.hi[node] = hi;
+    t.cost[node] = ci * box_area(lo, hi);
+    t.ntri[node] = 1; t.size[node] = 1; t.collapsed[node] = 1; t.mask[node] = 0;
+    __threadfence();
+    uint32_t p = t.parent[node];
+    while (p != NONE) {
+        uint32_t old = atomicAdd(&t.flags[p], 1u);
+        if (old == 0) return;                       // the sibling subtree finishes this node
+        __threadfence();
+        uint32_t l = t.left[p], r = t.right[p];
+        float4 llo = t.lo[l], lhi = t.hi[l], rlo = t.lo[r], rhi = t.hi[r];
+        float4 blo = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
+        float4 bhi = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+        (void)have_boxes;
+        float area = box_area(blo, bhi);
+        uint32_t nt = t.ntri[l] + t.ntri[r];
+        float c_inner = ct * area + t.cost[l] + t.cost[r];
+        float c_leaf = ci * area * (float)nt;
+        bool col = (nt <= (uint32_t)max_leaf) && (c_leaf <= c_inner);
+        // near-child mask: along the axis where the child centres are furthest apart, the child with
+        // the smaller centre is entered first by rays travelling in +axis.
+        float cl[3] = {llo.x + lhi.x, llo.y + lhi.y, llo.z + lhi.z}, cr[3] = {rlo.x + rhi.x, rlo.y + rhi.y, rlo.z + rhi.z};
+        int ax = 0; float best = fabsf(cl[0] - cr[0]);
+        if (fabsf(cl[1] - cr[1]) > best) { best = fabsf(cl[1] - cr[1]); ax = 1; }
+        if (fabsf(cl[2] - cr[2]) > best) { ax = 2; }
+        bool left_greater = cl[ax] > cr[ax];
+        uint32_t m = 0;
+        for (int o = 0; o < 8; o++) { bool negdir = (o >> ax) & 1; if (negdir != left_greater) m |= 1u << o; }
+        t.lo[p] = blo; t.hi[p] = bhi;
+        t.cost[p] = col ? c_leaf : c_inner;
+        t.ntri[p] = nt;
+        t.size[p] = col ? 1u : 1u + t.size[l] + t.size[r];
+        t.collapsed[p] = col ? 1 : 0;
+        t.mask[p] = (uint8_t)m;
+        __threadfence();
+        node = p;
+        p = t.parent[p];
+    }
+}
+
+// ------------------------------------------------------------------ numbering + emit
+__global__ void k_assign(TreeArrays t, uint32_t nnodes, uint32_t *__restrict__ new_index, uint32_t *__restrict__ leaf_offset, uint32_t *__restrict__ stat /*[0]=max depth,[1]=leaves*/) {
+    uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= nnodes) return;
+    bool dropped = false;
+    uint32_t pre = 0, lrank = 0, depth = 0, c = nd, p;
+    while ((p = t.parent[c]) != NONE) {
+        if (t.collapsed[p]) dropped = true;
+        uint32_t l = t.left[p];
+        if (l != c) { pre += t.size[l]; lrank += t.ntri[l]; }
+        pre += 1; depth++; c = p;
+    }
+    new_index[nd] = dropped ? NONE : pre;
+    leaf_offset[nd] = lrank;
+    if (!dropped) {
+        atomicMax(&stat[0], depth);
+        if (t.collapsed[nd]) atomicAdd(&stat[1], 1u);
+    }
+}
+
+__global__ void k_emit_nodes(TreeArrays t, uint32_t nnodes, const uint32_t *__restrict__ new_index, const uint32_t *__restrict__ leaf_offset, float4 *__restrict__ out) {
+    uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= nnodes) return;
+    uint32_t me = new_index[nd];
+    if (me == NONE) return;
+    uint32_t esc[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        uint32_t c = nd, e = NODE_TERM;
+        for (;;) {
+            uint32_t p = t.parent[c];
+            if (p == NONE) break;
+            uint32_t l = t.left[p], r = t.right[p];
+            uint32_t near = ((t.mask[p] >> o) & 1u) ? r : l;
+            if (c == near) { e = new_index[near == l ? r : l]; break; }
+            c = p;
+        }
+        esc[o] = e;
+    }
+    float4 lo = t.lo[nd], hi = t.hi[nd];
+    uint32_t a, b;
+    if (t.collapsed[nd]) { a = NODE_LEAF | leaf_offset[nd]; b = t.ntri[nd]; }
+    else { a = new_index[t.left[nd]]; b = ((uint32_t)t.mask[nd] << 24) | new_index[t.right[nd]]; }
+    out[4 * (size_t)me + 0] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(a));
+    out[4 * (size_t)me + 1] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(b));
+    out[4 * (size_t)me + 2] = make_float4(__uint_as_float(esc[0]), __uint_as_float(esc[1]), __uint_as_float(esc[2]), __uint_as_float(esc[3]));
+    out[4 * (size_t)me + 3] = make_float4(__uint_as_float(esc[4]), __uint_as_float(esc[5]), __uint_as_float(esc[6]), __uint_as_float(esc[7]));
+}
+
+__global__ void k_emit_packets(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ leaf_offset, uint32_t leaf_base, uint32_t n,
+                               const float4 *__restrict__ tri_world, float4 *__restrict__ packets) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t rank = leaf_offset[leaf_base + j];
+    uint32_t gid = vals[j];
+    packets[3 * (size_t)rank + 0] = tri_world[3 * (size_t)gid + 0];
+    packets[3 * (size_t)rank + 1] = tri_world[3 * (size_t)gid + 1];
+    packets[3 * (size_t)rank + 2] = tri_world[3 * (size_t)gid + 2];
+}
+
+// ------------------------------------------------------------------ PLOC (builder 1)
+// Clusters live in Morton order.  Each round: every cluster finds, within +-radius positions, the
+// neighbour minimising the surface area of the merged box; mutual pairs merge (the lower position
+// creates the node); survivors are compacted, order preserved.  Node ids: leaves (n-1)+j as for
+// Karras, internal nodes allocated from an atomic counter 0..n-2; the last one created is the root.
+__global__ void k_ploc_init(uint32_t n, uint32_t leaf_base, const uint32_t *__restrict__ vals, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi,
+                            uint32_t *__restrict__ cid, float4 *__restrict__ clo, float4 *__restrict__ chi) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t gid = vals[j];
+    cid[j] = leaf_base + j; clo[j] = leaf_lo[gid]; chi[j] = leaf_hi[gid];
+}
+
+__global__ void k_ploc_nn(uint32_t m, int radius, const float4 *__restrict__ clo, const float4 *__restrict__ chi, uint32_t *__restrict__ nn) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float4 lo = clo[i], hi = chi[i];
+    float best = 3.0e38f; uint32_t bj = NONE;
+    int j0 = (int)i - radius; if (j0 < 0) j0 = 0;
+    int j1 = (int)i + radius; if (j1 > (int)m - 1) j1 = (int)m - 1;
+    for (int j = j0; j <= j1; j++) {
+        if (j == (int)i) continue;
+        float4 l2 = clo[j], h2 = chi[j];
+        float dx = fmaxf(hi.x, h2.x) - fminf(lo.x, l2.x), dy = fmaxf(hi.y, h2.y) - fminf(lo.y, l2.y), dz = fmaxf(hi.z, h2.z) - fminf(lo.z, l2.z);
+        float a = dx * dy + dy * dz + dz * dx;
+        if (a < best) { best = a; bj = (uint32_t)j; }      // ties: lowest position wins (deterministic)
+    }
+    nn[i] = bj;
+}
+
+__global__ void k_ploc_merge(uint32_t m, const uint32_t *__restrict__ nn, const uint32_t *__restrict__ cid, const float4 *__restrict__ clo, const float4 *__restrict__ chi,
+                             uint32_t *__restrict__ keep /* 1 = survives (possibly as merged) */, uint32_t *__restrict__ new_cid, float4 *__restrict__ nlo, float4 *__restrict__ nhi,
+                             uint32_t *__restrict__ node_counter, uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
+                             float4 *__restrict__ node_lo, float4 *__restrict__ node_hi) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t j = nn[i];
+    bool mutual = (j != NONE) && (nn[j] == i);
+    if (mutual && i < j) {
+        uint32_t id = atomicAdd(node_counter, 1u);
+        uint32_t a = cid[i], b = cid[j];
+        left[id] = a; right[id] = b; parent[a] = id; parent[b] = id;
+        float4 lo = make_float4(fminf(clo[i].x, clo[j].x), fminf(clo[i].y, clo[j].y), fminf(clo[i].z, clo[j].z), 0.0f);
+        float4 hi = make_float4(fmaxf(chi[i].x, chi[j].x), fmaxf(chi[i].y, chi[j].y), fmaxf(chi[i].z, chi[j].z), 0.0f);
+        node_lo[id] = lo; node_hi[id] = hi;
+        keep[i] = 1; new_cid[i] = id; nlo[i] = lo; nhi[i] = hi;
+    } else if (mutual) {
+        keep[i] = 0;
+    } else {
+        keep[i] = 1; new_cid[i] = cid[i]; nlo[i] = clo[i]; nhi[i] = chi[i];
+    }
+}
+
+__global__ void k_ploc_compact(uint32_t m, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos /* exclusive scan of keep */,
+                               const uint32_t *__restrict__ new_cid, const float4 *__restrict__ nlo, const float4 *__restrict__ nhi,
+                               uint32_t *__restrict__ cid, float4 *__restrict__ clo, float4 *__restrict__ chi) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (keep[i]) { uint32_t p = pos[i]; cid[p] = new_cid[i]; clo[p] = nlo[i]; chi[p] = nhi[i]; }
+}
+
+// multi-block exclusive scan: per-block sums -> scan -> add
+__global__ void __launch_bounds__(1024) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ bsum, uint32_t count) {
+    __shared__ uint32_t wsum[16];
+    uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t v = i < count ? in[i] : 0, x = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (uint32_t k = 0; k < 16; k++) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
+    if (i < count) out[i] = woff + x - v;
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ bsum_scanned, uint32_t count, uint32_t *__restrict__ total, const uint32_t *__restrict__ last_in) {
+    uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < count) {
+        uint32_t v = out[i] + bsum_scanned[blockIdx.x];
+        out[i] = v;
+        if (i == count - 1) *total = v + last_in[i];
+    }
+}
+__global__ void k_set_root_parent(const uint32_t *__restrict__ cid, uint32_t *__restrict__ parent) { parent[cid[0]] = NONE; }
+
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace
+
+SceneView DeviceScene::view() const {
+    SceneView v{};
+    v.nodes = nodes.p; v.packets = packets.p; v.tri_shade = tri_shade.p; v.normals = normals.p;
+    v.base_color = base_color.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
+    v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
+    v.light_count = light_count; v.max_sub = stats.max_submeshes;
+    return v;
+}
+
+int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out) {
+    std::vector<LightDev> h((size_t)std::max(count, 1));
+    memset(h.data(), 0, h.size() * sizeof(LightDev));
+    for (int i = 0; i < count; i++) {
+        const MRTLight &L = lights[i];
+        LightDev &d = h[i];
+        int32_t ty = L.type;
+        float tyf; memcpy(&tyf, &ty, 4);
+        d.position = make_float4(L.position.x, L.position.y, L.position.z, tyf);
+        d.color = make_float4(L.color.x, L.color.y, L.color.z, 0);
+        d.forward = make_float4(L.forward.x, L.forward.y, L.forward.z, 0);
+        d.right = make_float4(L.right.x, L.right.y, L.right.z, 0);
+        d.up = make_float4(L.up.x, L.up.y, L.up.z, 0);
+        // normalize(direction) with the un-fused mrt-math order (Raytracing.metal:311,324); cos(coneAngle) (:314)
+        float dx = L.direction.x, dy = L.direction.y, dz = L.direction.z;
+        float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+        d.dirn = make_float4(dx * inv, dy * inv, dz * inv, cosf(L.coneAngle));
+    }
+    MRT_HIP(out.lights.alloc(h.size()));
+    MRT_HIP(hipMemcpyAsync(out.lights.p, h.data(), h.size() * sizeof(LightDev), hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    out.light_count = count;
+    return MRT_OK;
+}
+
+int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+    // ---- host-side concatenation (one upload per array)
+    size_t V = 0, T = 0, NI = 0; int max_sub = 1;
+    for (auto &m : meshes) {
+        V += m.positions.size() / 3;
+        max_sub = std::max<int>(max_sub, (int)m.sub_indices.size());
+        for (auto &s : m.sub_indices) { T += s.size() / 3; NI += s.size(); }
+    }
+    const size_t I = meshes.size();
+    if (T >= (1u << 26) || V >= 0xFFFFFFF0ull || I >= 65536 || max_sub >= 65536) { set_error("scene too large (limits: 2^26 triangles, 65535 instances/submeshes)"); return MRT_ERR_UNSUPPORTED; }
+    std::vector<float> h_pos(std::max<size_t>(V * 3, 3));
+    std::vector<float4> h_nrm(std::max<size_t>(V, 1));
+    std::vector<uint32_t> h_idx(std::max<size_t>(NI, 3));
+    std::vector<SubRec> recs;
+    std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
+    std::vector<float4> h_base(std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
+    size_t vb = 0, tb = 0, ib = 0;
+    for (size_t mi = 0; mi < I; mi++) {
+        const HostMesh &m = meshes[mi];
+        size_t nv = m.positions.size() / 3;
+        memcpy(&h_pos[vb * 3], m.positions.data(), nv * 12);
+        for (size_t v = 0; v < nv; v++) h_nrm[vb + v] = make_float4(m.normals[v * 3], m.normals[v * 3 + 1], m.normals[v * 3 + 2], 0.0f);
+        for (int c = 0; c < 4; c++) h_cols[mi * 4 + c] = make_float4(m.xf[c * 4 + 0], m.xf[c * 4 + 1], m.xf[c * 4 + 2], 0.0f);
+        for (size_t g = 0; g < m.sub_indices.size(); g++) {
+            const auto &ix = m.sub_indices[g];
+            h_base[mi * max_sub + g] = make_float4(m.sub_materials[g].baseColor.x, m.sub_materials[g].baseColor.y, m.sub_materials[g].baseColor.z, 0.0f);
+            h_gbase[mi * max_sub + g] = (uint32_t)tb;
+            if (ix.empty()) continue;
+            memcpy(&h_idx[ib], ix.data(), ix.size() * 4);
+            recs.push_back(SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)ib, (uint32_t)vb, (uint32_t)mi, (uint32_t)g});
+            tb += ix.size() / 3; ib += ix.size();
+        }
+        vb += nv;
+    }
+    out.stats = MRTSceneStats{};
+    out.stats.triangles = T; out.stats.vertices = V; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub;
+    out.stats.max_leaf_tris = opt.max_leaf;
+
+    MRT_HIP(out.normals.alloc(h_nrm.size()));
+    MRT_HIP(out.base_color.alloc(h_base.size()));
+    MRT_HIP(out.geom_base.alloc(h_gbase.size()));
+    MRT_HIP(out.inst_cols.alloc(h_cols.size()));
+    MRT_HIP(out.tri_shade.alloc(std::max<size_t>(T, 1)));
+    MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm.data(), h_nrm.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base.data(), h_base.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase.data(), h_gbase.size() * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols.data(), h_cols.size() * 16, hipMemcpyHostToDevice, stream));
+
+    if (T == 0) {       // empty scene: every ray misses
+        MRT_HIP(out.nodes.alloc(4)); MRT_HIP(out.packets.alloc(3));
+        MRT_HIP(hipStreamSynchronize(stream));
+        out.stats.bvh_nodes = 0; out.stats.bvh_leaves = 0;
+        out.stats.scene_bytes = 0;
+        return MRT_OK;
+    }
+
+    const uint32_t n = (uint32_t)T;
+    const uint32_t nnodes = 2 * n - 1;
+    const uint32_t leaf_base = n - 1;
+    DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
+    DevBuf<float4> tri_world, leaf_lo, leaf_hi, node_lo, node_hi;
+    DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat;
+    DevBuf<uint64_t> keys_a, keys_b;
+    DevBuf<float> cost;
+    DevBuf<uint8_t> collapsed, mask;
+    MRT_HIP(d_pos.alloc(h_pos.size())); MRT_HIP(d_idx.alloc(h_idx.size())); MRT_HIP(d_recs.alloc(recs.size()));
+    MRT_HIP(tri_world.alloc(3 * (size_t)n)); MRT_HIP(leaf_lo.alloc(n)); MRT_HIP(leaf_hi.alloc(n));
+    MRT_HIP(node_lo.alloc(nnodes)); MRT_HIP(node_hi.alloc(nnodes));
+    MRT_HIP(cbounds.alloc(6)); MRT_HIP(keys_a.alloc(n)); MRT_HIP(keys_b.alloc(n)); MRT_HIP(vals_a.alloc(n)); MRT_HIP(vals_b.alloc(n));
+    const uint32_t sort_blocks = cdiv(n, SORT_TILE);
+    MRT_HIP(ghist.alloc(256 * (size_t)sort_blocks));
+    MRT_HIP(parent.alloc(nnodes)); MRT_HIP(left.alloc(n)); MRT_HIP(right.alloc(n)); MRT_HIP(flags.alloc(nnodes));
+    MRT_HIP(ntri.alloc(nnodes)); MRT_HIP(size.alloc(nnodes)); MRT_HIP(cost.alloc(nnodes)); MRT_HIP(collapsed.alloc(nnodes)); MRT_HIP(mask.alloc(nnodes));
+    MRT_HIP(new_index.alloc(nnodes)); MRT_HIP(leaf_offset.alloc(nnodes)); MRT_HIP(stat.alloc(4));
+
+    hipEvent_t ev0, ev1;
+    MRT_HIP(hipEventCreate(&ev0)); MRT_HIP(hipEventCreate(&ev1));
+    MRT_HIP(hipMemcpyAsync(d_pos.p, h_pos.data(), h_pos.size() * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_idx.p, h_idx.data(), h_idx.size() * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(SubRec), hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipEventRecord(ev0, stream));
+    {
+        uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
+        MRT_HIP(hipMemcpyAsync(cbounds.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+    }
+    MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
+    MRT_HIP(hipMemsetAsync(stat.p, 0, stat.bytes(), stream));
+    const int B = 256;
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(n, B)), dim3(B), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, n,
+                       tri_world.p, out.tri_shade.p, leaf_lo.p, leaf_hi.p, cbounds.p);
+    hipLaunchKernelGGL(k_morton, dim3(cdiv(n, B)), dim3(B), 0, stream, leaf_lo.p, leaf_hi.p, cbounds.p, n, keys_a.p, vals_a.p);
+    // 8 passes of 8 bits: 63-bit keys
+    uint64_t *kin = keys_a.p, *kout = keys_b.p; uint32_t *vin = vals_a.p, *vout = vals_b.p;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = pass * 8;
+        hipLaunchKernelGGL(k_sort_hist, dim3(sort_blocks), dim3(SORT_THREADS), 0, stream, kin, n, shift, sort_blocks, ghist.p);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, ghist.p, 256 * sort_blocks);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(sort_blocks), dim3(SORT_THREADS), 0, stream, kin, vin, kout, vout, ghist.p, n, shift, sort_blocks);
+        std::swap(kin, kout); std::swap(vin, vout);
+    }
+    // after 8 swaps the sorted data is back in keys_a / vals_a (kin, vin)
+    TreeArrays t{node_lo.p, node_hi.p, parent.p, left.p, right.p, flags.p, cost.p, ntri.p, size.p, collapsed.p, mask.p};
+    if (n == 1) {
+        MRT_HIP(hipMemsetAsync(parent.p, 0xFF, 4, stream));
+    } else if (opt.builder == 0) {
+        hipLaunchKernelGGL(k_karras, dim3(cdiv(n - 1, B)), dim3(B), 0, stream, kin, (int)n, left.p, right.p, parent.p);
+    } else {
+        // PLOC rounds; cluster arrays double as scratch
+        DevBuf<uint32_t> cid, ncid, nn, keep, pos, bsum, counter;
+        DevBuf<float4> clo, chi, nlo, nhi;
+        MRT_HIP(cid.alloc(n)); MRT_HIP(ncid.alloc(n)); MRT_HIP(nn.alloc(n)); MRT_HIP(keep.alloc(n)); MRT_HIP(pos.alloc(n));
+        MRT_HIP(bsum.alloc(cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc(2));
+        MRT_HIP(clo.alloc(n)); MRT_HIP(chi.alloc(n)); MRT_HIP(nlo.alloc(n)); MRT_HIP(nhi.alloc(n));
+        MRT_HIP(hipMemsetAsync(counter.p, 0, 8, stream));
+        hipLaunchKernelGGL(k_ploc_init, dim3(cdiv(n, B)), dim3(B), 0, stream, n, leaf_base, vin, leaf_lo.p, leaf_hi.p, cid.p, clo.p, chi.p);
+        uint32_t m = n;
+        int guard = 0;
+        while (m > 1) {
+            if (++guard > 4096) { set_error("PLOC did not converge"); return MRT_ERR_HIP; }
+            hipLaunchKernelGGL(k_ploc_nn, dim3(cdiv(m, B)), dim3(B), 0, stream, m, opt.ploc_radius, clo.p, chi.p, nn.p);
+            hipLaunchKernelGGL(k_ploc_merge, dim3(cdiv(m, B)), dim3(B), 0, stream, m, nn.p, cid.p, clo.p, chi.p, keep.p, ncid.p, nlo.p, nhi.p,
+                               counter.p, left.p, right.p, parent.p, node_lo.p, node_hi.p);
+            uint32_t nb = cdiv(m, 1024);
+            hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, keep.p, pos.p, bsum.p, m);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, pos.p, bsum.p, m, counter.p + 1, keep.p);
+            hipLaunchKernelGGL(k_ploc_compact, dim3(cdiv(m, B)), dim3(B), 0, stream, m, keep.p, pos.p, ncid.p, nlo.p, nhi.p, cid.p, clo.p, chi.p);
+            uint32_t new_m = 0;
+            MRT_HIP(hipMemcpyAsync(&new_m, counter.p + 1, 4, hipMemcpyDeviceToHost, stream));
+            MRT_HIP(hipStreamSynchronize(stream));
+            if (new_m >= m || new_m == 0) { set_error("PLOC made no progress"); return MRT_ERR_HIP; }
+            m = new_m;
+        }
+        hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(1), 0, stream, cid.p, parent.p);
+        MRT_HIP(hipStreamSynchronize(stream));   // scratch buffers die at scope exit
+    }
+    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo.p, leaf_hi.p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0);
+    hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
+    // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
+    // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
+    MRT_HIP(out.nodes.alloc(4 * (size_t)nnodes));
+    MRT_HIP(out.packets.alloc(3 * (size_t)n));
+    hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, out.nodes.p);
+    hipLaunchKernelGGL(k_emit_packets, dim3(cdiv(n, B)), dim3(B), 0, stream, vin, leaf_offset.p, leaf_base, n, tri_world.p, out.packets.p);
+    MRT_HIP(hipEventRecord(ev1, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+
+    // ---- stats: find the root (new_index == 0) on the host side from a small readback
+    std::vector<uint32_t> h_new(nnodes);
+    MRT_HIP(hipMemcpy(h_new.data(), new_index.p, nnodes * 4, hipMemcpyDeviceToHost));
+    uint32_t root = NONE;
+    for (uint32_t i = 0; i < nnodes; i++) if (h_new[i] == 0) { root = i; break; }
+    if (root == NONE) { set_error("BVH build produced no root"); return MRT_ERR_HIP; }
+    uint32_t h_size = 0; float h_cost = 0; float4 rlo, rhi; uint32_t h_stat[4];
+    MRT_HIP(hipMemcpy(&h_size, size.p + root, 4, hipMemcpyDeviceToHost));
+    MRT_HIP(hipMemcpy(&h_cost, cost.p + root, 4, hipMemcpyDeviceToHost));
+    MRT_HIP(hipMemcpy(&rlo, node_lo.p + root, 16, hipMemcpyDeviceToHost));
+    MRT_HIP(hipMemcpy(&rhi, node_hi.p + root, 16, hipMemcpyDeviceToHost));
+    MRT_HIP(hipMemcpy(h_stat, stat.p, 16, hipMemcpyDeviceToHost));
+    float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
+    float area = 2.0f * (dx * dy + dy * dz + dz * dx);
+    out.stats.bvh_nodes = h_size;
+    out.stats.bvh_leaves = h_stat[1];
+    out.stats.max_depth = (int32_t)h_stat[0];
+    out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;
+    out.stats.build_ms = ms;
+    out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)n * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
+    return MRT_OK;
+}
+
+}  // namespace mrt

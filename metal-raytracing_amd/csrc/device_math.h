@@ -1,0 +1,113 @@
+// device_math.h — fp32 helpers for the HIP kernels ("mrt-math v1").
+//
+// The translation unit is compiled with -ffp-contract=off: a*b+c stays two roundings unless
+// __builtin_fmaf is spelled.  sqrt and '/' are correctly rounded (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  The *shading* helpers follow the reference's
+// expression order (Raytracing.metal:41-147); the triangle test and the vertex transform use the
+// fused forms.  Box tests may use any formulation (they only have to be conservative).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MRT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+MRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MRT_DEV f3 mk3(float4 a) { return mk3(a.x, a.y, a.z); }
+MRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+MRT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+MRT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+MRT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+MRT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+MRT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MRT_DEV float length3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
+MRT_DEV f3 normalize3(f3 a) { float inv = 1.0f / __builtin_sqrtf(dot3(a, a)); return a * inv; }
+MRT_DEV float saturatef(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+MRT_DEV float fdot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+MRT_DEV f3 fcross(f3 a, f3 b) {
+    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+// ---- Halton (Raytracing.metal:41-56).  Bases come from the prime table (:27-33), held in
+// constant memory together with fp32 reciprocals used only to form the exact integer quotient.
+static __constant__ short c_primes[100] = {
+    2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,  59,  61,  67,  71,
+    73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173,
+    179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281,
+    283, 293, 307, 311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409,
+    419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541};
+
+// Same float recurrence as the reference: f *= 1/b; r += f * (i % b); i /= b.  The integer
+// quotient is formed through an fp32 estimate with an exact fix-up (gfx950 has no integer divide),
+// valid for 0 <= i < 2^24, which covers offset (< 2^20) + frameIndex for 15M frames.
+MRT_DEV float halton_dev(int i, int d) {
+    int b = c_primes[d];
+    float fb = (float)b;
+    float invB = 1.0f / fb;
+    float f = 1.0f, r = 0.0f;
+    if (i >= (1 << 24)) {            // slow exact path, never taken by the renderer
+        while (i > 0) { f = f * invB; r = r + f * (float)(i % b); i = i / b; }
+        return r;
+    }
+    while (i > 0) {
+        int q = (int)((float)i * invB);
+        int rem = i - q * b;
+        while (rem < 0) { rem += b; q -= 1; }
+        while (rem >= b) { rem -= b; q += 1; }
+        f = f * invB;
+        r = r + f * (float)rem;
+        i = q;
+    }
+    return r;
+}
+
+// ---- sin/cos(2*pi*u): quadrant reduction in turns (exact) + Taylor polynomials with fmaf.
+// Stands in for Metal's sincos(2*M_PI_F*u) (Raytracing.metal:79-82).
+MRT_DEV void sincos_2pi_dev(float u, float &s, float &c) {
+    float x = u * 4.0f;
+    float qf = floorf(x + 0.5f);
+    float r = x - qf;
+    float th = r * 1.57079637f;
+    float s2 = th * th;
+    float sp = __builtin_fmaf(s2, 2.75573192e-6f, -1.98412698e-4f);
+    sp = __builtin_fmaf(s2, sp, 8.33333333e-3f);
+    sp = __builtin_fmaf(s2, sp, -1.66666667e-1f);
+    sp = __builtin_fmaf(s2 * th, sp, th);
+    float cp = __builtin_fmaf(s2, -2.75573192e-7f, 2.48015873e-5f);
+    cp = __builtin_fmaf(s2, cp, -1.38888889e-3f);
+    cp = __builtin_fmaf(s2, cp, 4.16666667e-2f);
+    cp = __builtin_fmaf(s2, cp, -0.5f);
+    cp = __builtin_fmaf(s2, cp, 1.0f);
+    int q = ((int)qf) & 3;
+    float ss = (q & 1) ? cp : sp;
+    float cc = (q & 1) ? sp : cp;
+    s = (q == 2 || q == 3) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// Raytracing.metal:78-88
+MRT_DEV f3 sample_cosine_hemisphere_dev(float ux, float uy) {
+    float sin_phi, cos_phi;
+    sincos_2pi_dev(ux, sin_phi, cos_phi);
+    float cos_theta = __builtin_sqrtf(uy);
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    return mk3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
+}
+
+// Raytracing.metal:132-147
+MRT_DEV f3 align_hemisphere_dev(f3 s, f3 n) {
+    f3 right = normalize3(cross3(n, mk3(0.0072f, 1.0f, 0.0034f)));
+    f3 forward = cross3(right, n);
+    return (s.x * right + s.y * n) + s.z * forward;
+}
+
+// per-pixel Halton offset in [0, 2^20) (Renderer.swift:259 uses arc4random; ours is a counter hash)
+MRT_DEV uint32_t seed_hash_dev(uint32_t seed, uint32_t idx) {
+    uint32_t h = idx * 0x9E3779B1u + seed * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h & 0xFFFFFu;
+}
+
+MRT_DEV float xorsign(float v, uint32_t sgn) { return __uint_as_float(__float_as_uint(v) ^ sgn); }

@@ -1,0 +1,61 @@
+// renderer.h — host frame driver state (Renderer.swift:12-43 restated for HIP).
+#pragma once
+#include "scene_device.h"
+#include "host_geometry.h"
+#include <array>
+
+namespace mrt {
+
+struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
+
+struct Renderer {
+    hipStream_t stream = nullptr;
+    const DeviceScene *scene = nullptr;
+    int width = 0, height = 0, max_bounces = 3;
+    uint32_t seed = 1;
+    MRTCamera camera{};
+    uint32_t frame_index = 0;            // Renderer.frameIndex (Renderer.swift:41)
+    int cur = 0;                         // accumulationTargets[0] == accum[cur] after the swap (:332-334)
+    int shard_rank = 0, shard_world = 1;
+    int tiles_local = 0;
+    uint32_t capacity = 0;               // ray-queue capacity = local tiles * 64
+    uint64_t owned_pixels = 0;
+    uint64_t frames_rendered = 0;
+
+    DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
+    DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
+    DevBuf<float4> sample;               // this frame's radiance per pixel
+    DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
+    DevBuf<uint32_t> counters;
+    DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::array<EvPair, 192> ev_ext;
+    int ext_used = 0;
+    bool pending_timing = false;
+    float ms_last = 0, ms_extend_last = 0; uint32_t extend_launches_last = 0;
+
+    Renderer() = default;
+    Renderer(const Renderer &) = delete;
+    ~Renderer();
+    int init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed, int max_bounces);
+    int resize(int w, int h);
+    int alloc_queues();
+    int set_shard(int rank, int world);
+    int render(int n_frames);
+    int wait();
+    int read_accum(float *rgba, size_t nbytes);
+    int copy_accum_to_device(void *dptr, size_t nbytes);
+    int write_accum_from_device(const void *dptr, size_t nbytes);
+    int read_tonemapped(uint8_t *rgba, size_t nbytes);
+    int stats(MRTRenderStats *out);
+    int reset_stats();
+};
+
+int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out);
+int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out);
+int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out);
+int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3);
+int probe_seeds(hipStream_t stream, uint32_t seed, int w, int h, uint32_t *out);
+
+}  // namespace mrt

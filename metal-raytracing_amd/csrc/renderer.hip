@@ -1,0 +1,578 @@
+// renderer.hip — the per-frame hot path as CDNA4 kernels + the host frame driver.
+//
+// Replaces `raytracingKernel` (Raytracing.metal:156-405) and the frame driver around it
+// (Renderer.draw / update / updateUniforms / createTextures, Renderer.swift:216-357).
+// The reference is one megakernel over Apple's opaque intersector; here the frame is a wavefront
+// pipeline over ray / hit records in HBM:
+//
+//   k_raygen      Halton-jittered primary rays                       (Raytracing.metal:171-221)
+//   k_extend      closest hit: stackless rope traversal + Möller–Trumbore   (:230-247, opaque in the reference)
+//   k_shade       normal interpolation, light pick + evaluation, throughput, NEE shadow-ray emit,
+//                 cosine-hemisphere bounce; wave-ballot compaction of both output queues  (:249-391)
+//   k_shadow      any hit; unoccluded contributions are added to the pixel's sample        (:360-374)
+//   k_accumulate  running average with the previous target                                  (:394-403)
+//
+// Record layout (all 16-byte lanes, one dwordx4 per lane per access, fully coalesced):
+//   rayA = {origin.xyz, tmax}   rayB = {direction.xyz, pixel}   thr = {throughput.rgb, -}   (path rays)
+//   hit  = {t, U/|det|, V/|det|, gid}                                                        (16 B)
+//   shadow rays reuse rayA/rayB with tmax = lightDistance - 1e-3; con = {Lc*throughput, -}
+#include "renderer.h"
+#include "device_math.h"
+#include <cstring>
+#include <algorithm>
+
+namespace mrt {
+namespace {
+
+struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + bounce
+    int32_t width, height;
+    uint32_t frameIndex;
+    int32_t lightCount;
+    float4 cam_pos, cam_right, cam_up, cam_fwd;
+    int32_t shard_rank, shard_world;
+    int32_t tiles_x, tiles_local;
+    int32_t bounce, max_bounces;
+};
+
+constexpr uint32_t DEAD_PIXEL = 0xFFFFFFFFu;
+
+// local slot -> pixel: one wave = one 8x8 tile (Renderer.swift:295-300), tiles dealt round-robin to shards
+MRT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, int &x, int &y) {
+    uint32_t lt = slot >> 6, k = slot & 63;
+    if ((int)lt >= fp.tiles_local) return false;
+    uint32_t tile = lt * (uint32_t)fp.shard_world + (uint32_t)fp.shard_rank;
+    uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
+    x = (int)(tx * 8 + (k & 7)); y = (int)(ty * 8 + (k >> 3));
+    return x < fp.width && y < fp.height;
+}
+
+__global__ void k_seed(uint32_t *__restrict__ seeds, uint32_t n, uint32_t seed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) seeds[i] = seed_hash_dev(seed, i);
+}
+
+// ------------------------------------------------------------------ primary rays
+__global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *__restrict__ seeds,
+                                               float4 *__restrict__ rayA, float4 *__restrict__ rayB, float4 *__restrict__ thr,
+                                               float4 *__restrict__ sample) {
+    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) {
+        if ((int)(slot >> 6) < fp.tiles_local) rayB[slot] = make_float4(0, 0, 0, __uint_as_float(DEAD_PIXEL));
+        return;
+    }
+    uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    uint32_t offset = seeds[pix];                                        // Raytracing.metal:175
+    int idx = (int)(offset + fp.frameIndex);
+    float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
+    float px = (float)x + r0, py = (float)y + r1;                        // :204
+    float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
+    uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
+    f3 dir = normalize3((uvx * mk3(fp.cam_right) + uvy * mk3(fp.cam_up)) + mk3(fp.cam_fwd));   // :216-218
+    rayA[slot] = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());      // :214,:220
+    rayB[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pix));
+    thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
+    sample[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                   // :227
+}
+
+// ------------------------------------------------------------------ traversal
+struct TravHit { float t, U, V, ad; uint32_t gid; };
+
+MRT_DEV float safe_inv(float d) {
+    float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+    return 1.0f / a;
+}
+
+// One triangle, Möller–Trumbore in the fused mrt-math form; division only after the barycentric
+// tests pass.  Returns true when 0 <= tmin <= t <= lim.
+MRT_DEV bool tri_test(const float4 *__restrict__ pk, f3 o, f3 d, float tmin, float lim, float &t, float &U, float &V, float &ad, uint32_t &gid) {
+    float4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
+    f3 v0 = mk3(p0), e1 = mk3(p1), e2 = mk3(p2);
+    f3 pv = fcross(d, e2);
+    float det = fdot(e1, pv);
+    if (!(det != 0.0f)) return false;
+    ad = fabsf(det);
+    uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    f3 tv = o - v0;
+    U = xorsign(fdot(tv, pv), sgn);
+    if (!(U >= 0.0f && U <= ad)) return false;
+    f3 q = fcross(tv, e1);
+    V = xorsign(fdot(d, q), sgn);
+    if (!(V >= 0.0f && U + V <= ad)) return false;
+    float T = xorsign(fdot(e2, q), sgn);
+    t = T / ad;
+    gid = __float_as_uint(p0.w);
+    return t >= tmin && t <= lim;
+}
+
+// Stackless traversal of the rope layout (scene_device.h).  State per ray: the current node index
+// and the best hit — no stack, no parent walk.  Closest hit = global min t, ties to the lowest gid,
+// so the result does not depend on the visiting order.
+template <bool ANY>
+MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h) {
+    h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
+    if (s.num_nodes == 0) return false;
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    const uint32_t *__restrict__ nodes_u = reinterpret_cast<const uint32_t *>(s.nodes);
+    uint32_t cur = 0;
+    while (cur != NODE_TERM) {
+        const float4 n0 = s.nodes[4 * (size_t)cur + 0];
+        const float4 n1 = s.nodes[4 * (size_t)cur + 1];
+        const uint32_t esc = nodes_u[16 * (size_t)cur + 8 + oct];
+        // conservative slab test: far side widened by ~4 ulp (Ize 2013), boxes padded at build time
+        float tx0 = (n0.x - o.x) * ix, tx1 = (n1.x - o.x) * ix;
+        float ty0 = (n0.y - o.y) * iy, ty1 = (n1.y - o.y) * iy;
+        float tz0 = (n0.z - o.z) * iz, tz1 = (n1.z - o.z) * iz;
+        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
+        tf = fminf(tf, h.t);
+        if (!(tn <= tf)) { cur = esc; continue; }
+        const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+        if (a & NODE_LEAF) {
+            const uint32_t first = a & 0x7FFFFFFFu;
+            for (uint32_t k = 0; k < b; k++) {
+                float t, U, V, ad; uint32_t gid;
+                if (tri_test(s.packets + 3 * (size_t)(first + k), o, d, tmin, h.t, t, U, V, ad, gid)) {
+                    if (ANY) return true;
+                    if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
+                }
+            }
+            cur = esc;
+        } else {
+            cur = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
+        }
+    }
+    return h.gid != 0xFFFFFFFFu;
+}
+
+// ------------------------------------------------------------------ closest hit over a ray queue
+__global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                                               const uint32_t *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    uint32_t n = count ? *count : capacity;
+    if (i >= n) return;
+    float4 A = rayA[i], B = rayB[i];
+    if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
+    TravHit h;
+    bool hit = traverse<false>(s, mk3(A), mk3(B), 0.0f, A.w, h);
+    hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+
+// wave-ballot compaction: one atomic per wave, lanes write at base + prefix popcount
+MRT_DEV uint32_t wave_compact_slot(bool alive, uint32_t *counter) {
+    unsigned long long m = __ballot(alive);
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)m) - 1;
+    if (alive && (int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
+__global__ void __launch_bounds__(64) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+                                              const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
+                                              const float4 *__restrict__ hits, const uint32_t *__restrict__ count_in, uint32_t capacity,
+                                              float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr, uint32_t *__restrict__ count_next,
+                                              float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon, uint32_t *__restrict__ count_shadow) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    uint32_t n = count_in ? *count_in : capacity;
+    bool active = i < n;
+    float4 H = active ? hits[i] : make_float4(-1, 0, 0, 0);
+    uint32_t gid = __float_as_uint(H.w);
+    active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
+    bool want_shadow = false, want_next = false;
+    f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0);
+    float ldist = 0.0f; uint32_t pix = 0;
+    if (active) {
+        float4 A = rayA[i], B = rayB[i], C = thr[i];
+        pix = __float_as_uint(B.w);
+        uint4 ts = s.tri_shade[gid];
+        uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
+        float bu = H.y, bv = H.z;
+        P = mk3(A) + mk3(B) * H.x;                                       // :261
+        float bw = 1.0f - bu - bv;                                       // :63-64
+        f3 n_obj = (bu * mk3(s.normals[ts.y]) + bv * mk3(s.normals[ts.z])) + bw * mk3(s.normals[ts.x]);   // :66-72
+        f3 c0 = mk3(s.inst_cols[inst * 4 + 0]), c1 = mk3(s.inst_cols[inst * 4 + 1]), c2 = mk3(s.inst_cols[inst * 4 + 2]);
+        f3 n_w = mk3((c0.x * n_obj.x + c1.x * n_obj.y) + c2.x * n_obj.z,
+                     (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
+                     (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
+        nrm = normalize3(n_w);                                           // :268
+        f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
+        int idx = (int)(seeds[pix] + fp.frameIndex);
+        const int dim0 = 2 + fp.bounce * 5;
+        float ls = halton_dev(idx, dim0 + 0);                            // :272
+        int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
+        const LightDev L = s.lights[li];
+        int ltype = __float_as_int(L.position.w);
+        if (ltype == MRTLightTypeAreaLight) {                            // :281-290, :94-128
+            float ax = halton_dev(idx, dim0 + 1) * 2.0f - 1.0f;
+            float ay = halton_dev(idx, dim0 + 2) * 2.0f - 1.0f;
+            f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
+            ldir = sp - P;
+            ldist = length3(ldir);
+            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
+            ldir = ldir * inv;
+            lcol = mk3(L.color) * (inv * inv);
+            lcol = lcol * saturatef(dot3(neg3(ldir), mk3(L.forward)));
+        } else if (ltype == MRTLightTypeSpotlight) {                     // :292-316
+            ldir = mk3(L.position) - P;
+            ldist = length3(ldir);
+            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
+            ldir = ldir * inv;
+            lcol = mk3(0, 0, 0);
+            float spot = dot3(neg3(ldir), mk3(L.dirn));
+            if (spot > L.dirn.w) lcol = (mk3(L.color) * inv) * inv;
+        } else if (ltype == MRTLightTypePointlight) {                    // :317-322
+            ldir = mk3(L.position) - P;
+            ldist = length3(ldir);
+            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
+            ldir = ldir * inv;
+            lcol = (mk3(L.color) * inv) * inv;
+        } else {                                                         // :323-327
+            ldir = neg3(mk3(L.dirn));
+            ldist = __builtin_inff();
+            lcol = mk3(L.color);
+        }
+        lcol = lcol * saturatef(dot3(nrm, ldir));                        // :331
+        lcol = lcol * (float)fp.lightCount;                              // :335
+        color = mk3(C) * surf;                                           // :339
+        want_shadow = length3(lcol) > 0.0001f;                           // :341
+        want_next = fp.bounce + 1 < fp.max_bounces;
+        if (want_next) {
+            float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
+            ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
+        }
+    }
+    uint32_t ss = wave_compact_slot(want_shadow, count_shadow);
+    if (want_shadow) {
+        f3 so = P + nrm * 1e-3f;                                         // :350
+        f3 con = lcol * color;                                           // :372
+        srayA[ss] = make_float4(so.x, so.y, so.z, ldist - 1e-3f);        // :356
+        srayB[ss] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
+        scon[ss] = make_float4(con.x, con.y, con.z, 0.0f);
+    }
+    uint32_t ns = wave_compact_slot(want_next, count_next);
+    if (want_next) {
+        f3 no = P + nrm * 1e-3f;                                         // :390
+        nrayA[ns] = make_float4(no.x, no.y, no.z, __builtin_inff());
+        nrayB[ns] = make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix));   // :391
+        nthr[ns] = make_float4(color.x, color.y, color.z, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------ shadow rays (Raytracing.metal:360-374)
+__global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                               const uint32_t *__restrict__ count, float4 *__restrict__ sample) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= *count) return;
+    float4 A = srayA[i], B = srayB[i];
+    TravHit h;
+    bool occluded = traverse<true>(s, mk3(A), mk3(B), 0.0f, A.w, h);
+    if (!occluded) {
+        uint32_t pix = __float_as_uint(B.w);
+        float4 c = scon[i], a = sample[pix];
+        sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);   // one shadow ray per pixel per bounce: no atomics
+    }
+}
+
+// ------------------------------------------------------------------ accumulate (Raytracing.metal:394-403)
+__global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst) {
+    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    float4 c = sample[pix];
+    if (fp.frameIndex > 0) {
+        float4 p = prev[pix];
+        float fi = (float)fp.frameIndex;
+        float den = (float)(fp.frameIndex + 1);
+        c.x = (c.x + p.x * fi) / den; c.y = (c.y + p.y * fi) / den; c.z = (c.z + p.z * fi) / den;
+    }
+    dst[pix] = make_float4(c.x, c.y, c.z, 1.0f);
+}
+
+// per-frame counter block: [0],[1] = path-queue counts (ping/pong), [2] = shadow count, then per-bounce records
+__global__ void k_frame_counters(uint32_t *__restrict__ c, unsigned long long *__restrict__ totals, int phase, uint32_t primary) {
+    if (phase == 0) { c[0] = 0; c[1] = 0; c[2] = 0; totals[0] += primary; totals[2] += primary; }       // frame start: bounce-0 closest rays = primary rays
+    else if (phase == 1) { totals[1] += c[2]; c[2] = 0; }                                               // after shadow pass
+    else if (phase == 2) { totals[0] += c[0]; c[1] = 0; }                                               // next bounce reads queue 0 -> count closest, reset the other
+    else if (phase == 3) { totals[0] += c[1]; c[0] = 0; }
+}
+
+// Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
+__global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4 *__restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float4 a = accum[(size_t)(h - 1 - y) * w + x];
+    float c[3] = {a.x, a.y, a.z};
+    unsigned char o[3];
+    for (int k = 0; k < 3; k++) { float v = c[k] / (1.0f + c[k]); v = saturatef(v); o[k] = (unsigned char)(v * 255.0f + 0.5f); }
+    out[(size_t)y * w + x] = make_uchar4(o[0], o[1], o[2], 255);
+}
+
+// ------------------------------------------------------------------ query kernels (C-ABI intersect_*)
+__global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, MRTIntersection *__restrict__ out) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    MRTRay r = rays[i];
+    TravHit h;
+    bool hit = traverse<false>(s, mk3(r.origin[0], r.origin[1], r.origin[2]), mk3(r.direction[0], r.direction[1], r.direction[2]), r.min_distance, r.max_distance, h);
+    MRTIntersection o;
+    o._pad = 0;
+    if (hit) {
+        uint4 ts = s.tri_shade[h.gid];
+        uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
+        o.type = 1; o.distance = h.t; o.instance_id = (int32_t)inst; o.geometry_id = (int32_t)geom;
+        o.primitive_id = (int32_t)(h.gid - s.geom_base[inst * (uint32_t)s.max_sub + geom]);
+        o.u = h.U / h.ad; o.v = h.V / h.ad;
+    } else { o.type = 0; o.distance = -1.0f; o.instance_id = o.geometry_id = o.primitive_id = -1; o.u = o.v = 0.0f; }
+    out[i] = o;
+}
+__global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    MRTRay r = rays[i];
+    TravHit h;
+    out[i] = traverse<true>(s, mk3(r.origin[0], r.origin[1], r.origin[2]), mk3(r.direction[0], r.direction[1], r.direction[2]), r.min_distance, r.max_distance, h) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ device-function probes
+__global__ void k_probe_halton(const int32_t *i, const int32_t *d, uint32_t n, float *out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = halton_dev(i[k], d[k]);
+}
+__global__ void k_probe_hemisphere(const float *u2, const float *n3, uint32_t n, float *out3) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    f3 v = align_hemisphere_dev(sample_cosine_hemisphere_dev(u2[2 * k], u2[2 * k + 1]), mk3(n3[3 * k], n3[3 * k + 1], n3[3 * k + 2]));
+    out3[3 * k] = v.x; out3[3 * k + 1] = v.y; out3[3 * k + 2] = v.z;
+}
+
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace
+
+// ====================================================================== Renderer (host)
+int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed_, int max_bounces_) {
+    stream = st; scene = sc; seed = seed_; max_bounces = max_bounces_;
+    MRT_HIP(hipEventCreate(&ev_begin)); MRT_HIP(hipEventCreate(&ev_end));
+    for (auto &e : ev_ext) { MRT_HIP(hipEventCreate(&e.a)); MRT_HIP(hipEventCreate(&e.b)); }
+    MRT_HIP(counters.alloc(16)); MRT_HIP(totals.alloc(4));
+    MRT_HIP(hipMemsetAsync(counters.p, 0, counters.bytes(), stream));
+    MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
+    return resize(w, h);
+}
+
+Renderer::~Renderer() {
+    if (ev_begin) (void)hipEventDestroy(ev_begin);
+    if (ev_end) (void)hipEventDestroy(ev_end);
+    for (auto &e : ev_ext) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+}
+
+int Renderer::resize(int w, int h) {                                   // Renderer.swift:353-356 → createTextures :231-275
+    width = w; height = h;
+    const size_t npix = (size_t)w * h;
+    MRT_HIP(seeds.alloc(npix));
+    MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix)); MRT_HIP(sample.alloc(npix));
+    MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
+    MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
+    MRT_HIP(hipMemsetAsync(sample.p, 0, sample.bytes(), stream));
+    hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256)), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
+    default_camera(w, h, &camera);
+    frame_index = 0; cur = 0;
+    MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
+    frames_rendered = 0;
+    return alloc_queues();
+}
+
+int Renderer::alloc_queues() {
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const int tiles = tiles_x * tiles_y;
+    tiles_local = (tiles - shard_rank + shard_world - 1) / shard_world;
+    if (tiles_local < 0) tiles_local = 0;
+    capacity = (uint32_t)tiles_local * 64u;
+    for (int k = 0; k < 2; k++) { MRT_HIP(rayA[k].alloc(capacity)); MRT_HIP(rayB[k].alloc(capacity)); MRT_HIP(thr[k].alloc(capacity)); }
+    MRT_HIP(hits.alloc(capacity)); MRT_HIP(srayA.alloc(capacity)); MRT_HIP(srayB.alloc(capacity)); MRT_HIP(scon.alloc(capacity));
+    // pixels owned by this shard (edge tiles may be partial)
+    uint64_t owned = 0;
+    for (int lt = 0; lt < tiles_local; lt++) {
+        int tile = lt * shard_world + shard_rank, ty = tile / tiles_x, tx = tile % tiles_x;
+        int pw = std::min(8, width - tx * 8), ph = std::min(8, height - ty * 8);
+        owned += (uint64_t)pw * ph;
+    }
+    owned_pixels = owned;
+    return MRT_OK;
+}
+
+int Renderer::set_shard(int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("invalid shard"); return MRT_ERR_INVALID_ARGUMENT; }
+    shard_rank = rank; shard_world = world;
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
+    MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
+    frame_index = 0; cur = 0;
+    return alloc_queues();
+}
+
+int Renderer::render(int n_frames) {                                   // Renderer.draw(in:) :284-351, n times
+    if (!scene) { set_error("renderer has no scene"); return MRT_ERR_STATE; }
+    SceneView sv = scene->view();
+    if (sv.light_count < 1) { set_error("scene has no lights (lightCount must be >= 1, Raytracing.metal:273)"); return MRT_ERR_STATE; }
+    FrameParams fp{};
+    fp.width = width; fp.height = height; fp.lightCount = sv.light_count;
+    fp.cam_pos = make_float4(camera.position.x, camera.position.y, camera.position.z, 0);
+    fp.cam_right = make_float4(camera.right.x, camera.right.y, camera.right.z, 0);
+    fp.cam_up = make_float4(camera.up.x, camera.up.y, camera.up.z, 0);
+    fp.cam_fwd = make_float4(camera.forward.x, camera.forward.y, camera.forward.z, 0);
+    fp.shard_rank = shard_rank; fp.shard_world = shard_world;
+    fp.tiles_x = (width + 7) / 8; fp.tiles_local = tiles_local; fp.max_bounces = max_bounces;
+    const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
+    uint32_t *c = counters.p;
+    ext_used = 0;
+    MRT_HIP(hipEventRecord(ev_begin, stream));
+    for (int f = 0; f < n_frames; f++) {
+        fp.frameIndex = frame_index;                                    // updateUniforms :216-229
+        hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, 0, (uint32_t)owned_pixels);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, stream, fp, seeds.p, rayA[0].p, rayB[0].p, thr[0].p, sample.p);
+        int q = 0;
+        for (int b = 0; b < max_bounces; b++) {
+            fp.bounce = b;
+            const uint32_t *cin = b == 0 ? nullptr : c + q;             // bounce 0: every slot of the primary queue
+            bool timed = ext_used < (int)ev_ext.size();
+            if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, stream));
+            hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, stream, sv, rayA[q].p, rayB[q].p, cin, capacity, hits.p);
+            if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, stream)); ext_used++; }
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(64), 0, stream, sv, fp, seeds.p, rayA[q].p, rayB[q].p, thr[q].p, hits.p, cin, capacity,
+                               rayA[1 - q].p, rayB[1 - q].p, thr[1 - q].p, c + (1 - q), srayA.p, srayB.p, scon.p, c + 2);
+            hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, stream, sv, srayA.p, srayB.p, scon.p, c + 2, sample.p);
+            hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, 1, 0u);
+            q = 1 - q;
+            if (b + 1 < max_bounces) hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, q == 0 ? 2 : 3, 0u);
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, stream, fp, sample.p, accum[cur].p, accum[1 - cur].p);
+        cur = 1 - cur;                                                  // ping-pong swap :332-334
+        frame_index++; frames_rendered++;
+    }
+    MRT_HIP(hipEventRecord(ev_end, stream));
+    MRT_HIP(hipGetLastError());
+    pending_timing = true;
+    return MRT_OK;
+}
+
+int Renderer::wait() {
+    MRT_HIP(hipStreamSynchronize(stream));
+    if (pending_timing) {
+        float ms = 0;
+        MRT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        ms_last = ms;
+        float ext = 0;
+        for (int k = 0; k < ext_used; k++) { float e = 0; MRT_HIP(hipEventElapsedTime(&e, ev_ext[k].a, ev_ext[k].b)); ext += e; }
+        ms_extend_last = ext; extend_launches_last = (uint32_t)ext_used;
+        pending_timing = false;
+    }
+    return MRT_OK;
+}
+
+int Renderer::read_accum(float *rgba, size_t nbytes) {
+    if (nbytes != (size_t)width * height * 16) { set_error("read_accum: nbytes must be width*height*16"); return MRT_ERR_INVALID_ARGUMENT; }
+    int rc = wait(); if (rc) return rc;
+    MRT_HIP(hipMemcpy(rgba, accum[cur].p, nbytes, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+int Renderer::copy_accum_to_device(void *dptr, size_t nbytes) {
+    if (nbytes != (size_t)width * height * 16) { set_error("copy_accum_to_device: nbytes must be width*height*16"); return MRT_ERR_INVALID_ARGUMENT; }
+    MRT_HIP(hipMemcpyAsync(dptr, accum[cur].p, nbytes, hipMemcpyDeviceToDevice, stream));
+    return MRT_OK;
+}
+int Renderer::write_accum_from_device(const void *dptr, size_t nbytes) {
+    if (nbytes != (size_t)width * height * 16) { set_error("write_accum_from_device: nbytes must be width*height*16"); return MRT_ERR_INVALID_ARGUMENT; }
+    MRT_HIP(hipMemcpyAsync(accum[cur].p, dptr, nbytes, hipMemcpyDeviceToDevice, stream));
+    return MRT_OK;
+}
+int Renderer::read_tonemapped(uint8_t *rgba, size_t nbytes) {
+    if (nbytes != (size_t)width * height * 4) { set_error("read_tonemapped: nbytes must be width*height*4"); return MRT_ERR_INVALID_ARGUMENT; }
+    DevBuf<uchar4> tmp; MRT_HIP(tmp.alloc((size_t)width * height));
+    hipLaunchKernelGGL(k_tonemap, dim3(cdiv(width, 16), cdiv(height, 16)), dim3(16, 16), 0, stream, accum[cur].p, width, height, tmp.p);
+    int rc = wait(); if (rc) return rc;
+    MRT_HIP(hipMemcpy(rgba, tmp.p, nbytes, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+
+int Renderer::stats(MRTRenderStats *out) {
+    int rc = wait(); if (rc) return rc;
+    unsigned long long t[4];
+    MRT_HIP(hipMemcpy(t, totals.p, sizeof t, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->frames = frames_rendered; out->closest_rays = t[0]; out->shadow_rays = t[1]; out->primary_rays = t[2];
+    // 96 B per closest ray, 72 B per shadow ray, 36 B per pixel (20 on frame 0), + one read of the scene per frame
+    uint64_t px = owned_pixels;
+    uint64_t per_frame_px = px * 36;
+    out->bytes_alg = t[0] * 96 + t[1] * 72 + frames_rendered * per_frame_px + frames_rendered * scene->stats.scene_bytes;
+    out->ms_gpu_last = ms_last; out->ms_extend_last = ms_extend_last; out->extend_launches_last = extend_launches_last;
+    return MRT_OK;
+}
+int Renderer::reset_stats() {
+    MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
+    frames_rendered = 0;
+    return MRT_OK;
+}
+
+// ---- scene queries
+int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out) {
+    if (n == 0) return MRT_OK;
+    DevBuf<MRTRay> d_r; DevBuf<MRTIntersection> d_o;
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
+    MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_query_closest, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    MRT_HIP(hipMemcpyAsync(out, d_o.p, n * sizeof(MRTIntersection), hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out) {
+    if (n == 0) return MRT_OK;
+    DevBuf<MRTRay> d_r; DevBuf<int32_t> d_o;
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
+    MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_query_any, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    MRT_HIP(hipMemcpyAsync(out, d_o.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+
+int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out) {
+    if (n == 0) return MRT_OK;
+    DevBuf<int32_t> di, dd; DevBuf<float> dout;
+    MRT_HIP(di.alloc(n)); MRT_HIP(dd.alloc(n)); MRT_HIP(dout.alloc(n));
+    MRT_HIP(hipMemcpyAsync(di.p, i, n * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(dd.p, d, n * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_probe_halton, dim3(cdiv(n, 256)), dim3(256), 0, stream, di.p, dd.p, (uint32_t)n, dout.p);
+    MRT_HIP(hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    return MRT_OK;
+}
+int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3) {
+    if (n == 0) return MRT_OK;
+    DevBuf<float> du, dn, dout;
+    MRT_HIP(du.alloc(2 * n)); MRT_HIP(dn.alloc(3 * n)); MRT_HIP(dout.alloc(3 * n));
+    MRT_HIP(hipMemcpyAsync(du.p, u2, n * 8, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(dn.p, n3, n * 12, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_probe_hemisphere, dim3(cdiv(n, 256)), dim3(256), 0, stream, du.p, dn.p, (uint32_t)n, dout.p);
+    MRT_HIP(hipMemcpyAsync(out3, dout.p, n * 12, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    return MRT_OK;
+}
+int probe_seeds(hipStream_t stream, uint32_t seed, int w, int h, uint32_t *out) {
+    size_t n = (size_t)w * h;
+    if (n == 0) return MRT_OK;
+    DevBuf<uint32_t> d; MRT_HIP(d.alloc(n));
+    hipLaunchKernelGGL(k_seed, dim3(cdiv(n, 256)), dim3(256), 0, stream, d.p, (uint32_t)n, seed);
+    MRT_HIP(hipMemcpyAsync(out, d.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    return MRT_OK;
+}
+
+}  // namespace mrt

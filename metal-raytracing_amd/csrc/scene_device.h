@@ -1,0 +1,106 @@
+// scene_device.h — HBM data layout of a committed scene, shared by the BVH builder (bvh_build.hip)
+// and the render kernels (render_kernels.hip).  DESIGN.md §4 documents every array.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mrt_abi.h"
+
+namespace mrt {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define MRT_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) return ::mrt::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- traversal node: 64 B, one per box ("rope" layout: every node carries, for each of the 8
+// ray-direction octants, the node to continue with once its subtree is finished).
+//   word 0..2  lo.xyz     word 3  a : leaf ? (NODE_LEAF | first packet) : index of the left child
+//   word 4..6  hi.xyz     word 7  b : leaf ? triangle count : (near-mask << 24) | index of the right child
+//   word 8..15 esc[8]                 : next node per octant, NODE_TERM = traversal finished
+// near-mask bit o = 1 when the RIGHT child is visited first by rays of octant o
+// (octant bit k set <=> direction component k negative).
+constexpr uint32_t NODE_LEAF = 0x80000000u;
+constexpr uint32_t NODE_TERM = 0xFFFFFFFFu;
+constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
+
+// ---- triangle packet: 48 B, leaf-contiguous, already in world space and in Möller–Trumbore form
+//   {v0.xyz, gid} {e1.xyz, -} {e2.xyz, -}
+// ---- shading record per global triangle id (16 B): vertex ids into `normals` + (instance<<16 | geometry)
+
+struct LightDev {            // 96 B, derived once per mrt_scene_set_lights from the 128-B MRTLight
+    float4 position;         // .w = type (as int bits)
+    float4 color;
+    float4 forward;          // area light (un-normalised, as the reference uses it)
+    float4 right;
+    float4 up;
+    float4 dirn;             // spot: normalize(direction), .w = cos(coneAngle); sun: normalize(direction)
+};
+
+struct SceneView {           // passed by value to kernels
+    const float4 *nodes;         // 4 x float4 per node
+    const float4 *packets;       // 3 x float4 per triangle, leaf order
+    const uint4 *tri_shade;      // per gid
+    const float4 *normals;       // object space, concatenated over meshes (float3 stride 16, Mesh.swift:27-29)
+    const float4 *base_color;    // per resource slot = instance*max_sub + geometry (Renderer.swift:139)
+    const float4 *inst_cols;     // 3 x float4 per instance: columns 0..2 of the 4x3 transform
+    const uint32_t *geom_base;   // per resource slot: first gid
+    const LightDev *lights;
+    uint32_t num_nodes;
+    uint32_t num_tris;
+    int32_t light_count;
+    int32_t max_sub;
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct HostMesh {                  // what the caller handed over through mrt_scene_add_mesh / _add_submesh
+    std::vector<float> positions;  // packed xyz, object space
+    std::vector<float> normals;    // packed xyz, object space
+    float xf[16];                  // column-major, last row forced to (0,0,0,1)
+    std::vector<std::vector<uint32_t>> sub_indices;
+    std::vector<MRTMaterial> sub_materials;
+};
+
+struct BuildOptions {
+    int builder = 1;          // 0 = Karras radix tree (plain LBVH), 1 = PLOC agglomeration over the Morton order
+    int max_leaf = 4;         // SAH leaf collapse limit
+    float cost_trav = 1.0f;   // SAH constants
+    float cost_isect = 1.0f;
+    int ploc_radius = 16;
+};
+
+struct DeviceScene {
+    DevBuf<float4> nodes, packets, normals, base_color, inst_cols;
+    DevBuf<uint4> tri_shade;
+    DevBuf<uint32_t> geom_base;
+    DevBuf<LightDev> lights;
+    int light_count = 0;
+    MRTSceneStats stats{};
+    SceneView view() const;
+};
+
+// bvh_build.hip
+int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out);
+
+}  // namespace mrt

@@ -1,0 +1,185 @@
+"""Host-side mirror of Renderer (Renderer.swift:12-357) over the C ABI.
+
+`Renderer(size, scene)` does what `Renderer.init?(metalView:)` does (device + queue, scene,
+targets, buffers, acceleration structures); `draw()` is `draw(in:)` — one frame: uniforms,
+dispatch, ping-pong swap.  There is no MTKView: the tonemap pass writes RGBA8 to host memory
+instead of a drawable (`tonemapped()`).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._ffi import Camera, Light, RenderStats, SceneStats, check, lib, ptr
+from .scene import DragonScene, Scene
+
+
+class Context:
+    """MTLCreateSystemDefaultDevice + makeCommandQueue (Renderer.swift:46-59)."""
+
+    def __init__(self, device=0):
+        self.handle = C.c_void_p()
+        check(lib.mrt_context_create(int(device), C.byref(self.handle)))
+        self.device = int(device)
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        check(lib.mrt_context_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def set_stream(self, hip_stream):
+        check(lib.mrt_context_set_stream(self.handle, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def close(self):
+        if self.handle:
+            lib.mrt_context_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class DeviceScene:
+    """The committed device-side scene: geometry upload + createAccelerationStructures
+    (Renderer.swift:184-214)."""
+
+    def __init__(self, ctx, scene, options=None):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        check(lib.mrt_scene_create(ctx.handle, C.byref(self.handle)))
+        for k, v in (options or {}).items():
+            check(lib.mrt_scene_set_option(self.handle, k.encode(), float(v)))
+        for mesh in scene.meshes:
+            mid = C.c_int32()
+            pos = np.ascontiguousarray(mesh.positions, np.float32)
+            nrm = np.ascontiguousarray(mesh.normals, np.float32)
+            xf = np.ascontiguousarray(mesh.transform.reshape(16), np.float32)
+            check(lib.mrt_scene_add_mesh(self.handle, ptr(pos), 12, ptr(nrm), 12, pos.shape[0], ptr(xf), C.byref(mid)))
+            for sub in mesh.submeshes:
+                idx = np.ascontiguousarray(sub.indices, np.uint32)
+                check(lib.mrt_mesh_add_submesh(self.handle, mid.value, ptr(idx), idx.shape[0], C.byref(sub.material), None))
+        self.set_lights(scene.lights)
+        check(lib.mrt_scene_commit(self.handle))
+
+    def set_lights(self, lights):
+        arr = (Light * max(1, len(lights)))(*lights)
+        check(lib.mrt_scene_set_lights(self.handle, arr, len(lights)))
+
+    @property
+    def stats(self):
+        s = SceneStats()
+        check(lib.mrt_scene_stats(self.handle, C.byref(s)))
+        return s
+
+    def intersect_closest(self, rays):
+        """rays: (n, 8) float32 [ox,oy,oz,tmin,dx,dy,dz,tmax] → structured array of Intersection."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], dtype=INTERSECTION_DTYPE)
+        check(lib.mrt_scene_intersect_closest(self.handle, ptr(rays), rays.shape[0], ptr(out)))
+        return out
+
+    def intersect_any(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], dtype=np.int32)
+        check(lib.mrt_scene_intersect_any(self.handle, ptr(rays), rays.shape[0], ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib.mrt_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+INTERSECTION_DTYPE = np.dtype([("type", np.int32), ("distance", np.float32), ("instance_id", np.int32), ("geometry_id", np.int32),
+                               ("primitive_id", np.int32), ("u", np.float32), ("v", np.float32), ("_pad", np.int32)])
+
+
+class Renderer:
+    """Renderer.swift:12-357."""
+
+    maxFramesInFlight = 3                                     # Renderer.swift:33 (frames are queued on one HIP stream)
+
+    def __init__(self, size, scene=None, device=0, seed=1, max_bounces=3, ctx=None, scene_options=None):
+        self.size = (int(size[0]), int(size[1]))
+        self.scene = scene if scene is not None else DragonScene(self.size)   # Renderer.swift:61
+        self._own_ctx = ctx is None
+        self.ctx = ctx or Context(device)
+        self.device_scene = DeviceScene(self.ctx, self.scene, scene_options)
+        self.handle = C.c_void_p()
+        check(lib.mrt_renderer_create(self.ctx.handle, self.device_scene.handle, self.size[0], self.size[1], int(seed), int(max_bounces), C.byref(self.handle)))
+        self.max_bounces = int(max_bounces)
+        self.set_camera(self.scene.camera)
+
+    # -- Renderer.frameIndex (Renderer.swift:41)
+    @property
+    def frameIndex(self):
+        v = C.c_uint32()
+        check(lib.mrt_renderer_frame_index(self.handle, C.byref(v)))
+        return v.value
+
+    @frameIndex.setter
+    def frameIndex(self, v):
+        check(lib.mrt_renderer_set_frame_index(self.handle, int(v)))
+
+    def set_camera(self, camera: Camera):
+        check(lib.mrt_renderer_set_camera(self.handle, C.byref(camera)))
+
+    def set_shard(self, rank, world):
+        check(lib.mrt_renderer_set_shard(self.handle, int(rank), int(world)))
+
+    def drawableSizeWillChange(self, size):                   # Renderer.swift:353-356
+        self.size = (int(size[0]), int(size[1]))
+        check(lib.mrt_renderer_resize(self.handle, self.size[0], self.size[1]))
+        self.scene.updateUniforms(self.size)
+        self.set_camera(self.scene.camera)
+
+    def draw(self, frames=1, wait=False):                     # Renderer.swift:284-351
+        check(lib.mrt_renderer_render(self.handle, int(frames)))
+        if wait:
+            self.wait()
+
+    def wait(self):
+        check(lib.mrt_renderer_wait(self.handle))
+
+    def accumulation(self):
+        """accumulationTargets[0] (Renderer.swift:332-334): (h, w, 4) float32, row 0 = bottom of the image."""
+        out = np.empty((self.size[1], self.size[0], 4), np.float32)
+        check(lib.mrt_renderer_read_accum(self.handle, ptr(out), out.nbytes))
+        return out
+
+    def tonemapped(self):
+        """fragmentShader (Shaders.metal:39-52): (h, w, 4) uint8, top row first."""
+        out = np.empty((self.size[1], self.size[0], 4), np.uint8)
+        check(lib.mrt_renderer_read_tonemapped_rgba8(self.handle, ptr(out), out.nbytes))
+        return out
+
+    def copy_accum_to(self, device_ptr, nbytes):
+        check(lib.mrt_renderer_copy_accum_to_device(self.handle, C.c_void_p(device_ptr), nbytes))
+
+    def write_accum_from(self, device_ptr, nbytes):
+        check(lib.mrt_renderer_write_accum_from_device(self.handle, C.c_void_p(device_ptr), nbytes))
+
+    @property
+    def stats(self):
+        s = RenderStats()
+        check(lib.mrt_renderer_stats(self.handle, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        check(lib.mrt_renderer_reset_stats(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib.mrt_renderer_destroy(self.handle)
+            self.handle = C.c_void_p()
+        self.device_scene.close()
+        if self._own_ctx:
+            self.ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def save_png(path, rgba8):
+    from PIL import Image
+    Image.fromarray(rgba8, "RGBA").save(path)
