@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: Mrays/s (closest-hit + shadow rays) and ms/frame,
+DragonScene 1920x1080 spp=1 (configs[1]).
+
+A "step" is one frame (one pass of the hot path over all pixels at 1 spp): raygen, then per bounce
+extend / shade / shadow, then accumulate — `Renderer.draw(in:)` of the reference
+(Renderer.swift:284-351).  Inputs (scene, BVH, seeds) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU; the image is sharded by 8x8 screen tile (tile_id % N == rank), the K
+frames are accumulated locally and ONE RCCL reduce of the RGBA32F radiance buffer assembles the
+image on rank 0 inside the timed region.  Total work is fixed → "strong" scaling.
+`--shard sample` instead gives every rank full frames of a disjoint frame-index range ("weak").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_CLOSEST_RAY = 96     # ray 2x32 B + hit 2x16 B
+BYTES_PER_SHADOW_RAY = 72
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "dragon4", "garden"])
+    ap.add_argument("--bounces", type=int, default=3)
+    ap.add_argument("--shard", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--builder", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mrt, scene, w, h, bounces, threads):
+    """The oracle (CPU restatement, kind 'port') on the GPU box's host cores: one full frame of the
+    same workload, same seeds.  Reported, never the thing shipped."""
+    import oracle as O
+    O.build_oracle()
+    threads = threads or (os.cpu_count() or 1)
+    osc = O.OracleScene(mrt.flatten_scene(scene), scene.lights)
+    r = O.OracleRenderer(osc, w, h, seed=1, max_bounces=bounces, camera=scene.camera)
+    t0 = time.perf_counter()
+    r.render(1, threads=threads)
+    dt = time.perf_counter() - t0
+    closest, shadow = r.counters()
+    img = r.accumulation()
+    return {"value": (closest + shadow) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"1 full frame of the same workload ({w}x{h} spp=1, {bounces} bounces, {closest + shadow} rays) in {dt:.2f} s",
+            "ms_per_frame": dt * 1e3}, img
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        a.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif a.gpus > 1:
+        sys.exit("launch with torch.distributed.run for --gpus > 1")
+
+    import metal_raytracing_amd as mrt
+    w, h = a.width, a.height
+    scene = mrt.SCENES[a.scene]((w, h))
+    opts = {} if a.builder is None else {"builder": a.builder}
+    r = mrt.Renderer((w, h), scene, device=local_rank, seed=1, max_bounces=a.bounces, scene_options=opts)
+    sst = r.device_scene.stats
+    if world > 1:
+        if a.shard == "tile":
+            r.set_shard(rank, world)
+        else:
+            r.set_option("sample_offset", rank * (a.warmup + a.steps))
+
+    def sync():
+        r.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    npix = w * h
+    accum_t = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+
+    # ---- warmup
+    r.draw(a.warmup, wait=True)
+    if world > 1:
+        r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
+        dist.reduce(accum_t, dst=0)
+    r.reset_stats()
+    sync()
+    # ---- timed region: exactly K steps (+ the one reduce of the output image for N > 1)
+    t0 = time.perf_counter()
+    done = 0
+    ext_ms, ext_launches = 0.0, 0
+    while done < a.steps:
+        k = min(64, a.steps - done)          # 64 frames x 3 bounces = 192 per-launch event pairs per batch
+        r.draw(k)
+        r.wait()
+        st = r.stats
+        ext_ms += st.ms_extend_last; ext_launches += st.extend_launches_last
+        done += k
+    if world > 1:
+        r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
+        dist.reduce(accum_t, dst=0)
+        if a.shard == "sample" and rank == 0:
+            accum_t /= world
+    sync()
+    dt = time.perf_counter() - t0
+    st = r.stats
+    rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        rays = rays.cuda(); tmax = tmax.cuda()
+        dist.all_reduce(rays); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rays = rays.cpu(); tmax = tmax.cpu()
+    dt = float(tmax[0])
+    closest, shadow, primary = (float(x) for x in rays)
+    steps_total = a.steps * (world if a.shard == "sample" and world > 1 else 1)
+
+    if rank == 0:
+        value = (closest + shadow) / dt / 1e6
+        # dominant kernel: k_extend (closest-hit traversal).  Algorithmic bytes per launch = 96 B x rays in the launch.
+        launches_total = a.steps * a.bounces
+        rays_per_launch = st.closest_rays / launches_total
+        avg_ms = ext_ms / max(1, ext_launches)
+        achieved = BYTES_PER_CLOSEST_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        frame_bytes = st.bytes_alg / max(1, st.frames)
+        out = {
+            "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True,
+            "scaling": "weak" if (a.shard == "sample" and world > 1) else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.scene} scene {w}x{h} spp=1, {a.bounces} bounces, closest-hit + shadow rays counted on device",
+                       "scene_sources": scene.describe(), "triangles": int(sst.triangles), "bvh_nodes": int(sst.bvh_nodes),
+                       "bvh_build_ms": round(sst.build_ms, 3), "sah_cost": round(sst.sah_cost, 3),
+                       "rays_per_frame": {"closest": closest / steps_total, "shadow": shadow / steps_total, "primary": primary / steps_total},
+                       "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
+                       "frame_bytes_alg": frame_bytes, "frame_alg_GBps": round(frame_bytes * st.frames / dt / 1e9, 2),
+                       "device": r.ctx.device_name},
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
+                         "launches_timed": ext_launches},
+        }
+        if a.png:
+            mrt.save_png(a.png, r.tonemapped())
+        if world == 1 and not a.no_cpu_baseline:
+            cb, ref = cpu_baseline(mrt, scene, w, h, a.bounces, a.cpu_threads)
+            out["cpu_baseline"] = cb
+            # parity of frame 0 against the oracle, same seeds (informational; the gates are tests/ -m gpu)
+            r0 = mrt.Renderer((w, h), scene, ctx=r.ctx, seed=1, max_bounces=a.bounces, scene_options=opts)
+            r0.draw(1, wait=True)
+            g = r0.accumulation(); r0.close()
+            d = np.abs(g[..., :3].astype(np.float64) - ref[..., :3])
+            out["parity"] = {"bit_exact_pixels": float((g.view(np.uint32) == ref.view(np.uint32)).all(-1).mean()),
+                             "rmse": float(np.sqrt((d ** 2).sum(-1).mean())), "within_1e-3": float((d.max(-1) <= 1e-3).mean())}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    r.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,7 @@ struct Renderer {
     uint32_t seed = 1;
     MRTCamera camera{};
     uint32_t frame_index = 0;            // Renderer.frameIndex (Renderer.swift:41)
+    uint32_t sample_offset = 0;          // added to frame_index for the Halton index only (sample-index sharding)
     int cur = 0;                         // accumulationTargets[0] == accum[cur] after the swap (:332-334)
     int shard_rank = 0, shard_world = 1;
     int tiles_local = 0;

@@ -26,7 +26,8 @@ namespace {
 
 struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + bounce
     int32_t width, height;
-    uint32_t frameIndex;
+    uint32_t frameIndex;        // accumulation weight (Raytracing.metal:395-401)
+    uint32_t sampleIndex;       // Halton index = seed offset + sampleIndex (:202); == frameIndex unless sample-sharded
     int32_t lightCount;
     float4 cam_pos, cam_right, cam_up, cam_fwd;
     int32_t shard_rank, shard_world;
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *_
     }
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     uint32_t offset = seeds[pix];                                        // Raytracing.metal:175
-    int idx = (int)(offset + fp.frameIndex);
+    int idx = (int)(offset + fp.sampleIndex);
     float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
     float px = (float)x + r0, py = (float)y + r1;                        // :204
     float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(64) k_shade(SceneView s, FrameParams fp, const
                      (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
         nrm = normalize3(n_w);                                           // :268
         f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
-        int idx = (int)(seeds[pix] + fp.frameIndex);
+        int idx = (int)(seeds[pix] + fp.sampleIndex);
         const int dim0 = 2 + fp.bounce * 5;
         float ls = halton_dev(idx, dim0 + 0);                            // :272
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
@@ -434,6 +435,7 @@ int Renderer::render(int n_frames) {                                   // Render
     MRT_HIP(hipEventRecord(ev_begin, stream));
     for (int f = 0; f < n_frames; f++) {
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229
+        fp.sampleIndex = frame_index + sample_offset;
         hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, 0, (uint32_t)owned_pixels);
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, stream, fp, seeds.p, rayA[0].p, rayB[0].p, thr[0].p, sample.p);
         int q = 0;

@@ -121,6 +121,9 @@ class Renderer:
     def set_camera(self, camera: Camera):
         check(lib.mrt_renderer_set_camera(self.handle, C.byref(camera)))
 
+    def set_option(self, key, value):
+        check(lib.mrt_renderer_set_option(self.handle, key.encode(), float(value)))
+
     def set_shard(self, rank, world):
         check(lib.mrt_renderer_set_shard(self.handle, int(rank), int(world)))
 

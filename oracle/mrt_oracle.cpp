@@ -425,10 +425,10 @@ struct StageDump {          // optional per-bounce dump for stage-level parity t
     int max_bounces = 0;
 };
 
-static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t offset, int px, int py, int max_bounces,
+static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t sample_index, uint32_t offset, int px, int py, int max_bounces,
                       bool brute, Counters &cnt, float *dump) {
     const float INF = std::numeric_limits<float>::infinity();
-    int idx = (int)(offset + u.frameIndex);
+    int idx = (int)(offset + sample_index);           // == u.frameIndex unless sample-sharded
     float r0 = halton(idx, 0), r1 = halton(idx, 1);                       // :202-203
     float pxf = (float)px + r0, pyf = (float)py + r1;                      // :204
     float uvx = pxf / (float)u.width, uvy = pyf / (float)u.height;         // :207
@@ -515,6 +515,7 @@ struct Renderer {
     uint32_t frameIndex = 0;
     Counters total;
     int shard_rank = 0, shard_world = 1;
+    uint32_t sample_offset = 0;
 };
 
 static void default_camera(int w, int h, MRTCamera *c) {       // Scene.swift:40-57
@@ -547,7 +548,7 @@ static void render_frames(Renderer &r, int nframes, int nthreads, bool brute, fl
                     }
                     size_t p = (size_t)y * r.w + x;
                     float *dp = dump ? dump + p * (size_t)r.max_bounces * 16 : nullptr;
-                    V3 c = trace_pixel(s, u, r.seeds[p], x, y, r.max_bounces, brute, cnts[tid], dp);
+                    V3 c = trace_pixel(s, u, u.frameIndex + r.sample_offset, r.seeds[p], x, y, r.max_bounces, brute, cnts[tid], dp);
                     float *a = &r.accum[p * 4];
                     if (u.frameIndex > 0) {                                        // :395-401
                         float fi = (float)u.frameIndex;
@@ -632,6 +633,7 @@ void orc_renderer_destroy(void *r) { delete (Renderer *)r; }
 void orc_renderer_set_camera(void *rp, const MRTCamera *c) { ((Renderer *)rp)->cam = *c; }
 void orc_renderer_set_shard(void *rp, int rank, int world) { Renderer *r = (Renderer *)rp; r->shard_rank = rank; r->shard_world = world; }
 void orc_renderer_set_frame_index(void *rp, uint32_t fi) { ((Renderer *)rp)->frameIndex = fi; }
+void orc_renderer_set_sample_offset(void *rp, uint32_t so) { ((Renderer *)rp)->sample_offset = so; }
 void orc_renderer_set_accum(void *rp, const float *rgba) { Renderer *r = (Renderer *)rp; memcpy(r->accum.data(), rgba, r->accum.size() * 4); }
 // dump: NULL or w*h*max_bounces*16 floats (per-bounce stage records; only the last frame's survive)
 void orc_renderer_render(void *rp, int nframes, int nthreads, int brute, float *dump) {

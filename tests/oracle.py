@@ -45,6 +45,7 @@ def lib():
         l.orc_renderer_set_camera.argtypes = [P, P]
         l.orc_renderer_set_shard.argtypes = [P, I, I]
         l.orc_renderer_set_frame_index.argtypes = [P, U]
+        l.orc_renderer_set_sample_offset.argtypes = [P, U]
         l.orc_renderer_set_accum.argtypes = [P, P]
         l.orc_renderer_render.argtypes = [P, I, I, I, P]
         l.orc_renderer_read_accum.argtypes = [P, P]
@@ -119,6 +120,9 @@ class OracleRenderer:
 
     def set_frame_index(self, fi):
         lib().orc_renderer_set_frame_index(self.h, fi)
+
+    def set_sample_offset(self, so):
+        lib().orc_renderer_set_sample_offset(self.h, so)
 
     def render(self, frames=1, threads=0, brute=False, dump=False):
         d = None

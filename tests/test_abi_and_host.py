@@ -1,0 +1,156 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol
+include/mrt_abi.h declares, the data contract has the reference's layout (ShaderTypes.h:60-107),
+and the host geometry helpers (OBJ/MTL reader, T*R*S, camera, procedural meshes) agree with
+independent restatements.  No compute calls: there is no GPU here."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = os.path.join(ROOT, "assets", "Resources")
+
+
+def test_library_exports_every_declared_symbol(mrt):
+    hdr = open(os.path.join(ROOT, "include", "mrt_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    raw = C.CDLL(mrt.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in mrt_abi.h but not exported"
+    from metal_raytracing_amd import _ffi
+    assert declared == set(_ffi.SIGNATURES), "ctypes table and header disagree"
+    assert mrt.lib.mrt_abi_version() == 1
+
+
+def test_struct_layout_matches_shader_types(mrt):
+    L, M, U, Cm = mrt.Light, mrt.Material, mrt.Uniforms, mrt.Camera
+    assert C.sizeof(Cm) == 64 and C.sizeof(L) == 128 and C.sizeof(U) == 96 and C.sizeof(M) == 64
+    assert [getattr(L, f).offset for f in ("type", "position", "color", "forward", "right", "up", "coneAngle", "direction")] == [0, 16, 32, 48, 64, 80, 96, 112]
+    assert [getattr(U, f).offset for f in ("width", "height", "blocksWide", "frameIndex", "lightCount", "camera")] == [0, 4, 8, 12, 16, 32]
+    assert [getattr(M, f).offset for f in ("baseColor", "specular", "emission", "specularExponent", "refractionIndex", "dissolve")] == [0, 16, 32, 48, 52, 56]
+    assert [getattr(Cm, f).offset for f in ("position", "right", "up", "forward")] == [0, 16, 32, 48]
+    assert mrt.LightType.sunlight == 1 and mrt.LightType.spotlight == 2 and mrt.LightType.pointlight == 3 and mrt.LightType.areaLight == 4
+
+
+def test_no_gpu_means_loud_failure_not_fallback(mrt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mrt.MRTError) as e:
+        mrt.Context(0)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "metal-raytracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "mrt_oracle" not in txt and "import oracle" not in txt and "oracle/" not in txt.replace("nothing under oracle/", ""), f
+
+
+# ---------------------------------------------------------------- OBJ/MTL reader vs an independent parser
+def _py_obj(path):
+    V, N, faces, mats, cur = [], [], [], [], None
+    for line in open(path):
+        t = line.split()
+        if not t: continue
+        if t[0] == "v": V.append([float(x) for x in t[1:4]])
+        elif t[0] == "vn": N.append([float(x) for x in t[1:4]])
+        elif t[0] == "usemtl": cur = t[1]; mats.append([cur, 0])
+        elif t[0] == "f":
+            if not mats: mats.append(["", 0])
+            vs = []
+            for c in t[1:]:
+                p = c.split("/")
+                vi = int(p[0]); ni = int(p[2]) if len(p) > 2 and p[2] else 0
+                vs.append((vi - 1 if vi > 0 else len(V) + vi, ni - 1 if ni > 0 else (len(N) + ni if ni < 0 else -1)))
+            for k in range(1, len(vs) - 1):
+                faces.append((vs[0], vs[k], vs[k + 1])); mats[-1][1] += 1
+    return np.array(V, np.float32), np.array(N, np.float32), faces, [m for m in mats if m[1]]
+
+
+@pytest.mark.parametrize("name,tris", [("plane", 2), ("plane-back", 2), ("sphere", 4900), ("train", 3624), ("treefir", 352), ("teapot", 15704)])
+def test_obj_reader(mrt, name, tris):
+    pos, nrm, subs = mrt.load_obj(os.path.join(RES, name + ".obj"))
+    V, N, faces, mats = _py_obj(os.path.join(RES, name + ".obj"))
+    assert sum(s.triangleCount for s in subs) == tris == len(faces)                 # counts of SURVEY §8 a-12
+    assert [s.name for s in subs] == [m[0] for m in mats] and [s.triangleCount for s in subs] == [m[1] for m in mats]
+    idx = np.concatenate([s.indices for s in subs])
+    assert idx.max() < len(pos)
+    assert len(pos) == len({(a, b) for f in faces for (a, b) in f})                 # one vertex per distinct (v,vn)
+    for k in np.random.default_rng(0).integers(0, len(faces), 200):
+        for c in range(3):
+            vi, ni = faces[k][c]
+            assert np.array_equal(pos[idx[k, c]], V[vi])
+            if ni >= 0: assert np.array_equal(nrm[idx[k, c]], N[ni])
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=2e-3)
+
+
+def test_mtl_reader(mrt):
+    _, _, subs = mrt.load_obj(os.path.join(RES, "train.obj"))
+    kd = {s.name: s.material.baseColor.tolist() for s in subs}
+    assert np.allclose(kd["Body"], [0.913099, 0.597202, 0.059511]) and np.allclose(kd["Hub"], [0.8, 0.8, 0.8])
+    m = [s for s in subs if s.name == "Body"][0].material
+    assert abs(m.specularExponent - 37.254902) < 1e-5 and m.refractionIndex == 1.0 and m.dissolve == 1.0 and np.allclose(m.specular.tolist(), [0.2] * 3)
+    _, _, subs = mrt.load_obj(os.path.join(RES, "plane.obj"))
+    assert np.allclose(subs[0].material.baseColor.tolist(), [0.5, 0.5, 0.5])        # plane.mtl:7
+    _, nrm, subs = mrt.load_obj(os.path.join(RES, "teapot.obj"))                    # default.mtl missing, no vn
+    assert np.allclose(subs[0].material.baseColor.tolist(), [0.8, 0.8, 0.8]) and len(subs) == 2
+
+
+def test_obj_errors(mrt, tmp_path):
+    with pytest.raises(mrt.MRTError) as e:
+        mrt.load_obj(str(tmp_path / "missing.obj"))
+    assert e.value.code == 4
+    p = tmp_path / "bad.obj"; p.write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(mrt.MRTError):
+        mrt.load_obj(str(p))
+    p = tmp_path / "empty.obj"; p.write_text("v 0 0 0\n")
+    with pytest.raises(mrt.MRTError):
+        mrt.load_obj(str(p))
+    p = tmp_path / "neg.obj"; p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf -4 -3 -1 -2\n")
+    pos, nrm, subs = mrt.load_obj(str(p))
+    assert subs[0].triangleCount == 2 and np.allclose(np.abs(nrm[:, 2]), 1)
+
+
+def test_procedural_meshes(mrt):
+    pos, nrm, subs = mrt.dragon_proxy()
+    assert subs[0].triangleCount == 871414 and len(subs) == 1                        # Stanford dragon count
+    assert np.allclose(pos.max(0), [0.45, 0.317, 0.20], atol=1e-6) and np.allclose(pos.min(0), [-0.45, -0.317, -0.20], atol=1e-6)
+    assert subs[0].material.baseColor.tolist() == [1.0, 0.0, 0.0]                    # dragon.mtl:6
+    assert subs[0].indices.max() == len(pos) - 1 and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-3)
+    tri = pos[subs[0].indices[::997]]
+    area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert (area > 0).mean() > 0.999
+    pos2, _, subs2 = mrt.dragon_proxy()
+    assert np.array_equal(pos, pos2) and np.array_equal(subs[0].indices, subs2[0].indices)   # deterministic
+    _, _, b = mrt.bunny_proxy()
+    assert b[0].triangleCount == 69451
+
+
+def test_transform_and_camera_match_oracle(mrt, orc):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        p, r, s = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3), float(rng.uniform(0.1, 5))
+        assert np.array_equal(mrt.make_transform(p, r, s), orc.make_transform(p, r, s))
+    for (w, h) in [(1920, 1080), (256, 256), (800, 600), (3840, 2160), (7, 5)]:
+        a, b = mrt.Scene.setupCamera((w, h)), orc.default_camera(w, h)
+        assert bytes(a) == bytes(b)
+
+
+def test_dragon_scene_definition(mrt):
+    sc = mrt.DragonScene((1920, 1080))                                              # DragonScene.swift:14-22
+    assert [m.name for m in sc.models] == ["train", "dragon", "treefir", "plane", "sphere", "sphere", "plane-back"]
+    assert [m.triangleCount for m in sc.meshes] == [3624, 871414, 352, 2, 4900, 4900, 2] and sc.triangleCount == 885194
+    assert max(len(m.submeshes) for m in sc.meshes) == 6                            # maxSubmeshes (Renderer.swift:128)
+    assert len(sc.lights) == 2 and sc.lights[0].type == 4 and sc.lights[1].type == 2  # Scene.swift:21-30
+    assert abs(sc.lights[1].coneAngle - 25 / 180 * math.pi) < 1e-6
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dragonscene_setup.npz"))
+    assert np.array_equal(np.stack([m.transform for m in sc.meshes]), g["transforms"])
