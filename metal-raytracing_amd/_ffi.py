@@ -158,6 +158,7 @@ SIGNATURES = {
     "mrt_debug_halton": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_hemisphere": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_seeds": (C.c_int, [_P, _U32, _I32, _I32, _P]),
+    "mrt_debug_traversal_stats": (C.c_int, [_P, _P, _SZ, _I32, _P]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -227,6 +227,15 @@ int mrt_scene_intersect_any(MRTScene scene, const MRTRay *rays, size_t n, int32_
     MRT_CATCH
 }
 
+int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t *out4) {
+    MRT_TRY
+    REQUIRE(scene && (n == 0 || (rays && out4)), "mrt_debug_traversal_stats: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_debug_traversal_stats: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::query_stats(scene->dev, scene->ctx->stream, rays, n, any_hit, out4);
+    MRT_CATCH
+}
+
 // ---------------------------------------------------------------- host geometry helpers
 int mrt_obj_load(const char *obj_path, MRTMeshData *out) {
     MRT_TRY
@@ -335,6 +344,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     REQUIRE(r && key, "mrt_renderer_set_option: bad argument");
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
+    else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,4]"); r->r.frames_in_flight = (int)value; }
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     return MRT_OK;

@@ -264,9 +264,11 @@ static void finish(ProcMesh &pm, const double half[3], const char *name, const M
 }
 }  // namespace
 
-// Dragon stand-in: a serpentine body with scale-like displacement, four legs, two horns and a row
-// of 25 dorsal spikes.  717 824 + 102 912 + 12 928 + 37 750 = 871 414 triangles (Stanford dragon
-// count).  Centred at the origin, half-extents (0.45, 0.317, 0.20).
+// Dragon stand-in: a serpentine body with scale-like displacement, four legs, two horns, a row of
+// 25 dorsal spikes and a tongue, all tessellated as closed tubes with near-square quads (no sliver
+// fans: the Stanford scan it stands in for is uniformly tessellated).
+// 740 352 + 102 912 + 12 928 + 15 000 + 222 = 871 414 triangles (Stanford dragon count).
+// Centred at the origin, half-extents (0.45, 0.317, 0.20).
 void make_dragon_proxy(MeshData &out) {
     const double PI = 3.14159265358979323846;
     ProcMesh pm;
@@ -277,14 +279,19 @@ void make_dragon_proxy(MeshData &out) {
         double z = 0.22 * sin(3.0 * PI * s) * (1.0 - 0.5 * s);
         return P3{x, y, z};
     };
-    auto body_r = [&](double s, double a) -> double {
-        double base = 0.035 + 0.23 * pow(sin(PI * std::min(1.0, s * 1.18)), 1.5) * (1.0 - 0.55 * s);
+    auto body_base = [&](double s) -> double {
+        double base = 0.23 * pow(sin(PI * std::min(1.0, 0.02 + s * 1.16)), 1.5) * (1.0 - 0.55 * s);
         if (s > 0.86) base += 0.10 * exp(-pow((s - 0.94) / 0.045, 2.0));            // head bulge
-        double scales = 0.012 * sin(140.0 * PI * s) * sin(24.0 * a) + 0.006 * sin(61.0 * a + 300.0 * s);
-        double belly = 1.0 - 0.18 * cos(a);
-        return std::max(0.004, base * belly + scales * (base / 0.2));
+        double taper = std::min(1.0, std::min(s, 1.0 - s) / 0.004);                  // ends close to a point: tiny caps
+        return (0.02 + base) * (0.03 + 0.97 * taper);
     };
-    pm.tube(512, 700, spine, body_r);
+    auto body_r = [&](double s, double a) -> double {
+        double base = body_base(s);
+        double scales = 0.010 * sin(140.0 * PI * s) * sin(24.0 * a) + 0.005 * sin(61.0 * a + 300.0 * s);
+        double belly = 1.0 - 0.18 * cos(a);
+        return std::max(0.0005, base * belly + scales * std::min(1.0, base / 0.2));
+    };
+    pm.tube(512, 722, spine, body_r);                                               // 2*512*723 = 740 352
     const double leg_s[4] = {0.30, 0.30, 0.62, 0.62};
     const double leg_side[4] = {1, -1, 1, -1};
     for (int l = 0; l < 4; l++) {
@@ -294,22 +301,34 @@ void make_dragon_proxy(MeshData &out) {
             double bend = sin(PI * s);
             return P3{root.x + 0.10 * bend * (l < 2 ? 1 : -1) + 0.05 * s, root.y - 0.05 - (root.y + 0.62) * s, root.z + sd * (0.14 + 0.10 * bend)};
         };
-        auto leg_r = [&](double s, double a) -> double { return 0.055 * (1.0 - 0.6 * s) + 0.02 * exp(-pow((s - 0.97) / 0.05, 2.0)) + 0.003 * sin(8.0 * a) * sin(40.0 * s); };
-        pm.tube(64, 200, leg_c, leg_r);
+        auto leg_r = [&](double s, double a) -> double {
+            double taper = std::min(1.0, std::min(s, 1.0 - s) / 0.01);
+            return (0.055 * (1.0 - 0.6 * s) + 0.02 * exp(-pow((s - 0.97) / 0.05, 2.0)) + 0.003 * sin(8.0 * a) * sin(40.0 * s)) * (0.05 + 0.95 * taper);
+        };
+        pm.tube(64, 200, leg_c, leg_r);                                             // 4 x 25 728
     }
     for (int h = 0; h < 2; h++) {
         P3 root = spine(0.95);
         double sd = h ? 1 : -1;
         auto horn_c = [&](double s) -> P3 { return P3{root.x - 0.22 * s + 0.05 * s * s, root.y + 0.10 + 0.28 * s, root.z + sd * (0.06 + 0.10 * s * s)}; };
-        auto horn_r = [&](double s, double a) -> double { return 0.03 * (1.0 - 0.93 * s) + 0.002 * sin(6.0 * a + 30.0 * s); };
-        pm.tube(32, 100, horn_c, horn_r);
+        auto horn_r = [&](double s, double a) -> double { return 0.03 * (1.0 - 0.97 * s) * (0.05 + 0.95 * std::min(1.0, s / 0.02)) + 0.001 * sin(6.0 * a + 30.0 * s) * (1.0 - s); };
+        pm.tube(32, 100, horn_c, horn_r);                                           // 2 x 6 464
     }
     for (int k = 0; k < 25; k++) {
         double s = 0.10 + 0.78 * k / 24.0;
         P3 c = spine(s);
-        double r0 = 0.035 + 0.23 * pow(sin(PI * std::min(1.0, s * 1.18)), 1.5) * (1.0 - 0.55 * s);
-        P3 base{c.x, c.y + 0.75 * r0, c.z};
-        pm.cone(755, base, P3{-0.03, 0.10 + 0.05 * sin(7.0 * s), 0.0}, 0.022, true);
+        double r0 = body_base(s);
+        P3 base{c.x, c.y + 0.70 * r0, c.z};
+        double hgt = 0.10 + 0.05 * sin(7.0 * s);
+        auto spike_c = [&](double q) -> P3 { return P3{base.x - 0.03 * q, base.y + hgt * q, base.z}; };
+        auto spike_r = [&](double q, double a) -> double { return 0.022 * (1.0 - 0.97 * q) * (0.1 + 0.9 * std::min(1.0, q / 0.05)); };
+        pm.tube(12, 24, spike_c, spike_r);                                          // 25 x 600
+    }
+    {
+        P3 mouth = spine(0.995);
+        auto tongue_c = [&](double q) -> P3 { return P3{mouth.x + 0.09 * q, mouth.y - 0.03 - 0.03 * q * q, mouth.z + 0.01 * sin(6.0 * q)}; };
+        auto tongue_r = [&](double q, double a) -> double { return 0.006 * (1.0 - 0.9 * q); };
+        pm.tube(3, 36, tongue_c, tongue_r);                                         // 222
     }
     MRTMaterial mat; memset(&mat, 0, sizeof mat);                 // Resources/dragon.mtl: Kd 1 0 0, Ks .2, Ns 37.25, Ni 1, d 1
     mat.baseColor = MRTFloat3{1.0f, 0.0f, 0.0f, 0}; mat.specular = MRTFloat3{0.2f, 0.2f, 0.2f, 0};

@@ -8,6 +8,19 @@ namespace mrt {
 
 struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
 
+// One frame in flight (Renderer.maxFramesInFlight = 3, Renderer.swift:33): its own HIP stream, ray /
+// hit / shadow queues, per-pixel sample buffer and per-bounce queue counters.  Frames on different
+// lanes overlap on the GPU (one frame's straggler waves are covered by the next frame's bulk); only the
+// accumulate step is ordered frame to frame, by an event.
+struct FrameLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t accumulated = nullptr;    // recorded after this lane's k_accumulate
+    DevBuf<float4> sample;               // this frame's radiance per pixel
+    DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
+    DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
+};
+constexpr int MAX_FRAMES_IN_FLIGHT = 4;
+
 struct Renderer {
     hipStream_t stream = nullptr;
     const DeviceScene *scene = nullptr;
@@ -25,9 +38,9 @@ struct Renderer {
 
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
-    DevBuf<float4> sample;               // this frame's radiance per pixel
-    DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
-    DevBuf<uint32_t> counters;
+    FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
+    int frames_in_flight = 3;            // Renderer.maxFramesInFlight (Renderer.swift:33)
+    hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -55,6 +68,7 @@ struct Renderer {
 
 int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out);
 int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out);
+int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4);
 int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out);
 int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3);
 int probe_seeds(hipStream_t stream, uint32_t seed, int w, int h, uint32_t *out);

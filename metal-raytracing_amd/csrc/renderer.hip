@@ -18,6 +18,7 @@
 //   shadow rays reuse rayA/rayB with tmax = lightDistance - 1e-3; con = {Lc*throughput, -}
 #include "renderer.h"
 #include "device_math.h"
+#include "traverse.h"
 #include <cstring>
 #include <algorithm>
 
@@ -76,82 +77,13 @@ __global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *_
     sample[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                   // :227
 }
 
-// ------------------------------------------------------------------ traversal
-struct TravHit { float t, U, V, ad; uint32_t gid; };
-
-MRT_DEV float safe_inv(float d) {
-    float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
-    return 1.0f / a;
-}
-
-// One triangle, Möller–Trumbore in the fused mrt-math form; division only after the barycentric
-// tests pass.  Returns true when 0 <= tmin <= t <= lim.
-MRT_DEV bool tri_test(const float4 *__restrict__ pk, f3 o, f3 d, float tmin, float lim, float &t, float &U, float &V, float &ad, uint32_t &gid) {
-    float4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
-    f3 v0 = mk3(p0), e1 = mk3(p1), e2 = mk3(p2);
-    f3 pv = fcross(d, e2);
-    float det = fdot(e1, pv);
-    if (!(det != 0.0f)) return false;
-    ad = fabsf(det);
-    uint32_t sgn = __float_as_uint(det) & 0x80000000u;
-    f3 tv = o - v0;
-    U = xorsign(fdot(tv, pv), sgn);
-    if (!(U >= 0.0f && U <= ad)) return false;
-    f3 q = fcross(tv, e1);
-    V = xorsign(fdot(d, q), sgn);
-    if (!(V >= 0.0f && U + V <= ad)) return false;
-    float T = xorsign(fdot(e2, q), sgn);
-    t = T / ad;
-    gid = __float_as_uint(p0.w);
-    return t >= tmin && t <= lim;
-}
-
-// Stackless traversal of the rope layout (scene_device.h).  State per ray: the current node index
-// and the best hit — no stack, no parent walk.  Closest hit = global min t, ties to the lowest gid,
-// so the result does not depend on the visiting order.
-template <bool ANY>
-MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h) {
-    h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
-    if (s.num_nodes == 0) return false;
-    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
-    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t *__restrict__ nodes_u = reinterpret_cast<const uint32_t *>(s.nodes);
-    uint32_t cur = 0;
-    while (cur != NODE_TERM) {
-        const float4 n0 = s.nodes[4 * (size_t)cur + 0];
-        const float4 n1 = s.nodes[4 * (size_t)cur + 1];
-        const uint32_t esc = nodes_u[16 * (size_t)cur + 8 + oct];
-        // conservative slab test: far side widened by ~4 ulp (Ize 2013), boxes padded at build time
-        float tx0 = (n0.x - o.x) * ix, tx1 = (n1.x - o.x) * ix;
-        float ty0 = (n0.y - o.y) * iy, ty1 = (n1.y - o.y) * iy;
-        float tz0 = (n0.z - o.z) * iz, tz1 = (n1.z - o.z) * iz;
-        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
-        tf = fminf(tf, h.t);
-        if (!(tn <= tf)) { cur = esc; continue; }
-        const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
-        if (a & NODE_LEAF) {
-            const uint32_t first = a & 0x7FFFFFFFu;
-            for (uint32_t k = 0; k < b; k++) {
-                float t, U, V, ad; uint32_t gid;
-                if (tri_test(s.packets + 3 * (size_t)(first + k), o, d, tmin, h.t, t, U, V, ad, gid)) {
-                    if (ANY) return true;
-                    if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
-                }
-            }
-            cur = esc;
-        } else {
-            cur = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
-        }
-    }
-    return h.gid != 0xFFFFFFFFu;
-}
+// traversal core: traverse.h
 
 // ------------------------------------------------------------------ closest hit over a ray queue
 __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                                               const uint32_t *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
+                                               const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    uint32_t n = count ? *count : capacity;
+    uint32_t n = count ? (uint32_t)*count : capacity;
     if (i >= n) return;
     float4 A = rayA[i], B = rayB[i];
     if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
@@ -160,25 +92,24 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 
-// wave-ballot compaction: one atomic per wave, lanes write at base + prefix popcount
-MRT_DEV uint32_t wave_compact_slot(bool alive, uint32_t *counter) {
-    unsigned long long m = __ballot(alive);
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    int leader = __ffsll((long long)m) - 1;
-    if (alive && (int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader < 0 ? 0 : leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
+// Queue compaction.  Lanes ballot, waves post their two counts to LDS, and ONE packed 64-bit atomic per
+// workgroup reserves the output ranges of both queues ({next rays: low word, shadow rays: high word}):
+// a single counter word sustains only ~88 returning atomics/us on gfx950 (MI355X_MICROARCH.md, row
+// "dequeue"), so per-wave atomics on 32 K waves would cost more than the shading itself.
+constexpr int SHADE_THREADS = 1024;
+constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-__global__ void __launch_bounds__(64) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
-                                              const float4 *__restrict__ hits, const uint32_t *__restrict__ count_in, uint32_t capacity,
-                                              float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr, uint32_t *__restrict__ count_next,
-                                              float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon, uint32_t *__restrict__ count_shadow) {
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    uint32_t n = count_in ? *count_in : capacity;
+                                              const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
+                                              float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
+                                              float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon,
+                                              unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */) {
+    __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES];
+    __shared__ unsigned long long blk_base;
+    uint32_t i = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    uint32_t n = count_in ? (uint32_t)*count_in : capacity;
     bool active = i < n;
     float4 H = active ? hits[i] : make_float4(-1, 0, 0, 0);
     uint32_t gid = __float_as_uint(H.w);
@@ -246,16 +177,28 @@ __global__ void __launch_bounds__(64) k_shade(SceneView s, FrameParams fp, const
             ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
         }
     }
-    uint32_t ss = wave_compact_slot(want_shadow, count_shadow);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m_sh = __ballot(want_shadow), m_nx = __ballot(want_next);
+    if (lane == 0) { w_shadow[wv] = (uint32_t)__popcll(m_sh); w_next[wv] = (uint32_t)__popcll(m_nx); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tn = 0, ts = 0;
+        for (int k = 0; k < SHADE_WAVES; k++) { uint32_t a = w_next[k], b = w_shadow[k]; w_next[k] = tn; w_shadow[k] = ts; tn += a; ts += b; }
+        blk_base = (tn | ts) ? atomicAdd(count_out, ((unsigned long long)ts << 32) | tn) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long base = blk_base;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     if (want_shadow) {
+        uint32_t ss = (uint32_t)(base >> 32) + w_shadow[wv] + (uint32_t)__popcll(m_sh & lt);
         f3 so = P + nrm * 1e-3f;                                         // :350
         f3 con = lcol * color;                                           // :372
         srayA[ss] = make_float4(so.x, so.y, so.z, ldist - 1e-3f);        // :356
         srayB[ss] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
         scon[ss] = make_float4(con.x, con.y, con.z, 0.0f);
     }
-    uint32_t ns = wave_compact_slot(want_next, count_next);
     if (want_next) {
+        uint32_t ns = (uint32_t)base + w_next[wv] + (uint32_t)__popcll(m_nx & lt);
         f3 no = P + nrm * 1e-3f;                                         // :390
         nrayA[ns] = make_float4(no.x, no.y, no.z, __builtin_inff());
         nrayB[ns] = make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix));   // :391
@@ -265,9 +208,9 @@ __global__ void __launch_bounds__(64) k_shade(SceneView s, FrameParams fp, const
 
 // ------------------------------------------------------------------ shadow rays (Raytracing.metal:360-374)
 __global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                               const uint32_t *__restrict__ count, float4 *__restrict__ sample) {
+                                               const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= *count) return;
+    if (i >= (uint32_t)(*count >> 32)) return;
     float4 A = srayA[i], B = srayB[i];
     TravHit h;
     bool occluded = traverse<true>(s, mk3(A), mk3(B), 0.0f, A.w, h);
@@ -279,7 +222,20 @@ __global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__rest
 }
 
 // ------------------------------------------------------------------ accumulate (Raytracing.metal:394-403)
-__global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst) {
+// Also the frame's bookkeeping (block 0, thread 0): per-bounce queue counters {next rays, shadow rays} are
+// folded into the running totals and zeroed for the next frame.
+__global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst,
+                                                   unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long closest = primary, shadow = 0;
+        for (int b = 0; b < fp.max_bounces; b++) {
+            unsigned long long c = bounce_counts[b];
+            if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
+            shadow += c >> 32;
+            bounce_counts[b] = 0;
+        }
+        totals[0] += closest; totals[1] += shadow; totals[2] += primary;
+    }
     uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     int x, y;
     if (!slot_to_pixel(fp, slot, x, y)) return;
@@ -292,14 +248,6 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
         c.x = (c.x + p.x * fi) / den; c.y = (c.y + p.y * fi) / den; c.z = (c.z + p.z * fi) / den;
     }
     dst[pix] = make_float4(c.x, c.y, c.z, 1.0f);
-}
-
-// per-frame counter block: [0],[1] = path-queue counts (ping/pong), [2] = shadow count, then per-bounce records
-__global__ void k_frame_counters(uint32_t *__restrict__ c, unsigned long long *__restrict__ totals, int phase, uint32_t primary) {
-    if (phase == 0) { c[0] = 0; c[1] = 0; c[2] = 0; totals[0] += primary; totals[2] += primary; }       // frame start: bounce-0 closest rays = primary rays
-    else if (phase == 1) { totals[1] += c[2]; c[2] = 0; }                                               // after shadow pass
-    else if (phase == 2) { totals[0] += c[0]; c[1] = 0; }                                               // next bounce reads queue 0 -> count closest, reset the other
-    else if (phase == 3) { totals[0] += c[1]; c[0] = 0; }
 }
 
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
@@ -339,6 +287,18 @@ __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__r
     out[i] = traverse<true>(s, mk3(r.origin[0], r.origin[1], r.origin[2]), mk3(r.direction[0], r.direction[1], r.direction[2]), r.min_distance, r.max_distance, h) ? 1 : 0;
 }
 
+// per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
+__global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    MRTRay r = rays[i];
+    TravHit h; TravCounters tc{0, 0, 0, 0};
+    f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
+    else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
+    out[4 * i + 0] = tc.steps; out[4 * i + 1] = tc.leaves; out[4 * i + 2] = tc.tris; out[4 * i + 3] = h.gid;
+}
+
 // ------------------------------------------------------------------ device-function probes
 __global__ void k_probe_halton(const int32_t *i, const int32_t *d, uint32_t n, float *out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,9 +319,15 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
 int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed_, int max_bounces_) {
     stream = st; scene = sc; seed = seed_; max_bounces = max_bounces_;
     MRT_HIP(hipEventCreate(&ev_begin)); MRT_HIP(hipEventCreate(&ev_end));
+    MRT_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     for (auto &e : ev_ext) { MRT_HIP(hipEventCreate(&e.a)); MRT_HIP(hipEventCreate(&e.b)); }
-    MRT_HIP(counters.alloc(16)); MRT_HIP(totals.alloc(4));
-    MRT_HIP(hipMemsetAsync(counters.p, 0, counters.bytes(), stream));
+    for (auto &L : lanes) {
+        MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
+        MRT_HIP(L.bounce_counts.alloc(32));
+        MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
+    }
+    MRT_HIP(totals.alloc(4));
     MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
     return resize(w, h);
 }
@@ -369,17 +335,22 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
 Renderer::~Renderer() {
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto &e : ev_ext) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+    for (auto &L : lanes) {
+        if (L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
+        if (L.accumulated) (void)hipEventDestroy(L.accumulated);
+    }
 }
 
 int Renderer::resize(int w, int h) {                                   // Renderer.swift:353-356 → createTextures :231-275
     width = w; height = h;
     const size_t npix = (size_t)w * h;
     MRT_HIP(seeds.alloc(npix));
-    MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix)); MRT_HIP(sample.alloc(npix));
+    MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix));
     MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
     MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
-    MRT_HIP(hipMemsetAsync(sample.p, 0, sample.bytes(), stream));
+    for (auto &L : lanes) { MRT_HIP(L.sample.alloc(npix)); MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream)); }
     hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256)), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
     default_camera(w, h, &camera);
     frame_index = 0; cur = 0;
@@ -394,8 +365,10 @@ int Renderer::alloc_queues() {
     tiles_local = (tiles - shard_rank + shard_world - 1) / shard_world;
     if (tiles_local < 0) tiles_local = 0;
     capacity = (uint32_t)tiles_local * 64u;
-    for (int k = 0; k < 2; k++) { MRT_HIP(rayA[k].alloc(capacity)); MRT_HIP(rayB[k].alloc(capacity)); MRT_HIP(thr[k].alloc(capacity)); }
-    MRT_HIP(hits.alloc(capacity)); MRT_HIP(srayA.alloc(capacity)); MRT_HIP(srayB.alloc(capacity)); MRT_HIP(scon.alloc(capacity));
+    for (auto &L : lanes) {
+        for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(capacity)); MRT_HIP(L.rayB[k].alloc(capacity)); MRT_HIP(L.thr[k].alloc(capacity)); }
+        MRT_HIP(L.hits.alloc(capacity)); MRT_HIP(L.srayA.alloc(capacity)); MRT_HIP(L.srayB.alloc(capacity)); MRT_HIP(L.scon.alloc(capacity));
+    }
     // pixels owned by this shard (edge tiles may be partial)
     uint64_t owned = 0;
     for (int lt = 0; lt < tiles_local; lt++) {
@@ -430,33 +403,44 @@ int Renderer::render(int n_frames) {                                   // Render
     fp.shard_rank = shard_rank; fp.shard_world = shard_world;
     fp.tiles_x = (width + 7) / 8; fp.tiles_local = tiles_local; fp.max_bounces = max_bounces;
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
-    uint32_t *c = counters.p;
+    const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
+    const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
+    // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
+    MRT_HIP(hipEventRecord(ev_fork, stream));
+    for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
+    hipEvent_t last_acc = nullptr;
     for (int f = 0; f < n_frames; f++) {
+        FrameLane &L = lanes[f % F];
+        hipStream_t st = L.stream;
+        unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229
         fp.sampleIndex = frame_index + sample_offset;
-        hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, 0, (uint32_t)owned_pixels);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, stream, fp, seeds.p, rayA[0].p, rayB[0].p, thr[0].p, sample.p);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
         int q = 0;
         for (int b = 0; b < max_bounces; b++) {
             fp.bounce = b;
-            const uint32_t *cin = b == 0 ? nullptr : c + q;             // bounce 0: every slot of the primary queue
+            const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
             bool timed = ext_used < (int)ev_ext.size();
-            if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, stream));
-            hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, stream, sv, rayA[q].p, rayB[q].p, cin, capacity, hits.p);
-            if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, stream)); ext_used++; }
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(64), 0, stream, sv, fp, seeds.p, rayA[q].p, rayB[q].p, thr[q].p, hits.p, cin, capacity,
-                               rayA[1 - q].p, rayB[1 - q].p, thr[1 - q].p, c + (1 - q), srayA.p, srayB.p, scon.p, c + 2);
-            hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, stream, sv, srayA.p, srayB.p, scon.p, c + 2, sample.p);
-            hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, 1, 0u);
+            if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
+            hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+            if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
+            hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
+                               L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b);
+            hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
             q = 1 - q;
-            if (b + 1 < max_bounces) hipLaunchKernelGGL(k_frame_counters, dim3(1), dim3(1), 0, stream, c, totals.p, q == 0 ? 2 : 3, 0u);
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, stream, fp, sample.p, accum[cur].p, accum[1 - cur].p);
+        // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
+        if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels);
+        MRT_HIP(hipEventRecord(L.accumulated, st));
+        last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334
         frame_index++; frames_rendered++;
     }
+    // join: the main stream continues after every lane has drained
+    for (int k = 0; k < std::min(F, n_frames); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
     MRT_HIP(hipEventRecord(ev_end, stream));
     MRT_HIP(hipGetLastError());
     pending_timing = true;
@@ -540,6 +524,18 @@ int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, siz
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_query_any, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+
+int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4) {
+    if (n == 0) return MRT_OK;
+    DevBuf<MRTRay> d_r; DevBuf<uint32_t> d_o;
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(4 * n));
+    MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_query_stats, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
+    MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 16, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     return MRT_OK;

@@ -1,0 +1,13 @@
+"""Summarises rocprofv3 --pmc CSV output per kernel: mean counter value per dispatch."""
+import csv, sys, glob, collections
+path = sys.argv[1]
+files = glob.glob(path + "/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        k = next((s for s in ("k_raygen", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_path", "k_trace") if s in n), None)
+        if not k: continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k, {c: round(sum(v) / len(v), 1) for c, v in sorted(d.items())}, "dispatches", max(len(v) for v in d.values()))
