@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--shard", default="tile", choices=["tile", "sample"])
     ap.add_argument("--builder", type=int, default=None)
+    ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="Renderer.maxFramesInFlight (default 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -92,6 +93,8 @@ def main():
     opts = {} if a.builder is None else {"builder": a.builder}
     r = mrt.Renderer((w, h), scene, device=local_rank, seed=1, max_bounces=a.bounces, scene_options=opts)
     sst = r.device_scene.stats
+    for kv in a.opt:
+        k, v = kv.split("="); r.set_option(k, float(v))
     if a.frames_in_flight is not None:
         r.set_option("frames_in_flight", a.frames_in_flight)
     if world > 1:

@@ -237,8 +237,9 @@ int mrt_renderer_reset_stats(MRTRenderer r);
 int mrt_debug_halton(MRTContext ctx, const int32_t *i, const int32_t *d, size_t n, float *out);
 int mrt_debug_hemisphere(MRTContext ctx, const float *u2, const float *normal3, size_t n, float *out3);
 int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height, uint32_t *out);
-/* Diagnostics: per ray {node visits, leaf visits, triangle tests, hit gid} of the traversal (4 x uint32 each). */
-int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t *out4);
+/* Diagnostics: per ray {node visits, leaf visits, triangle tests, hit gid, start tick, end tick, 0, 0}
+ * (8 x uint32 each; ticks of the 100 MHz wall clock).                                           */
+int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t *out8);
 
 #ifdef __cplusplus
 }

@@ -344,7 +344,9 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     REQUIRE(r && key, "mrt_renderer_set_option: bad argument");
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
-    else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,4]"); r->r.frames_in_flight = (int)value; }
+    else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,8]"); r->r.frames_in_flight = (int)value; }
+    else if (k == "persistent") r->r.persistent = value != 0;
+    else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     return MRT_OK;

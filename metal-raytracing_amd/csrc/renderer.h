@@ -19,7 +19,7 @@ struct FrameLane {
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
 };
-constexpr int MAX_FRAMES_IN_FLIGHT = 4;
+constexpr int MAX_FRAMES_IN_FLIGHT = 8;
 
 struct Renderer {
     hipStream_t stream = nullptr;
@@ -40,6 +40,8 @@ struct Renderer {
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 3;            // Renderer.maxFramesInFlight (Renderer.swift:33)
+    bool persistent = true;              // persistent wavefronts with lane refill for the two traversal kernels
+    int persistent_waves = 8192;         // 256 CUs x 32 waves
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
 

@@ -92,6 +92,27 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 
+// ------------------------------------------------------------------ persistent variants (lane refill)
+__global__ void __launch_bounds__(64) k_extend_persistent(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                                                          const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
+    const uint32_t n = count ? (uint32_t)*count : capacity;
+    if (blockIdx.x * 64u >= n) return;
+    traverse_queue<false>(s, rayA, rayB, n, blockIdx.x, gridDim.x, [&](uint32_t idx, uint32_t, bool hit, const TravHit &h) {
+        hits[idx] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    });
+}
+__global__ void __launch_bounds__(64) k_shadow_persistent(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                          const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
+    const uint32_t n = (uint32_t)(*count >> 32);
+    if (blockIdx.x * 64u >= n) return;
+    traverse_queue<true>(s, srayA, srayB, n, blockIdx.x, gridDim.x, [&](uint32_t idx, uint32_t pix, bool occluded, const TravHit &) {
+        if (!occluded) {
+            float4 c = scon[idx], a = sample[pix];
+            sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);
+        }
+    });
+}
+
 // Queue compaction.  Lanes ballot, waves post their two counts to LDS, and ONE packed 64-bit atomic per
 // workgroup reserves the output ranges of both queues ({next rays: low word, shadow rays: high word}):
 // a single counter word sustains only ~88 returning atomics/us on gfx950 (MI355X_MICROARCH.md, row
@@ -294,9 +315,12 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
     MRTRay r = rays[i];
     TravHit h; TravCounters tc{0, 0, 0, 0};
     f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    unsigned long long t0 = wall_clock64();
     if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
     else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
-    out[4 * i + 0] = tc.steps; out[4 * i + 1] = tc.leaves; out[4 * i + 2] = tc.tris; out[4 * i + 3] = h.gid;
+    unsigned long long t1 = wall_clock64();
+    out[8 * i + 0] = tc.steps; out[8 * i + 1] = tc.leaves; out[8 * i + 2] = tc.tris; out[8 * i + 3] = h.gid;
+    out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters; out[8 * i + 7] = 0;   // 100 MHz ticks
 }
 
 // ------------------------------------------------------------------ device-function probes
@@ -405,6 +429,7 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
+    const uint32_t grid_p = std::max<uint32_t>(1u, std::min<uint32_t>(grid, (uint32_t)persistent_waves));
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
@@ -424,11 +449,13 @@ int Renderer::render(int n_frames) {                                   // Render
             const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
             bool timed = ext_used < (int)ev_ext.size();
             if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
-            hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+            if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+            else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
             if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
             hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b);
-            hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+            if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+            else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
             q = 1 - q;
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
@@ -532,10 +559,10 @@ int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, siz
 int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4) {
     if (n == 0) return MRT_OK;
     DevBuf<MRTRay> d_r; DevBuf<uint32_t> d_o;
-    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(4 * n));
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_query_stats, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
-    MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 16, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     return MRT_OK;

@@ -36,70 +36,148 @@ MRT_DEV bool tri_test(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float tmin, f
 
 struct TravCounters { uint32_t steps, leaves, tris, wave_iters; };
 
-constexpr int MAX_LEAF_BATCH = 4;     // triangles fetched per round trip at a leaf
-
-// Stackless traversal of the rope layout (scene_device.h).  State per ray: the current node index
-// and the best hit — no stack, no parent walk.  Closest hit = global min t, ties to the lowest gid,
-// so the result does not depend on the visiting order.
-// Loop shape ("while-while"): lanes walk inner nodes until each has a leaf whose box it hits (or is
-// done); then the wave tests leaf triangles together, all of a leaf's packets fetched in one round
-// trip.  Every step is one dependent memory round trip, so the chain length of the slowest ray in a
-// wave — not arithmetic — sets the wave's time.
+// Stackless traversal of the rope layout (scene_device.h).  State per ray: the next node, the pending
+// triangle range of the current leaf and the best hit — no stack, no parent walk.  Closest hit =
+// global min t, ties to the lowest gid, so the result does not depend on the visiting order.
+//
+// Loop shape: ONE kind of iteration.  Every iteration each live lane issues the same three 16-byte
+// loads from its own base — a node (box lo|a, box hi|b, the escape quad of its octant) or one triangle
+// packet (v0|gid, e1, e2) — so a wave iteration is exactly one memory round trip in which EVERY lane
+// advances (a box test or a triangle test).  Measured on MI355X the wave time is (iterations of its
+// slowest lane) x (round-trip latency); a split inner-node / leaf loop made the slowest wave iterate
+// 4x more often than any of its lanes needed.
 template <bool ANY, bool STATS = false>
 MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_nodes == 0) return false;
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t *__restrict__ nodes_u = reinterpret_cast<const uint32_t *>(s.nodes);
-    uint32_t cur = 0;
+    const uint32_t esc_quad = 2u + (oct >> 2), esc_lane = oct & 3u;
+    uint32_t cur = 0;                 // next node, NODE_TERM when the walk is over
+    uint32_t tri = 0, tri_end = 0;    // pending packets of the current leaf
     for (;;) {
-        uint32_t leaf_first = 0, leaf_count = 0;
-        while (cur != NODE_TERM) {
-            if (STATS) { tc->steps++; }
-            const float4 n0 = s.nodes[4 * (size_t)cur + 0];
-            const float4 n1 = s.nodes[4 * (size_t)cur + 1];
-            const uint32_t esc = nodes_u[16 * (size_t)cur + 8 + oct];
+        const bool do_tri = tri < tri_end;
+        if (!do_tri && cur == NODE_TERM) break;
+        if (STATS) { if (do_tri) tc->tris++; else tc->steps++; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc->wave_iters++; }
+        const float4 *__restrict__ rec = do_tri ? s.packets + 3 * (size_t)tri : s.nodes + 4 * (size_t)cur;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[do_tri ? 2u : esc_quad];
+        if (do_tri) {
+            tri++;
+            float t, U, V, ad;
+            if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
+                if (ANY) return true;
+                const uint32_t gid = __float_as_uint(r0.w);
+                if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
+            }
+        } else {
             // conservative slab test: far side widened by ~4 ulp (Ize 2013), boxes padded at build time
-            float tx0 = (n0.x - o.x) * ix, tx1 = (n1.x - o.x) * ix;
-            float ty0 = (n0.y - o.y) * iy, ty1 = (n1.y - o.y) * iy;
-            float tz0 = (n0.z - o.z) * iz, tz1 = (n1.z - o.z) * iz;
+            float tx0 = (r0.x - o.x) * ix, tx1 = (r1.x - o.x) * ix;
+            float ty0 = (r0.y - o.y) * iy, ty1 = (r1.y - o.y) * iy;
+            float tz0 = (r0.z - o.z) * iz, tz1 = (r1.z - o.z) * iz;
             float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
             float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
             tf = fminf(tf, h.t);
-            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+            const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);
+            const float escf = esc_lane == 0 ? r2.x : esc_lane == 1 ? r2.y : esc_lane == 2 ? r2.z : r2.w;
+            const uint32_t esc = __float_as_uint(escf);
             const bool hit = tn <= tf;
             const bool leaf = (a & NODE_LEAF) != 0;
             const uint32_t child = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
             cur = (hit && !leaf) ? child : esc;
-            if (hit && leaf) { leaf_first = a & 0x7FFFFFFFu; leaf_count = b; break; }
-        }
-        if (leaf_count == 0) break;
-        if (STATS) { tc->leaves++; tc->tris += leaf_count; }
-        for (uint32_t base = 0; base < leaf_count; base += MAX_LEAF_BATCH) {
-            float4 pk[MAX_LEAF_BATCH][3];
-#pragma unroll
-            for (int k = 0; k < MAX_LEAF_BATCH; k++) {
-                // clamp instead of predicate: the loads are issued unconditionally, back to back
-                uint32_t idx = leaf_first + min(base + (uint32_t)k, leaf_count - 1);
-                pk[k][0] = s.packets[3 * (size_t)idx + 0];
-                pk[k][1] = s.packets[3 * (size_t)idx + 1];
-                pk[k][2] = s.packets[3 * (size_t)idx + 2];
-            }
-#pragma unroll
-            for (int k = 0; k < MAX_LEAF_BATCH; k++) {
-                if (base + (uint32_t)k < leaf_count) {
-                    float t, U, V, ad;
-                    if (tri_test(pk[k][0], pk[k][1], pk[k][2], o, d, tmin, h.t, t, U, V, ad)) {
-                        if (ANY) return true;
-                        uint32_t gid = __float_as_uint(pk[k][0].w);
-                        if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
-                    }
-                }
-            }
+            if (hit && leaf) { if (STATS) tc->leaves++; tri = a & 0x7FFFFFFFu; tri_end = tri + b; }
         }
     }
     return h.gid != 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent wavefronts with lane refill (BASELINE.json configs[4]: "persistent-wavefront + ray
+// compaction").  A fixed set of W waves walks a ray queue of n rays: wave w owns the 64-ray chunks
+// w, w+W, w+2W, ... (round-robin, so the expensive screen regions are spread over all waves, and no
+// atomics: one counter word sustains only ~88 returning atomics/us on gfx950).  Whenever at least
+// REFILL_MIN lanes of the wave have finished their ray, those lanes emit their result through `sink`
+// and load the next rays of the wave's stream, so lanes do not idle while the slowest ray of a
+// 64-ray batch finishes — with one ray per lane the VALU ran at ~28 % lane occupancy on the
+// incoherent bounce rays (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+constexpr int REFILL_MIN = 8;
+
+template <bool ANY, class Sink>
+MRT_DEV void traverse_queue(const SceneView &s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                            uint32_t n, uint32_t wave, uint32_t nwaves, Sink sink) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t p_next = 0;                       // wave-uniform: position in this wave's ray stream
+    bool live = false;                         // lane holds a ray in flight
+    uint32_t idx = 0xFFFFFFFFu, pix = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    float ix = 0, iy = 0, iz = 0;
+    uint32_t oct = 0, esc_quad = 2, esc_lane = 0;
+    uint32_t cur = NODE_TERM, tri = 0, tri_end = 0;
+    TravHit h; h.t = 0; h.U = 0; h.V = 0; h.ad = 1; h.gid = 0xFFFFFFFFu;
+    bool occluded = false;
+    for (;;) {
+        // ---- retire finished rays, refill idle lanes
+        const bool finished = live && cur == NODE_TERM && tri >= tri_end;
+        const unsigned long long idle = __ballot(!live || finished);
+        const bool stream_left = ((p_next >> 6) * nwaves + wave) * 64u < n;      // wave-uniform
+        if (idle == ~0ull || (stream_left && __popcll(idle) >= REFILL_MIN) || (!stream_left && __ballot(finished) != 0ull)) {
+            if (finished) { sink(idx, pix, ANY ? occluded : (h.gid != 0xFFFFFFFFu), h); live = false; }
+            if (!stream_left) { if (__ballot(live) == 0ull) break; }
+            else {
+                const uint32_t p = p_next + (uint32_t)__popcll(idle & lt);
+                p_next += (uint32_t)__popcll(idle);
+                if (!live) {
+                    const uint32_t i = ((p >> 6) * nwaves + wave) * 64u + (p & 63u);
+                    if (i < n) {
+                        const float4 A = rayA[i], B = rayB[i];
+                        idx = i; pix = __float_as_uint(B.w);
+                        o = mk3(A); d = mk3(B);
+                        ix = safe_inv(d.x); iy = safe_inv(d.y); iz = safe_inv(d.z);
+                        oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                        esc_quad = 2u + (oct >> 2); esc_lane = oct & 3u;
+                        h.t = A.w; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
+                        occluded = false;
+                        const bool dead = pix == 0xFFFFFFFFu || s.num_nodes == 0;    // partial-tile slot / empty scene: immediate miss
+                        cur = dead ? NODE_TERM : 0u; tri = 0; tri_end = 0;
+                        live = true;
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- one traversal step for every live, unfinished lane (same shape as traverse<>)
+        if (live && !finished) {
+            const bool do_tri = tri < tri_end;
+            const float4 *__restrict__ rec = do_tri ? s.packets + 3 * (size_t)tri : s.nodes + 4 * (size_t)cur;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[do_tri ? 2u : esc_quad];
+            if (do_tri) {
+                tri++;
+                float t, U, V, ad;
+                if (tri_test(r0, r1, r2, o, d, 0.0f, h.t, t, U, V, ad)) {
+                    if (ANY) { occluded = true; cur = NODE_TERM; tri = tri_end; }
+                    else {
+                        const uint32_t gid = __float_as_uint(r0.w);
+                        if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
+                    }
+                }
+            } else {
+                float tx0 = (r0.x - o.x) * ix, tx1 = (r1.x - o.x) * ix;
+                float ty0 = (r0.y - o.y) * iy, ty1 = (r1.y - o.y) * iy;
+                float tz0 = (r0.z - o.z) * iz, tz1 = (r1.z - o.z) * iz;
+                float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+                float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
+                tf = fminf(tf, h.t);
+                const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);
+                const float escf = esc_lane == 0 ? r2.x : esc_lane == 1 ? r2.y : esc_lane == 2 ? r2.z : r2.w;
+                const uint32_t esc = __float_as_uint(escf);
+                const bool hit = tn <= tf;
+                const bool leaf = (a & NODE_LEAF) != 0;
+                const uint32_t child = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
+                cur = (hit && !leaf) ? child : esc;
+                if (hit && leaf) { tri = a & 0x7FFFFFFFu; tri_end = tri + b; }
+            }
+        }
+    }
 }
 
 }  // namespace

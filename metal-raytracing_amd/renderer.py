@@ -82,9 +82,9 @@ class DeviceScene:
         return out
 
     def traversal_stats(self, rays, any_hit=False):
-        """Diagnostics: (n, 4) uint32 {node visits, leaf visits, triangle tests, hit gid} per ray."""
+        """Diagnostics: (n, 8) uint32 {node visits, leaf visits, triangle tests, hit gid, t0, t1, 0, 0} per ray."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
-        out = np.zeros((rays.shape[0], 4), np.uint32)
+        out = np.zeros((rays.shape[0], 8), np.uint32)
         check(lib.mrt_debug_traversal_stats(self.handle, ptr(rays), rays.shape[0], 1 if any_hit else 0, ptr(out)))
         return out
 

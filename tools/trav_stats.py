@@ -19,16 +19,26 @@ def primary_rays(w, h, step=1):
     return rays
 
 def report(tag, st):
-    steps, leaves, tris = st[:, 0].astype(np.float64), st[:, 1], st[:, 2]
+    steps, leaves, tris = (st[:, 0] + st[:, 2]).astype(np.float64), st[:, 1], st[:, 2]
     wave_max = steps.reshape(-1, 64).max(1)
     util = steps.reshape(-1, 64).sum(1) / (64 * np.maximum(wave_max, 1))
+    t0 = st[:, 4].astype(np.int64).reshape(-1, 64)[:, 0]; t1 = st[:, 5].astype(np.int64).reshape(-1, 64).max(1)
+    base = t0.min(); span = (t1.max() - base) / 100.0
+    dur = (t1 - t0) / 100.0
+    ts = np.linspace(0, span, 21)[1:]
+    occ = [int(((t0 - base) / 100.0 <= x).sum() - ((t1 - base) / 100.0 <= x).sum()) for x in ts]
+    wi = st[:, 6].astype(np.int64).reshape(-1, 64)
+    inner = wi.sum(1); leafph = np.zeros_like(inner)
+    k = int(np.argmax(dur))
+    print(f"     slowest wave #{k}: {dur[k]:.1f} us, inner iterations {inner[k]}, leaf phases {leafph[k]}, max lane steps {st[:,0].reshape(-1,64)[k].max()}, sum lane steps {st[:,0].reshape(-1,64)[k].sum()} -> {dur[k]*1000/max(1,inner[k]+leafph[k]):.0f} ns per round trip; all waves: {dur.sum()*1000/(inner.sum()+leafph.sum()):.0f} ns per round trip")
+    print(f"     kernel span {span:8.1f} us  waves {len(t0)}  wave dur mean {dur.mean():7.1f} p50 {np.percentile(dur,50):6.1f} p99 {np.percentile(dur,99):7.1f} max {dur.max():7.1f} us | resident waves over time: {occ}")
     print(f"  {tag:10s} steps mean {steps.mean():7.1f} p99 {np.percentile(steps,99):5.0f} p99.9 {np.percentile(steps,99.9):5.0f} max {steps.max():6.0f} | leaves {leaves.mean():5.1f} tris {tris.mean():5.1f} | wave-max mean {wave_max.mean():7.1f}  lane util {util.mean()*100:5.1f}%  hit {(st[:,3]!=0xFFFFFFFF).mean()*100:.1f}%", flush=True)
 
 if __name__ == "__main__":
     w, h = 1920, 1080
     sc = m.DragonScene((w, h))
     ctx = m.Context(0)
-    rays = primary_rays(w, h, step=3)
+    rays = primary_rays(w, h, step=1)
     variants = [dict(builder=0), dict(builder=1), dict(builder=1, ploc_radius=8), dict(builder=1, ploc_radius=32), dict(builder=1, max_leaf=8), dict(builder=1, max_leaf=2), dict(builder=1, cost_trav=2.0)]
     if len(sys.argv) > 1:
         variants = [json.loads(a) for a in sys.argv[1:]]
