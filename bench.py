@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per frame in flight (before HIP initialises)
+
 import numpy as np
 import torch
 

@@ -181,6 +181,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "max_leaf") { REQUIRE(value >= 1 && value <= 16, "max_leaf must be in [1,16]"); scene->opt.max_leaf = (int)value; }
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
+    else if (k == "wide") scene->opt.wide = (int)value;
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     scene->committed = false;
@@ -346,6 +347,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,8]"); r->r.frames_in_flight = (int)value; }
     else if (k == "persistent") r->r.persistent = value != 0;
+    else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }

@@ -456,6 +456,114 @@ __global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restric
 }
 __global__ void k_set_root_parent(const uint32_t *__restrict__ cid, uint32_t *__restrict__ parent) { parent[cid[0]] = NONE; }
 
+// ------------------------------------------------------------------ 8-wide collapse + quantisation
+// One thread per wide node of the current level.  Greedy collapse (largest surface area first) of the
+// refitted binary tree; children that are binary inner nodes form the next level (BFS numbering, so a
+// node's children are contiguous and the top of the tree sits at the lowest indices).
+__global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_offset, const uint32_t *__restrict__ fin, uint32_t n_in,
+                             uint32_t base_in, uint32_t next_base, uint32_t *__restrict__ fout, uint32_t *__restrict__ counters /* [0] next-level nodes, [1] packets */,
+                             float4 *__restrict__ wnodes, const float4 *__restrict__ packets, float4 *__restrict__ wpackets) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n_in;
+    uint32_t ch[8]; int nch = 0;
+    uint32_t ninner = 0, ntris = 0;
+    float4 nlo = make_float4(0, 0, 0, 0), nhi = nlo;
+    if (active) {
+        const uint32_t f = fin[i];
+        nlo = t.lo[f]; nhi = t.hi[f];
+        if (t.collapsed[f]) { ch[0] = f; nch = 1; }
+        else {
+            ch[0] = t.left[f]; ch[1] = t.right[f]; nch = 2;
+            while (nch < 8) {
+                int best = -1; float ba = -1.0f;
+                for (int k = 0; k < nch; k++) {
+                    uint32_t c = ch[k];
+                    if (!t.collapsed[c]) { float a = box_area(t.lo[c], t.hi[c]); if (a > ba) { ba = a; best = k; } }
+                }
+                if (best < 0) break;
+                uint32_t c = ch[best];
+                ch[best] = t.left[c]; ch[nch++] = t.right[c];
+            }
+        }
+        for (int k = 0; k < nch; k++) { if (t.collapsed[ch[k]]) ntris += t.ntri[ch[k]]; else ninner++; }
+    }
+    // wave-aggregated reservation of next-level node slots and packet slots
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t xi = ninner, xt = ntris;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t a = __shfl_up(xi, o), b = __shfl_up(xt, o); if (lane >= (uint32_t)o) { xi += a; xt += b; } }
+    uint32_t tot_i = __shfl(xi, 63), tot_t = __shfl(xt, 63), base_i = 0, base_t = 0;
+    if (lane == 63) { if (tot_i) base_i = atomicAdd(&counters[0], tot_i); if (tot_t) base_t = atomicAdd(&counters[1], tot_t); }
+    base_i = __shfl(base_i, 63); base_t = __shfl(base_t, 63);
+    if (!active) return;
+    const uint32_t my_i = base_i + xi - ninner, my_t = base_t + xt - ntris;
+    // slot assignment: preferred slot = side of the node centre per axis; greedy nearest free slot (Hamming)
+    int slot_of[8]; bool used[8] = {false, false, false, false, false, false, false, false};
+    const float cx = nlo.x + nhi.x, cy = nlo.y + nhi.y, cz = nlo.z + nhi.z;      // 2 x centre
+    for (int k = 0; k < nch; k++) {
+        uint32_t c = ch[k];
+        float4 lo = t.lo[c], hi = t.hi[c];
+        int pref = ((lo.x + hi.x) > cx ? 1 : 0) | ((lo.y + hi.y) > cy ? 2 : 0) | ((lo.z + hi.z) > cz ? 4 : 0);
+        int bs = -1, bd = 99;
+        for (int sl = 0; sl < 8; sl++) if (!used[sl]) { int dd = __popc((unsigned)(sl ^ pref)); if (dd < bd) { bd = dd; bs = sl; } }
+        used[bs] = true; slot_of[k] = bs;
+    }
+    int child_in_slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (int k = 0; k < nch; k++) child_in_slot[slot_of[k]] = k;
+    // quantisation grid: p = lo, step 2^e >= extent / 255 per axis
+    float ext[3] = {nhi.x - nlo.x, nhi.y - nlo.y, nhi.z - nlo.z};
+    uint32_t eb[3]; float inv_step[3], step[3];
+    for (int a = 0; a < 3; a++) {
+        float sdiv = ext[a] / 255.0f;
+        uint32_t bits = __float_as_uint(sdiv);
+        uint32_t e = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+        if (e < 1u) e = 1u; if (e > 254u) e = 254u;
+        eb[a] = e;
+        step[a] = __uint_as_float(e << 23);
+        inv_step[a] = __uint_as_float((254u - e) << 23);        // 2^-(e-127)
+    }
+    const float pl[3] = {nlo.x, nlo.y, nlo.z};
+    uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z then qhi x,y,z; 2 dwords (8 bytes) each
+    uint32_t meta[2] = {0, 0}, imask = 0, rank_i = 0, off_t = 0;
+    for (int sl = 0; sl < 8; sl++) {
+        int k = child_in_slot[sl];
+        uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
+        if (k >= 0) {
+            uint32_t c = ch[k];
+            float4 lo = t.lo[c], hi = t.hi[c];
+            const float cl[3] = {lo.x, lo.y, lo.z}, chh[3] = {hi.x, hi.y, hi.z};
+            for (int a = 0; a < 3; a++) {
+                float fl = floorf((cl[a] - pl[a]) * inv_step[a]);
+                float fh = ceilf((chh[a] - pl[a]) * inv_step[a]);
+                fl = fminf(fmaxf(fl, 0.0f), 255.0f); fh = fminf(fmaxf(fh, 0.0f), 255.0f);
+                // make sure the decoded planes still enclose the child after rounding of (c - p)
+                if (pl[a] + fl * step[a] > cl[a] && fl > 0.0f) fl -= 1.0f;
+                if (pl[a] + fh * step[a] < chh[a] && fh < 255.0f) fh += 1.0f;
+                ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
+            }
+            if (t.collapsed[c]) {
+                uint32_t cnt = t.ntri[c];
+                uint32_t m = (cnt << 5) | off_t;
+                meta[sl >> 2] |= m << (8 * (sl & 3));
+                uint32_t src = leaf_offset[c];
+                for (uint32_t r = 0; r < cnt; r++)
+                    for (int j = 0; j < 3; j++) wpackets[3 * (size_t)(my_t + off_t + r) + j] = packets[3 * (size_t)(src + r) + j];
+                off_t += cnt;
+            } else {
+                imask |= 1u << sl;
+                fout[my_i + rank_i] = c;
+                rank_i++;
+            }
+        }
+        for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
+    }
+    const size_t w = 5 * (size_t)(base_in + i);
+    wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
+    wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
+    wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
+    wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
+    wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+}
+
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
 }  // namespace
@@ -464,6 +572,7 @@ SceneView DeviceScene::view() const {
     SceneView v{};
     v.nodes = nodes.p; v.packets = packets.p; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
+    v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
@@ -643,7 +752,6 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
 
     // ---- stats: find the root (new_index == 0) on the host side from a small readback
     std::vector<uint32_t> h_new(nnodes);
@@ -665,6 +773,45 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;
     out.stats.build_ms = ms;
     out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)n * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
+    out.num_wnodes = 0; out.wide_depth = 0;
+    if (opt.wide) {
+        // ---- 8-wide compressed layout, level by level (BFS numbering)
+        if (opt.max_leaf > 7) { set_error("wide layout needs max_leaf <= 7"); return MRT_ERR_INVALID_ARGUMENT; }
+        const size_t max_w = (size_t)h_size / 2 + 2;
+        DevBuf<uint32_t> fa, fb, wc;
+        MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
+        MRT_HIP(out.wnodes.alloc(5 * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
+        MRT_HIP(hipEventRecord(ev0, stream));
+        MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
+        MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
+        uint32_t n_in = 1, base_in = 0, total = 0; int depth = 0;
+        uint32_t *fin = fa.p, *fo = fb.p;
+        while (n_in > 0) {
+            depth++;
+            if (total + n_in > max_w) { set_error("wide BVH build overflow"); return MRT_ERR_HIP; }
+            MRT_HIP(hipMemsetAsync(wc.p, 0, 4, stream));
+            hipLaunchKernelGGL(k_wide_level, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
+                               out.wnodes.p, out.packets.p, out.wpackets.p);
+            uint32_t n_out = 0;
+            MRT_HIP(hipMemcpyAsync(&n_out, wc.p, 4, hipMemcpyDeviceToHost, stream));
+            MRT_HIP(hipStreamSynchronize(stream));
+            total += n_in; base_in += n_in; n_in = n_out;
+            std::swap(fin, fo);
+        }
+        MRT_HIP(hipEventRecord(ev1, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        MRT_HIP(hipGetLastError());
+        float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
+        uint32_t h_wc[2]; MRT_HIP(hipMemcpy(h_wc, wc.p, 8, hipMemcpyDeviceToHost));
+        if (h_wc[1] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
+        out.stats.build_ms += wms;
+        out.wide_depth = depth;
+        if (depth <= WIDE_STACK) out.num_wnodes = total;       // deeper than the LDS stack: keep the rope backend
+        out.stats.scene_bytes += (uint64_t)total * 80 + (uint64_t)n * 48;
+        out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
+        out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;
+    }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     return MRT_OK;
 }
 

@@ -39,8 +39,9 @@ struct Renderer {
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
-    int frames_in_flight = 3;            // Renderer.maxFramesInFlight (Renderer.swift:33)
-    bool persistent = true;              // persistent wavefronts with lane refill for the two traversal kernels
+    int frames_in_flight = 4;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 4 lanes measured best on MI355X
+    bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)
+    bool persistent = false;             // persistent wavefronts with lane refill for the two traversal kernels
     int persistent_waves = 8192;         // 256 CUs x 32 waves
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays

@@ -19,6 +19,7 @@
 #include "renderer.h"
 #include "device_math.h"
 #include "traverse.h"
+#include "traverse_wide.h"
 #include <cstring>
 #include <algorithm>
 
@@ -90,6 +91,34 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
     TravHit h;
     bool hit = traverse<false>(s, mk3(A), mk3(B), 0.0f, A.w, h);
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+
+// ------------------------------------------------------------------ wide-BVH backend (LDS stack)
+__global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
+                                                    const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
+    __shared__ uint2 stk[WIDE_STACK][64];
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    uint32_t n = count ? (uint32_t)*count : capacity;
+    if (i >= n) return;
+    float4 A = rayA[i], B = rayB[i];
+    if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
+    TravHit h;
+    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
+    hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+__global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                    const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
+    __shared__ uint2 stk[WIDE_STACK][64];
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= (uint32_t)(*count >> 32)) return;
+    float4 A = srayA[i], B = srayB[i];
+    TravHit h;
+    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
+    if (!occluded) {
+        uint32_t pix = __float_as_uint(B.w);
+        float4 c = scon[i], a = sample[pix];
+        sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------ persistent variants (lane refill)
@@ -283,12 +312,15 @@ __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4
 }
 
 // ------------------------------------------------------------------ query kernels (C-ABI intersect_*)
+template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, MRTIntersection *__restrict__ out) {
+    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
     TravHit h;
-    bool hit = traverse<false>(s, mk3(r.origin[0], r.origin[1], r.origin[2]), mk3(r.direction[0], r.direction[1], r.direction[2]), r.min_distance, r.max_distance, h);
+    const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
     MRTIntersection o;
     o._pad = 0;
     if (hit) {
@@ -300,27 +332,33 @@ __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay 
     } else { o.type = 0; o.distance = -1.0f; o.instance_id = o.geometry_id = o.primitive_id = -1; o.u = o.v = 0.0f; }
     out[i] = o;
 }
+template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int32_t *__restrict__ out) {
+    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
     TravHit h;
-    out[i] = traverse<true>(s, mk3(r.origin[0], r.origin[1], r.origin[2]), mk3(r.direction[0], r.direction[1], r.direction[2]), r.min_distance, r.max_distance, h) ? 1 : 0;
+    const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
 }
 
 // per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
+template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t *__restrict__ out) {
+    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
     TravHit h; TravCounters tc{0, 0, 0, 0};
+    tc.alu_dup = (any >> 8) & 0xFF; tc.mem_dup = (any >> 16) & 0xFF; any &= 1;
     f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
     unsigned long long t0 = wall_clock64();
-    if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
-    else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc);
+    if (WIDE) { if (any) traverse_wide<true, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); else traverse_wide<false, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); }
+    else { if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); }
     unsigned long long t1 = wall_clock64();
     out[8 * i + 0] = tc.steps; out[8 * i + 1] = tc.leaves; out[8 * i + 2] = tc.tris; out[8 * i + 3] = h.gid;
-    out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters; out[8 * i + 7] = 0;   // 100 MHz ticks
+    out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters; out[8 * i + 7] = __float_as_uint(tc.sink);   // 100 MHz ticks
 }
 
 // ------------------------------------------------------------------ device-function probes
@@ -429,6 +467,7 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
+    const bool wide = use_wide && sv.num_wnodes > 0;
     const uint32_t grid_p = std::max<uint32_t>(1u, std::min<uint32_t>(grid, (uint32_t)persistent_waves));
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
@@ -449,12 +488,14 @@ int Renderer::render(int n_frames) {                                   // Render
             const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
             bool timed = ext_used < (int)ev_ext.size();
             if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
-            if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+            if (wide) hipLaunchKernelGGL(k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+            else if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
             else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
             if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
             hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b);
-            if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+            if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+            else if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
             else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
             q = 1 - q;
         }
@@ -538,7 +579,8 @@ int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays,
     DevBuf<MRTRay> d_r; DevBuf<MRTIntersection> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_query_closest, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_closest<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    else hipLaunchKernelGGL(k_query_closest<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * sizeof(MRTIntersection), hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
@@ -549,7 +591,8 @@ int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, siz
     DevBuf<MRTRay> d_r; DevBuf<int32_t> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_query_any, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_any<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    else hipLaunchKernelGGL(k_query_any<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * 4, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
@@ -561,7 +604,8 @@ int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, s
     DevBuf<MRTRay> d_r; DevBuf<uint32_t> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_query_stats, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_stats<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
+    else hipLaunchKernelGGL(k_query_stats<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
     MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());

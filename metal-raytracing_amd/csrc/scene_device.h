@@ -33,6 +33,16 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 //   {v0.xyz, gid} {e1.xyz, -} {e2.xyz, -}
 // ---- shading record per global triangle id (16 B): vertex ids into `normals` + (instance<<16 | geometry)
 
+// ---- wide node: 80 B = 5 x float4, eight children with 8-bit quantised boxes (after Ylitie, Karras, Laine
+// 2017, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"):
+//   f4 0: origin p.xyz | ex | ey<<8 | ez<<16 | imask<<24      child box = p + q * 2^(e-127); imask bit i = child i is a node
+//   f4 1: child_base | tri_base | meta[0..3] | meta[4..7]      node child i -> child_base + popc(imask & ((1<<i)-1));
+//                                                              leaf child i -> packets tri_base + (meta&31) .. + (meta>>5) - 1
+//   f4 2: qlo_x[8] qlo_y[8]      f4 3: qlo_z[8] qhi_x[8]      f4 4: qhi_y[8] qhi_z[8]      (empty slot: qlo=255, qhi=0)
+// Slot bit k set = the child lies on the + side of the node centre along axis k, so children are entered
+// front to back in the order of (slot ^ ray octant).
+constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
+
 struct LightDev {            // 96 B, derived once per mrt_scene_set_lights from the 128-B MRTLight
     float4 position;         // .w = type (as int bits)
     float4 color;
@@ -51,6 +61,10 @@ struct SceneView {           // passed by value to kernels
     const float4 *inst_cols;     // 3 x float4 per instance: columns 0..2 of the 4x3 transform
     const uint32_t *geom_base;   // per resource slot: first gid
     const LightDev *lights;
+    // 8-wide compressed layout (WideNode below) for the LDS-stack traversal backend; num_wnodes == 0 → not built
+    const float4 *wnodes;        // 5 x float4 per wide node
+    const float4 *wpackets;      // 3 x float4 per triangle, grouped per wide node
+    uint32_t num_wnodes;
     uint32_t num_nodes;
     uint32_t num_tris;
     int32_t light_count;
@@ -87,10 +101,12 @@ struct BuildOptions {
     float cost_trav = 1.0f;   // SAH constants
     float cost_isect = 1.0f;
     int ploc_radius = 16;
+    int wide = 0;             // 1 = also build the 8-wide compressed layout (LDS-stack backend, renderer option "wide")
 };
 
 struct DeviceScene {
-    DevBuf<float4> nodes, packets, normals, base_color, inst_cols;
+    DevBuf<float4> nodes, packets, normals, base_color, inst_cols, wnodes, wpackets;
+    uint32_t num_wnodes = 0; int wide_depth = 0;
     DevBuf<uint4> tri_shade;
     DevBuf<uint32_t> geom_base;
     DevBuf<LightDev> lights;

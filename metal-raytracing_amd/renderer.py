@@ -81,11 +81,11 @@ class DeviceScene:
         check(lib.mrt_scene_intersect_any(self.handle, ptr(rays), rays.shape[0], ptr(out)))
         return out
 
-    def traversal_stats(self, rays, any_hit=False):
+    def traversal_stats(self, rays, any_hit=False, alu_dup=0, mem_dup=0):
         """Diagnostics: (n, 8) uint32 {node visits, leaf visits, triangle tests, hit gid, t0, t1, 0, 0} per ray."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         out = np.zeros((rays.shape[0], 8), np.uint32)
-        check(lib.mrt_debug_traversal_stats(self.handle, ptr(rays), rays.shape[0], 1 if any_hit else 0, ptr(out)))
+        check(lib.mrt_debug_traversal_stats(self.handle, ptr(rays), rays.shape[0], (1 if any_hit else 0) | (alu_dup << 8) | (mem_dup << 16), ptr(out)))
         return out
 
     def close(self):

@@ -345,3 +345,30 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
     mean = sum(singles) / 4
     assert np.allclose(acc[..., :3], mean, rtol=1e-5, atol=1e-6)
     assert np.array_equal(singles[0].astype(np.float32), img[..., :3])
+
+
+# ---------------------------------------------------------------- alternative traversal backends
+@pytest.mark.parametrize("backend", ["rope", "rope_persistent", "wide_lds_stack", "one_frame_in_flight", "eight_frames_in_flight"])
+def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
+    """Every traversal backend / scheduling option must give the oracle's image: the stackless rope walk
+    (default), its persistent-wavefront variant (lane refill + postponed leaves), the 8-wide compressed
+    layout with the LDS stack, and any number of frames in flight."""
+    w, h = 256, 144
+    sc = mrt.DragonScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"wide": 1} if backend == "wide_lds_stack" else None)
+    if backend == "rope_persistent": r.set_option("persistent", 1); r.set_option("persistent_waves", 97)
+    if backend == "wide_lds_stack": r.set_option("wide", 1)
+    if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
+    if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
+    r.draw(5, wait=True)
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
+    assert_parity(r.accumulation(), ref)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    if backend == "wide_lds_stack":
+        rays = _rays(np.random.default_rng(3), 4000, np.array([-2, 0, -1.5]), np.array([3, 2, 3]))
+        osc = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
+        g, o = r.device_scene.intersect_closest(rays), osc.intersect_closest(rays)
+        assert np.array_equal(g["primitive_id"], o["primitive_id"]) and np.array_equal(g["distance"].view(np.uint32), o["distance"].view(np.uint32))
+        rays[:, 7] = 1.5
+        assert np.array_equal(r.device_scene.intersect_any(rays), osc.intersect_any(rays))
+    r.close()
