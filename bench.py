@@ -55,12 +55,27 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic():
+    """HBM bytes per k_extend launch from the rocprofv3 PMC passes kept under profiles/ (tools/collect_profiles.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
+    gfx950; gather widths are uncalibrated, so this is an upper estimate).  None if no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["hbm_traffic_bytes_per_launch"]["k_extend"]["bytes_corrected"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(mrt, scene, w, h, bounces, threads):
     """The oracle (CPU restatement, kind 'port') on the GPU box's host cores: one full frame of the
     same workload, same seeds.  Reported, never the thing shipped."""
     import oracle as O
     O.build_oracle()
-    threads = threads or (os.cpu_count() or 1)
+    threads = threads or min(os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU is 16 cores
     osc = O.OracleScene(mrt.flatten_scene(scene), scene.lights)
     r = O.OracleRenderer(osc, w, h, seed=1, max_bounces=bounces, camera=scene.camera)
     t0 = time.perf_counter()
@@ -90,6 +105,7 @@ def main():
         sys.exit("launch with torch.distributed.run for --gpus > 1")
 
     import metal_raytracing_amd as mrt
+    from metal_raytracing_amd.distributed import reduce_accumulation
     w, h = a.width, a.height
     scene = mrt.SCENES[a.scene]((w, h))
     opts = {} if a.builder is None else {"builder": a.builder}
@@ -134,9 +150,7 @@ def main():
         done += k
     if world > 1:
         r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
-        dist.reduce(accum_t, dst=0)
-        if a.shard == "sample" and rank == 0:
-            accum_t /= world
+        reduce_accumulation(accum_t, a.shard, dst=0)      # the ONE collective per output image (RCCL over xGMI)
     sync()
     dt = time.perf_counter() - t0
     st = r.stats
@@ -158,6 +172,7 @@ def main():
         avg_ms = ext_ms / max(1, ext_launches)
         achieved = BYTES_PER_CLOSEST_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = st.bytes_alg / max(1, st.frames)
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -172,7 +187,8 @@ def main():
                        "frame_bytes_alg": frame_bytes, "frame_alg_GBps": round(frame_bytes * st.frames / dt / 1e9, 2),
                        "device": r.ctx.device_name},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(BYTES_PER_CLOSEST_RAY * rays_per_launch),
                          "bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": ext_launches},
         }

@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of one image: one process per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI), no collective on the data path while rendering, ONE reduce of the RGBA32F radiance buffer per
+output image.  The reference is single-GPU (MTLCreateSystemDefaultDevice,
+Renderer.swift:46); this layer is new.
+
+Two partitions:
+  * "tile"   — rank r owns the 8x8 screen tiles with tile_id % world == r (round-robin, so the expensive
+               screen regions are spread over all GPUs); every rank accumulates its own pixels over all
+               frames, other pixels stay 0; the reduce is a disjoint sum.  Strong scaling.
+  * "sample" — every rank renders full frames for a disjoint range of sample indices (Halton index offset);
+               the reduce sums the per-rank means and rank 0 divides by world.  Weak scaling.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def tile_owner_map(width, height, world):
+    """(height, width) int32: owning rank of every pixel under the "tile" partition."""
+    tiles_x = (width + 7) // 8
+    ys, xs = np.mgrid[0:height, 0:width]
+    return (((ys // 8) * tiles_x + xs // 8) % world).astype(np.int32)
+
+
+def owned_pixel_count(width, height, rank, world):
+    return int((tile_owner_map(width, height, world) == rank).sum())
+
+
+def reduce_accumulation(accum: torch.Tensor, mode="tile", dst=0, group=None):
+    """Assemble the image on `dst` from the per-rank accumulation buffers (in place on `dst`)."""
+    world = dist.get_world_size(group)
+    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if mode == "sample" and dist.get_rank(group) == dst:
+        accum /= world
+    return accum
+
+
+class ShardedRenderer:
+    """A Renderer bound to this rank's GPU and shard.  `gather()` runs the one collective."""
+
+    def __init__(self, size, scene, rank, world, mode="tile", device=None, frames_total=None, **kw):
+        from .renderer import Renderer
+        self.rank, self.world, self.mode = rank, world, mode
+        self.renderer = Renderer(size, scene, device=rank if device is None else device, **kw)
+        if world > 1:
+            if mode == "tile":
+                self.renderer.set_shard(rank, world)
+            elif mode == "sample":
+                if frames_total is None:
+                    raise ValueError("sample sharding needs frames_total (frames per rank)")
+                self.renderer.set_option("sample_offset", rank * int(frames_total))
+            else:
+                raise ValueError(mode)
+        w, h = self.renderer.size
+        self.buffer = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{self.renderer.ctx.device}")
+
+    def draw(self, frames=1):
+        self.renderer.draw(frames)
+
+    def gather(self, dst=0):
+        r = self.renderer
+        r.copy_accum_to(self.buffer.data_ptr(), self.buffer.numel() * 4)
+        r.wait()
+        if self.world > 1:
+            reduce_accumulation(self.buffer, self.mode, dst)
+        return self.buffer
+
+    def close(self):
+        self.renderer.close()

@@ -1,0 +1,40 @@
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the small summaries kept under profiles/."""
+import csv, glob, json, os, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)      # merged back by gpurun; copy into profiles/ afterwards
+os.makedirs(P, exist_ok=True)
+res = {}
+ks = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if ks:
+    rows = list(csv.DictReader(open(ks[0])))
+    with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            import re
+            mm = re.search(r"(k_[a-z0-9_]+)", r["Name"]); name = mm.group(1) if mm else r["Name"].split("(")[0]
+            f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    for r in rows:
+        for k in ("k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+            if k + "(" in r["Name"] or r["Name"].endswith(k):
+                res.setdefault("kernel_avg_us", {})[k] = float(r["AverageNs"]) / 1e3
+                res.setdefault("kernel_calls", {})[k] = int(r["Calls"])
+def pmc(dirname, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter: continue
+            for k in ("k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+                if k + "(" in r["Kernel_Name"]: acc[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+# units: KB (1024 B) per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes
+# of wide coalesced reads -> x2; other access widths are uncalibrated, so this is an upper estimate for gathers.
+res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": fetch.get(k), "write_KB": write.get(k),
+                                           "bytes_corrected": (2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 if k in fetch else None} for k in set(fetch) | set(write)}
+try:
+    res["bench_under_rocprof"] = json.loads(open(out + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
+except Exception as e:
+    res["bench_under_rocprof"] = str(e)
+json.dump(res, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "bench_under_rocprof"}, indent=1))
