@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--shard", default="tile", choices=["tile", "sample"])
     ap.add_argument("--builder", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
+    ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="Renderer.maxFramesInFlight (default 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -109,6 +110,8 @@ def main():
     w, h = a.width, a.height
     scene = mrt.SCENES[a.scene]((w, h))
     opts = {} if a.builder is None else {"builder": a.builder}
+    for kv in a.sopt:
+        k, v = kv.split("="); opts[k] = float(v)
     r = mrt.Renderer((w, h), scene, device=local_rank, seed=1, max_bounces=a.bounces, scene_options=opts)
     sst = r.device_scene.stats
     for kv in a.opt:
@@ -166,11 +169,16 @@ def main():
 
     if rank == 0:
         value = (closest + shadow) / dt / 1e6
-        # dominant kernel: k_extend (closest-hit traversal).  Algorithmic bytes per launch = 96 B x rays in the launch.
-        launches_total = a.steps * a.bounces
-        rays_per_launch = st.closest_rays / launches_total
+        # dominant kernels: the traversal launches (k_trace_primary + k_trace_mixed; k_extend in the unfused pipeline).
+        # Algorithmic bytes per launch = (96 B x closest-hit rays + 72 B x shadow rays) / traversal launches;
+        # the fused launches carry both kinds, the unfused k_extend only the 96-B rays.
+        launches_per_frame = max(1.0, ext_launches / a.steps) if ext_launches < 512 else float(a.bounces + 1)
+        fused = launches_per_frame > a.bounces + 0.5
+        traced_bytes = BYTES_PER_CLOSEST_RAY * st.closest_rays + (BYTES_PER_SHADOW_RAY * st.shadow_rays if fused else 0)
+        bytes_per_launch = traced_bytes / (a.steps * launches_per_frame)
+        rays_per_launch = (st.closest_rays + (st.shadow_rays if fused else 0)) / (a.steps * launches_per_frame)
         avg_ms = ext_ms / max(1, ext_launches)
-        achieved = BYTES_PER_CLOSEST_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = st.bytes_alg / max(1, st.frames)
         traffic, traffic_src = measured_traffic()
         out = {
@@ -186,10 +194,10 @@ def main():
                        "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
                        "frame_bytes_alg": frame_bytes, "frame_alg_GBps": round(frame_bytes * st.frames / dt / 1e9, 2),
                        "device": r.ctx.device_name},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_trace_primary+k_trace_mixed" if fused else "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(BYTES_PER_CLOSEST_RAY * rays_per_launch),
-                         "bytes_per_ray": BYTES_PER_CLOSEST_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                         "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": ext_launches},
         }
         if a.png:

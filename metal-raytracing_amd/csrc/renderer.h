@@ -40,6 +40,7 @@ struct Renderer {
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 4;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 4 lanes measured best on MI355X
+    bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)
     bool persistent = false;             // persistent wavefronts with lane refill for the two traversal kernels
     int persistent_waves = 8192;         // 256 CUs x 32 waves
@@ -47,7 +48,7 @@ struct Renderer {
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    std::array<EvPair, 192> ev_ext;
+    std::array<EvPair, 512> ev_ext;
     int ext_used = 0;
     bool pending_timing = false;
     float ms_last = 0, ms_extend_last = 0; uint32_t extend_launches_last = 0;

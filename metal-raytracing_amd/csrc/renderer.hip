@@ -55,6 +55,19 @@ __global__ void k_seed(uint32_t *__restrict__ seeds, uint32_t n, uint32_t seed) 
 }
 
 // ------------------------------------------------------------------ primary rays
+// Raytracing.metal:175, :202-221
+MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, int x, int y, f3 &org, f3 &dir) {
+    uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    uint32_t offset = seeds[pix];                                        // :175
+    int idx = (int)(offset + fp.sampleIndex);
+    float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
+    float px = (float)x + r0, py = (float)y + r1;                        // :204
+    float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
+    uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
+    dir = normalize3((uvx * mk3(fp.cam_right) + uvy * mk3(fp.cam_up)) + mk3(fp.cam_fwd));   // :216-218
+    org = mk3(fp.cam_pos);                                               // :214
+}
+
 __global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *__restrict__ seeds,
                                                float4 *__restrict__ rayA, float4 *__restrict__ rayB, float4 *__restrict__ thr,
                                                float4 *__restrict__ sample) {
@@ -91,6 +104,50 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
     TravHit h;
     bool hit = traverse<false>(s, mk3(A), mk3(B), 0.0f, A.w, h);
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+
+// ------------------------------------------------------------------ fused pipeline (default)
+// Fewer, fatter traversal launches: every launch ends in a latency-bound tail (a handful of waves walking
+// the longest rays), so the frame runs  primary -> shade -> [shadow(b) + extend(b+1)] -> shade -> ... .
+//   k_trace_primary : primary-ray generation (Raytracing.metal:171-221) fused with the first closest-hit query
+//   k_trace_mixed   : one launch over two queues — the next-bounce rays (closest hit -> hit records) and the
+//                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
+//                     the loop; a shadow lane simply stops at its first hit.
+__global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits) {
+    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) {
+        if ((int)(slot >> 6) < fp.tiles_local) hits[slot] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        return;
+    }
+    f3 org, dir;
+    primary_ray(fp, seeds, x, y, org, dir);
+    TravHit h;
+    bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
+    hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+
+__global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                    const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                    const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_next + n_shadow) return;
+    const bool shadow = i >= n_next;
+    const uint32_t j = shadow ? i - n_next : i;
+    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
+    TravHit h;
+    bool hit = traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow);
+    if (shadow) {
+        if (!hit) {
+            uint32_t pix = __float_as_uint(B.w);
+            float4 cc = scon[j], a = sample[pix];
+            sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f);   // one shadow ray per pixel per bounce: no atomics
+        }
+    } else {
+        hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    }
 }
 
 // ------------------------------------------------------------------ wide-BVH backend (LDS stack)
@@ -155,12 +212,18 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
                                               float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon,
-                                              unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */) {
+                                              unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */,
+                                              float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */) {
     __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES];
     __shared__ unsigned long long blk_base;
     uint32_t i = blockIdx.x * SHADE_THREADS + threadIdx.x;
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
     bool active = i < n;
+    int px_x = 0, px_y = 0;
+    if (sample_primary) {
+        active = active && slot_to_pixel(fp, i, px_x, px_y);
+        if (active) sample_primary[(uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // Raytracing.metal:227
+    }
     float4 H = active ? hits[i] : make_float4(-1, 0, 0, 0);
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
@@ -168,7 +231,14 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
     f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0);
     float ldist = 0.0f; uint32_t pix = 0;
     if (active) {
-        float4 A = rayA[i], B = rayB[i], C = thr[i];
+        float4 A, B, C;
+        if (sample_primary) {
+            f3 org, dir;
+            primary_ray(fp, seeds, px_x, px_y, org, dir);
+            A = make_float4(org.x, org.y, org.z, __builtin_inff());
+            B = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x));
+            C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
+        } else { A = rayA[i]; B = rayB[i]; C = thr[i]; }
         pix = __float_as_uint(B.w);
         uint4 ts = s.tri_shade[gid];
         uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
@@ -481,23 +551,45 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229
         fp.sampleIndex = frame_index + sample_offset;
+        if (fused && !wide && !persistent) {
+            const uint32_t grid_mixed = 2 * grid;
+            auto timed_begin = [&]() -> bool { bool t = ext_used < (int)ev_ext.size(); if (t) (void)hipEventRecord(ev_ext[ext_used].a, st); return t; };
+            auto timed_end = [&](bool t) { if (t) { (void)hipEventRecord(ev_ext[ext_used].b, st); ext_used++; } };
+            fp.bounce = 0;
+            bool t0 = timed_begin();
+            hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
+            timed_end(t0);
+            int q = 0;                                                  // shade(b) writes next rays into queue q
+            for (int b = 0; b < max_bounces; b++) {
+                fp.bounce = b;
+                const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
+                // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
+                hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
+                bool t1 = timed_begin();
+                hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                timed_end(t1);
+                q = 1 - q;
+            }
+        } else {
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
-        int q = 0;
-        for (int b = 0; b < max_bounces; b++) {
-            fp.bounce = b;
-            const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
-            bool timed = ext_used < (int)ev_ext.size();
-            if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
-            if (wide) hipLaunchKernelGGL(k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-            else if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-            else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-            if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
-            hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
-                               L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b);
-            if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-            else if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-            else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-            q = 1 - q;
+            int q = 0;
+            for (int b = 0; b < max_bounces; b++) {
+                fp.bounce = b;
+                const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
+                bool timed = ext_used < (int)ev_ext.size();
+                if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
+                if (wide) hipLaunchKernelGGL(k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+                else if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+                else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+                if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
+                hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
+                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr);
+                if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                q = 1 - q;
+            }
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
         if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));

@@ -46,8 +46,8 @@ struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0,
 // advances (a box test or a triangle test).  Measured on MI355X the wave time is (iterations of its
 // slowest lane) x (round-trip latency); a split inner-node / leaf loop made the slowest wave iterate
 // 4x more often than any of its lanes needed.
-template <bool ANY, bool STATS = false>
-MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr) {
+template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
+MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_nodes == 0) return false;
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
@@ -65,7 +65,7 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
             tri++;
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
-                if (ANY) return true;
+                if (ANY || (RUNTIME_ANY && any_rt)) return true;
                 const uint32_t gid = __float_as_uint(r0.w);
                 if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
             }

@@ -6,6 +6,6 @@ out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-
 try:
     d = json.loads(out.stdout.strip().splitlines()[-1])
     r = d["roofline"]
-    print(f"value={d['value']} Mrays/s  ms/frame={d['ms_per_step']}  extend avg {r['avg_launch_ms']} ms ({r['achieved']} GB/s alg)  build {d['config']['bvh_build_ms']} ms  sah {d['config']['sah_cost']}")
+    print(f"value={d['value']} Mrays/s  ms/frame={d['ms_per_step']}  trace avg {r['avg_launch_ms']} ms ({r['achieved']} GB/s alg)  build {d['config']['bvh_build_ms']} ms  sah {d['config']['sah_cost']}")
 except Exception as e:
     print("bench failed:", e, out.stdout[-2000:], out.stderr[-3000:])

@@ -15,7 +15,7 @@ if ks:
             mm = re.search(r"(k_[a-z0-9_]+)", r["Name"]); name = mm.group(1) if mm else r["Name"].split("(")[0]
             f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
     for r in rows:
-        for k in ("k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+        for k in ("k_trace_primary", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
             if k + "(" in r["Name"] or r["Name"].endswith(k):
                 res.setdefault("kernel_avg_us", {})[k] = float(r["AverageNs"]) / 1e3
                 res.setdefault("kernel_calls", {})[k] = int(r["Calls"])
@@ -24,7 +24,7 @@ def pmc(dirname, counter):
     for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter: continue
-            for k in ("k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+            for k in ("k_trace_primary", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
                 if k + "(" in r["Kernel_Name"]: acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
