@@ -182,6 +182,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "lds_nodes") { REQUIRE(value >= 0 && value <= 2048, "lds_nodes must be in [0,2048]"); scene->opt.lds_nodes = (int)value; }
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     scene->committed = false;
@@ -347,6 +348,8 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,8]"); r->r.frames_in_flight = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
+    else if (k == "lds") r->r.use_lds = value != 0;
+    else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "persistent") r->r.persistent = value != 0;
     else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }

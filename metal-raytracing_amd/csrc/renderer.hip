@@ -150,6 +150,59 @@ __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *_
     }
 }
 
+// ---- the same two kernels with the hot top of the tree staged in LDS ("LDS-staged BVH nodelets"): workgroups of
+// TRACE_LDS_THREADS threads copy nodes [0, hot) (64 B each, largest surface area first) into LDS once and then
+// serve every visit of those nodes from LDS instead of the L1/TA path.
+constexpr int TRACE_LDS_THREADS = 512;
+
+MRT_DEV void stage_hot_nodes(const SceneView &s, float4 *lds) {
+    const uint32_t words = s.hot_nodes * 4u;
+    for (uint32_t k = threadIdx.x; k < words; k += TRACE_LDS_THREADS) lds[k] = s.nodes[k];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TRACE_LDS_THREADS) k_trace_primary_lds(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits) {
+    extern __shared__ float4 lds_nodes[];
+    stage_hot_nodes(s, lds_nodes);
+    uint32_t slot = blockIdx.x * TRACE_LDS_THREADS + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) {
+        if ((int)(slot >> 6) < fp.tiles_local) hits[slot] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        return;
+    }
+    f3 org, dir;
+    primary_ray(fp, seeds, x, y, org, dir);
+    TravHit h;
+    bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h, nullptr, false, lds_nodes, s.hot_nodes);
+    hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+}
+
+__global__ void __launch_bounds__(TRACE_LDS_THREADS) k_trace_mixed_lds(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                       const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                                       const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
+    extern __shared__ float4 lds_nodes[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
+    if (blockIdx.x * TRACE_LDS_THREADS >= n_next + n_shadow) return;          // whole workgroup beyond the queues: nothing to stage for
+    stage_hot_nodes(s, lds_nodes);
+    uint32_t i = blockIdx.x * TRACE_LDS_THREADS + threadIdx.x;
+    if (i >= n_next + n_shadow) return;
+    const bool shadow = i >= n_next;
+    const uint32_t j = shadow ? i - n_next : i;
+    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
+    TravHit h;
+    bool hit = traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow, lds_nodes, s.hot_nodes);
+    if (shadow) {
+        if (!hit) {
+            uint32_t pix = __float_as_uint(B.w);
+            float4 cc = scon[j], a = sample[pix];
+            sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f);
+        }
+    } else {
+        hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    }
+}
+
 // ------------------------------------------------------------------ wide-BVH backend (LDS stack)
 __global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                     const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
@@ -160,7 +213,7 @@ __global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *_
     float4 A = rayA[i], B = rayB[i];
     if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
     TravHit h;
-    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
+    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, &stk[0][0]);
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 __global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
@@ -170,11 +223,35 @@ __global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *_
     if (i >= (uint32_t)(*count >> 32)) return;
     float4 A = srayA[i], B = srayB[i];
     TravHit h;
-    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
+    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, &stk[0][0]);
     if (!occluded) {
         uint32_t pix = __float_as_uint(B.w);
         float4 c = scon[i], a = sample[pix];
         sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                         const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                         const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
+    extern __shared__ uint2 stk_dyn[];        // [wide-tree depth][64]: 512 B per level, sized by the host from the scene's depth
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_next + n_shadow) return;
+    const bool shadow = i >= n_next;
+    const uint32_t j = shadow ? i - n_next : i;
+    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
+    TravHit h;
+    bool hit = traverse_wide<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk_dyn, nullptr, shadow);
+    if (shadow) {
+        if (!hit) {
+            uint32_t pix = __float_as_uint(B.w);
+            float4 cc = scon[j], a = sample[pix];
+            sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f);
+        }
+    } else {
+        hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
     }
 }
 
@@ -390,7 +467,7 @@ __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay 
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
+    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, &stk[0][0]) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
     MRTIntersection o;
     o._pad = 0;
     if (hit) {
@@ -410,7 +487,7 @@ __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__r
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
+    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, &stk[0][0]) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
 }
 
 // per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
@@ -424,7 +501,7 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
     tc.alu_dup = (any >> 8) & 0xFF; tc.mem_dup = (any >> 16) & 0xFF; any &= 1;
     f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
     unsigned long long t0 = wall_clock64();
-    if (WIDE) { if (any) traverse_wide<true, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); else traverse_wide<false, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); }
+    if (WIDE) { if (any) traverse_wide<true, true>(s, o, d, r.min_distance, r.max_distance, h, &stk[0][0], &tc); else traverse_wide<false, true>(s, o, d, r.min_distance, r.max_distance, h, &stk[0][0], &tc); }
     else { if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); }
     unsigned long long t1 = wall_clock64();
     out[8 * i + 0] = tc.steps; out[8 * i + 1] = tc.leaves; out[8 * i + 2] = tc.tris; out[8 * i + 3] = h.gid;
@@ -553,11 +630,14 @@ int Renderer::render(int n_frames) {                                   // Render
         fp.sampleIndex = frame_index + sample_offset;
         if (fused && !wide && !persistent) {
             const uint32_t grid_mixed = 2 * grid;
+            const bool lds = use_lds && sv.hot_nodes > 0;
+            const uint32_t lds_bytes = sv.hot_nodes * 64u;
             auto timed_begin = [&]() -> bool { bool t = ext_used < (int)ev_ext.size(); if (t) (void)hipEventRecord(ev_ext[ext_used].a, st); return t; };
             auto timed_end = [&](bool t) { if (t) { (void)hipEventRecord(ev_ext[ext_used].b, st); ext_used++; } };
             fp.bounce = 0;
             bool t0 = timed_begin();
-            hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
+            if (lds) hipLaunchKernelGGL(k_trace_primary_lds, dim3(cdiv(capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, fp, seeds.p, L.hits.p);
+            else hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             timed_end(t0);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
@@ -567,7 +647,9 @@ int Renderer::render(int n_frames) {                                   // Render
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 bool t1 = timed_begin();
-                hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 timed_end(t1);
                 q = 1 - q;
             }

@@ -47,20 +47,37 @@ struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0,
 // slowest lane) x (round-trip latency); a split inner-node / leaf loop made the slowest wave iterate
 // 4x more often than any of its lanes needed.
 template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
-MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false) {
+MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false,
+                      const float4 *lds_nodes = nullptr, uint32_t hot = 0) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_nodes == 0) return false;
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    // slab planes as one fma each: t = plane * inv - o * inv.  The extra rounding (<= 1 ulp of o*inv, i.e.
+    // <= 6e-8 * |o| along the axis) is far inside the build-time padding of the boxes (1e-6 + 1e-5 * |coord|).
+    const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t esc_quad = 2u + (oct >> 2), esc_lane = oct & 3u;
+    const uint32_t esc_off = 32u + ((oct >> 2) << 4), esc_lane = oct & 3u;
+    // nodes and packets live in one allocation: one wave-uniform base + a 32-bit byte offset per lane
+    const char *__restrict__ base = reinterpret_cast<const char *>(s.nodes);
+    const uint32_t pk0 = (uint32_t)(reinterpret_cast<const char *>(s.packets) - base);
     uint32_t cur = 0;                 // next node, NODE_TERM when the walk is over
     uint32_t tri = 0, tri_end = 0;    // pending packets of the current leaf
     for (;;) {
         const bool do_tri = tri < tri_end;
         if (!do_tri && cur == NODE_TERM) break;
         if (STATS) { if (do_tri) tc->tris++; else tc->steps++; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc->wave_iters++; }
-        const float4 *__restrict__ rec = do_tri ? s.packets + 3 * (size_t)tri : s.nodes + 4 * (size_t)cur;
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[do_tri ? 2u : esc_quad];
+        const uint32_t off = do_tri ? pk0 + tri * 48u : cur << 6;
+        float4 r0, r1, r2;
+        if (!do_tri && cur < hot) {
+            // the `hot` largest-area nodes (the top of the tree, visited by most rays) are staged in LDS by the
+            // kernel: these steps bypass the vector-memory path, which is what bounds the bulk of the kernel
+            const float4 *__restrict__ ln = lds_nodes + 4u * cur;
+            r0 = ln[0]; r1 = ln[1]; r2 = ln[esc_off >> 4];
+        } else {
+            r0 = *reinterpret_cast<const float4 *>(base + off);
+            r1 = *reinterpret_cast<const float4 *>(base + off + 16u);
+            r2 = *reinterpret_cast<const float4 *>(base + off + (do_tri ? 32u : esc_off));
+        }
         if (do_tri) {
             tri++;
             float t, U, V, ad;
@@ -71,9 +88,9 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
             }
         } else {
             // conservative slab test: far side widened by ~4 ulp (Ize 2013), boxes padded at build time
-            float tx0 = (r0.x - o.x) * ix, tx1 = (r1.x - o.x) * ix;
-            float ty0 = (r0.y - o.y) * iy, ty1 = (r1.y - o.y) * iy;
-            float tz0 = (r0.z - o.z) * iz, tz1 = (r1.z - o.z) * iz;
+            float tx0 = __builtin_fmaf(r0.x, ix, nox), tx1 = __builtin_fmaf(r1.x, ix, nox);
+            float ty0 = __builtin_fmaf(r0.y, iy, noy), ty1 = __builtin_fmaf(r1.y, iy, noy);
+            float tz0 = __builtin_fmaf(r0.z, iz, noz), tz1 = __builtin_fmaf(r1.z, iz, noz);
             float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
             float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
             tf = fminf(tf, h.t);
@@ -87,7 +104,7 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
                 }
                 for (int r = 0; r < tc->mem_dup; r++) {
                     const float4 *__restrict__ rr = s.nodes + 4 * (size_t)((cur + 7919u * (r + 1)) % s.num_nodes);
-                    tc->sink += rr[0].x + rr[1].y + rr[esc_quad].z;
+                    tc->sink += rr[0].x + rr[1].y + rr[2].z;
                 }
             }
             const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);

@@ -20,9 +20,9 @@ namespace {
 
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
 
-// stack: LDS array of uint2 [WIDE_STACK][64] for the wave; `lane` indexes the second dimension
-template <bool ANY, bool STATS = false>
-MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, uint2 (*stack)[64], TravCounters *tc = nullptr) {
+// stack: LDS array of uint2 [depth][64] for the wave (depth = the scene's wide-tree depth, <= WIDE_STACK)
+template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
+MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, uint2 *stack /* [depth][64] in LDS */, TravCounters *tc = nullptr, bool any_rt = false) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_wnodes == 0) return false;
     const uint32_t lane = threadIdx.x & 63;
@@ -39,7 +39,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             if ((g_mask >> 8) == 0) {
                 if (sp == 0) break;
                 sp--;
-                const uint2 e = stack[sp][lane];
+                const uint2 e = stack[sp * 64u + lane];
                 g_base = e.x; g_mask = e.y;
             }
             const uint32_t hits = g_mask >> 8;
@@ -57,7 +57,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             const float4 r0 = pk[0], r1 = pk[1], r2 = pk[2];
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
-                if (ANY) return true;
+                if (ANY || (RUNTIME_ANY && any_rt)) return true;
                 const uint32_t gid = __float_as_uint(r0.w);
                 if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
             }
@@ -93,7 +93,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
                 }
             }
             if (STATS && tri_hits) tc->leaves++;
-            if ((g_mask >> 8) != 0) { stack[sp][lane] = make_uint2(g_base, g_mask); sp++; }     // siblings still to visit
+            if ((g_mask >> 8) != 0) { stack[sp * 64u + lane] = make_uint2(g_base, g_mask); sp++; }     // siblings still to visit
             g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | imask;
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }

@@ -81,16 +81,16 @@ def _rays(rng, n, lo, hi, tmax=np.inf):
     return rays
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder,wide", [(0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("name,n", [("plane", 500), ("sphere", 3000), ("train", 3000), ("treefir", 2000), ("teapot", 1500)])
-def test_intersect_matches_brute_force(mrt, orc, gpu_ctx, name, n, builder):
+def test_intersect_matches_brute_force(mrt, orc, gpu_ctx, name, n, builder, wide):
     class S(mrt.Scene):
         def __init__(self, size):
             super().__init__(size)
             self.models = [mrt.Model(name=name, position=[0.1, -0.2, 0.3], rotation=[0.2, 0.5, -0.1], scale=1.3),
                            mrt.Model(name="plane", position=[0, -3, 0], scale=50)]
     sc = S((8, 8))
-    ds = mrt.DeviceScene(gpu_ctx, sc, {"builder": builder})
+    ds = mrt.DeviceScene(gpu_ctx, sc, {"builder": builder, "wide": wide})
     osc = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
     me = sc.meshes[0]
     w = (me.transform.T @ np.c_[me.positions, np.ones(len(me.positions))].T).T[:, :3]
@@ -348,23 +348,27 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["rope", "rope_persistent", "wide_lds_stack", "one_frame_in_flight", "eight_frames_in_flight"])
+@pytest.mark.parametrize("backend", ["hybrid_default", "rope_only", "rope_unfused", "rope_persistent", "rope_lds_nodes", "wide_all", "one_frame_in_flight", "eight_frames_in_flight"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
-    """Every traversal backend / scheduling option must give the oracle's image: the stackless rope walk
-    (default), its persistent-wavefront variant (lane refill + postponed leaves), the 8-wide compressed
-    layout with the LDS stack, and any number of frames in flight."""
+    """Every traversal backend / scheduling option must give the oracle's image: the default hybrid (stackless
+    rope walk for primary rays, 8-wide compressed layout + LDS stack for bounce and shadow rays), rope only,
+    the unfused kernel sequence, the persistent-wavefront variant (lane refill + postponed leaves), LDS-staged
+    hot nodes, wide layout for everything, and any number of frames in flight."""
     w, h = 256, 144
     sc = mrt.DragonScene((w, h))
-    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"wide": 1} if backend == "wide_lds_stack" else None)
+    sopt = {"wide": 0} if backend.startswith("rope") else None
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
+    if backend == "rope_unfused": r.set_option("fused", 0)
     if backend == "rope_persistent": r.set_option("persistent", 1); r.set_option("persistent_waves", 97)
-    if backend == "wide_lds_stack": r.set_option("wide", 1)
+    if backend == "rope_lds_nodes": r.set_option("lds", 1)
+    if backend == "wide_all": r.set_option("wide", 1)
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     r.draw(5, wait=True)
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
-    if backend == "wide_lds_stack":
+    if backend in ("hybrid_default", "rope_only"):          # the query entry points use the wide layout when the scene has one
         rays = _rays(np.random.default_rng(3), 4000, np.array([-2, 0, -1.5]), np.array([3, 2, 3]))
         osc = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
         g, o = r.device_scene.intersect_closest(rays), osc.intersect_closest(rays)
