@@ -350,6 +350,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "fused") r->r.fused = value != 0;
     else if (k == "lds") r->r.use_lds = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
+    else if (k == "wide_stream") r->r.wide_stream = value != 0;
     else if (k == "persistent") r->r.persistent = value != 0;
     else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }

@@ -41,6 +41,7 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 4;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 4 lanes measured best on MI355X
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
+    bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 256 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_lds = false;                // stage the scene's hot nodes (largest area first) in LDS in the trace kernels
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)

@@ -101,5 +101,133 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
     return h.gid != 0xFFFFFFFFu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-level stream traversal with lane refill (the "persistent wavefront + ray compaction" of BASELINE.json
+// configs[4]) on the wide layout.  rocprofv3 on the one-ray-per-lane kernel: VALUBusy 81 %, VALUUtilization 19 % —
+// the VALU is saturated by instructions in which four lanes out of five are idle, because the rays of a wave
+// finish at very different times.  Here a wave owns `per_wave` consecutive rays of the queue; the next 64 of
+// them are PREFETCHED into registers (origin, direction, 1/direction — computed by all 64 lanes at full
+// occupancy), and whenever REFILL_AT lanes are idle they take the next prefetched rays by cross-lane reads
+// (ds_bpermute), without touching memory.  A refilled lane starts with an empty stack, so nothing but the ray
+// moves.  `emit(idx, B.w, hit, h)` is called by a lane when its ray finishes.
+constexpr int WIDE_REFILL_AT = 16;
+
+template <class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint2 *stack, RayFetch fetch, Emit emit) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // prefetched batch: ray (batch_base + lane)
+    float4 pA = make_float4(0, 0, 0, 0), pB = pA; float pix_ = 0, piy_ = 0, piz_ = 0; uint32_t p_any = 0;
+    uint32_t batch_base = begin, batch_used = 64;      // wave-uniform; used == 64 -> nothing prefetched
+    uint32_t next_batch = begin;
+    // live ray
+    bool live = false; bool any = false;
+    uint32_t idx = 0, pixw = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); float ix = 0, iy = 0, iz = 0; bool nx = false, ny = false, nz = false; uint32_t oct = 0;
+    TravHit h; h.t = 0; h.U = 0; h.V = 0; h.ad = 1; h.gid = 0xFFFFFFFFu;
+    uint32_t sp = 0, g_base = 0, g_mask = 0, t_base = 0, t_mask = 0, pending = 0; bool have_pending = false;
+    for (;;) {
+        const unsigned long long m_idle = __ballot(!live);
+        const uint32_t n_idle = (uint32_t)__popcll(m_idle);
+        bool refilled = false;
+        if (n_idle >= (uint32_t)WIDE_REFILL_AT || m_idle == ~0ull) {
+            if (batch_used >= 64 && next_batch < end) {        // prefetch the next 64 rays (coalesced), all lanes
+                batch_base = next_batch; next_batch += 64; batch_used = 0;
+                const uint32_t i = batch_base + lane;
+                if (i < end) {
+                    fetch(i, pA, pB, p_any);
+                    pix_ = safe_inv(pB.x); piy_ = safe_inv(pB.y); piz_ = safe_inv(pB.z);
+                }
+            }
+            const uint32_t avail = batch_used < 64 ? min(64u - batch_used, end > batch_base + batch_used ? end - (batch_base + batch_used) : 0u) : 0u;
+            if (avail == 0) { if (m_idle == ~0ull) break; }
+            else {
+                const uint32_t rank = (uint32_t)__popcll(m_idle & lt);
+                const uint32_t src = batch_used + rank;                    // lane holding my new ray
+                const bool take = !live && rank < avail;
+                // cross-lane reads are executed by every lane (bpermute needs the whole wave)
+                const int sl = (int)(take ? src : lane);
+                const float ax_ = __shfl(pA.x, sl), ay_ = __shfl(pA.y, sl), az_ = __shfl(pA.z, sl), aw_ = __shfl(pA.w, sl);
+                const float bx_ = __shfl(pB.x, sl), by_ = __shfl(pB.y, sl), bz_ = __shfl(pB.z, sl), bw_ = __shfl(pB.w, sl);
+                const float jx = __shfl(pix_, sl), jy = __shfl(piy_, sl), jz = __shfl(piz_, sl);
+                const uint32_t ja = __shfl(p_any, sl);
+                if (take) {
+                    o = mk3(ax_, ay_, az_); d = mk3(bx_, by_, bz_); ix = jx; iy = jy; iz = jz;
+                    nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                    h.t = aw_; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
+                    idx = batch_base + src; pixw = __float_as_uint(bw_); any = ja != 0;
+                    sp = 0; g_base = 0; g_mask = 0; t_base = 0; t_mask = 0; pending = 0; have_pending = s.num_wnodes != 0;
+                    live = true;
+                }
+                batch_used += min(avail, n_idle);
+                refilled = true;
+            }
+        }
+        if (refilled) continue;
+        if (live) {
+            const bool do_tri = t_mask != 0;
+            bool finished = false;
+            if (!do_tri && !have_pending) {
+                if ((g_mask >> 8) == 0) {
+                    if (sp == 0) finished = true;
+                    else { sp--; const uint2 e = stack[sp * 64u + lane]; g_base = e.x; g_mask = e.y; }
+                }
+                if (!finished) {
+                    const uint32_t hits = g_mask >> 8;
+                    const uint32_t b = (uint32_t)__ffs((int)hits) - 1u;
+                    g_mask &= ~(0x100u << b);
+                    const uint32_t slot = b ^ oct;
+                    pending = g_base + (uint32_t)__popc(g_mask & 0xFFu & ((1u << slot) - 1u));
+                    have_pending = true;
+                }
+            }
+            if (finished) { emit(idx, pixw, any, h.gid != 0xFFFFFFFFu, h); live = false; }
+            else if (do_tri) {
+                const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
+                t_mask &= t_mask - 1u;
+                const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)(t_base + k);
+                const float4 r0 = pk[0], r1 = pk[1], r2 = pk[2];
+                float t, U, V, ad;
+                if (tri_test(r0, r1, r2, o, d, 0.0f, h.t, t, U, V, ad)) {
+                    const uint32_t gid = __float_as_uint(r0.w);
+                    if (any) { h.gid = gid; emit(idx, pixw, any, true, h); live = false; }
+                    else if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
+                }
+            } else {
+                const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
+                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
+                have_pending = false;
+                const uint32_t ew = __float_as_uint(n0.w);
+                const uint32_t imask = ew >> 24;
+                const float ax = __uint_as_float((ew & 0xFFu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xFFu) << 23) * iy, az = __uint_as_float(((ew >> 16) & 0xFFu) << 23) * iz;
+                const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
+                const uint32_t lx0 = __float_as_uint(n2.x), lx1 = __float_as_uint(n2.y), ly0 = __float_as_uint(n2.z), ly1 = __float_as_uint(n2.w);
+                const uint32_t lz0 = __float_as_uint(n3.x), lz1 = __float_as_uint(n3.y), hx0 = __float_as_uint(n3.z), hx1 = __float_as_uint(n3.w);
+                const uint32_t hy0 = __float_as_uint(n4.x), hy1 = __float_as_uint(n4.y), hz0 = __float_as_uint(n4.z), hz1 = __float_as_uint(n4.w);
+                const uint32_t nrx[2] = {nx ? hx0 : lx0, nx ? hx1 : lx1}, frx[2] = {nx ? lx0 : hx0, nx ? lx1 : hx1};
+                const uint32_t nry[2] = {ny ? hy0 : ly0, ny ? hy1 : ly1}, fry[2] = {ny ? ly0 : hy0, ny ? ly1 : hy1};
+                const uint32_t nrz[2] = {nz ? hz0 : lz0, nz ? hz1 : lz1}, frz[2] = {nz ? lz0 : hz0, nz ? lz1 : hz1};
+                const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+                uint32_t node_hits = 0, tri_hits = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int w = i >> 2, k = i & 3;
+                    const float tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
+                                           fmaxf(__builtin_fmaf(ubyte_f(nrz[w], k), az, bz), 0.0f));
+                    const float tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
+                                                 __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, h.t);
+                    if (tn <= tf) {
+                        if ((imask >> i) & 1u) node_hits |= 1u << ((uint32_t)i ^ oct);
+                        else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; tri_hits |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
+                    }
+                }
+                if ((g_mask >> 8) != 0) { stack[sp * 64u + lane] = make_uint2(g_base, g_mask); sp++; }
+                g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | imask;
+                t_base = __float_as_uint(n1.y); t_mask = tri_hits;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace mrt
