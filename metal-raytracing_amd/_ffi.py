@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrt_hip.so")
+LIB_PATH = os.environ.get("MRT_LIB_PATH") or os.path.join(_HERE, "libmrt_hip.so")   # MRT_LIB_PATH: A/B builds during tuning
 
 MRT_OK = 0
 MRT_ERR_INVALID_ARGUMENT, MRT_ERR_NO_DEVICE, MRT_ERR_HIP, MRT_ERR_IO, MRT_ERR_STATE, MRT_ERR_OUT_OF_MEMORY, MRT_ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6, 7

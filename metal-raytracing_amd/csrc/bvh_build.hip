@@ -465,27 +465,38 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
                              float4 *__restrict__ wnodes, const float4 *__restrict__ packets, float4 *__restrict__ wpackets) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n_in;
-    uint32_t ch[8]; int nch = 0;
+    uint32_t ch[8]; bool isleaf[8]; int nch = 0;
     uint32_t ninner = 0, ntris = 0;
     float4 nlo = make_float4(0, 0, 0, 0), nhi = nlo;
     if (active) {
         const uint32_t f = fin[i];
         nlo = t.lo[f]; nhi = t.hi[f];
-        if (t.collapsed[f]) { ch[0] = f; nch = 1; }
+        if (t.collapsed[f]) { ch[0] = f; isleaf[0] = true; nch = 1; }
         else {
             ch[0] = t.left[f]; ch[1] = t.right[f]; nch = 2;
+            isleaf[0] = t.collapsed[ch[0]]; isleaf[1] = t.collapsed[ch[1]];
+            // phase 1: open inner children, largest surface area first
             while (nch < 8) {
                 int best = -1; float ba = -1.0f;
-                for (int k = 0; k < nch; k++) {
-                    uint32_t c = ch[k];
-                    if (!t.collapsed[c]) { float a = box_area(t.lo[c], t.hi[c]); if (a > ba) { ba = a; best = k; } }
-                }
+                for (int k = 0; k < nch; k++)
+                    if (!isleaf[k]) { float a = box_area(t.lo[ch[k]], t.hi[ch[k]]); if (a > ba) { ba = a; best = k; } }
                 if (best < 0) break;
                 uint32_t c = ch[best];
-                ch[best] = t.left[c]; ch[nch++] = t.right[c];
+                ch[best] = t.left[c]; isleaf[best] = t.collapsed[ch[best]];
+                ch[nch] = t.right[c]; isleaf[nch] = t.collapsed[ch[nch]]; nch++;
             }
         }
-        for (int k = 0; k < nch; k++) { if (t.collapsed[ch[k]]) ntris += t.ntri[ch[k]]; else ninner++; }
+        // phase 2: slots left over are free box tests — split multi-triangle leaves back along the binary tree, so
+        // that fewer triangles (one sequential round trip each) are tested behind every box that is hit
+        while (nch < 8) {
+            int best = -1; float ba = -1.0f;
+            for (int k = 0; k < nch; k++)
+                if (isleaf[k] && t.ntri[ch[k]] > 1) { float a = box_area(t.lo[ch[k]], t.hi[ch[k]]); if (a > ba) { ba = a; best = k; } }
+            if (best < 0) break;
+            uint32_t c = ch[best];
+            ch[best] = t.left[c]; ch[nch] = t.right[c]; isleaf[nch] = true; nch++;
+        }
+        for (int k = 0; k < nch; k++) { if (isleaf[k]) ntris += t.ntri[ch[k]]; else ninner++; }
     }
     // wave-aggregated reservation of next-level node slots and packet slots
     const uint32_t lane = threadIdx.x & 63;
@@ -540,7 +551,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
                 if (pl[a] + fh * step[a] < chh[a] && fh < 255.0f) fh += 1.0f;
                 ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
             }
-            if (t.collapsed[c]) {
+            if (isleaf[k]) {
                 uint32_t cnt = t.ntri[c];
                 uint32_t m = (cnt << 5) | off_t;
                 meta[sl >> 2] |= m << (8 * (sl & 3));

@@ -257,8 +257,11 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
 
 // Stream variant of k_trace_mixed_wide: one wave walks WIDE_STREAM_RAYS consecutive rays of the combined queue
 // [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).
-constexpr uint32_t WIDE_STREAM_RAYS = 256;
-__global__ void __launch_bounds__(64) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+#ifndef MRT_WIDE_STREAM_RAYS
+#define MRT_WIDE_STREAM_RAYS 256
+#endif
+constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
+__global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
     extern __shared__ uint2 stk_dyn[];

@@ -110,7 +110,10 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 // occupancy), and whenever REFILL_AT lanes are idle they take the next prefetched rays by cross-lane reads
 // (ds_bpermute), without touching memory.  A refilled lane starts with an empty stack, so nothing but the ray
 // moves.  `emit(idx, B.w, hit, h)` is called by a lane when its ray finishes.
-constexpr int WIDE_REFILL_AT = 16;
+#ifndef MRT_WIDE_REFILL_AT
+#define MRT_WIDE_REFILL_AT 16
+#endif
+constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 template <class RayFetch, class Emit>
 MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint2 *stack, RayFetch fetch, Emit emit) {
