@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per frame in flight (before HIP initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per frame in flight (before HIP initialises)
 
 import numpy as np
 import torch
@@ -45,13 +45,14 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "dragon4", "garden"])
     ap.add_argument("--bounces", type=int, default=3)
-    ap.add_argument("--shard", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--shard", default="sample", choices=["tile", "sample"], help="N > 1: sample-index sharding (weak scaling, default) or 8x8 screen-tile sharding (strong scaling)")
     ap.add_argument("--builder", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
     ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="Renderer.maxFramesInFlight (default 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
     return ap.parse_args()
 
@@ -100,8 +101,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ndev = max(1, torch.cuda.device_count())
+        local_rank = local_rank % ndev                      # rehearsal with more ranks than GPUs (gloo only)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     elif a.gpus > 1:
         sys.exit("launch with torch.distributed.run for --gpus > 1")
 
@@ -121,6 +127,8 @@ def main():
     if world > 1:
         if a.shard == "tile":
             r.set_shard(rank, world)
+            if a.frames_in_flight is None:
+                r.set_option("frames_in_flight", 8)     # 1/N of the pixels per frame: more frames in flight to cover the per-kernel tails
         else:
             r.set_option("sample_offset", rank * (a.warmup + a.steps))
 
@@ -135,9 +143,14 @@ def main():
 
     # ---- warmup
     r.draw(a.warmup, wait=True)
-    if world > 1:
+    def reduce_image():
         r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
-        dist.reduce(accum_t, dst=0)
+        if a.dist_backend == "nccl":
+            reduce_accumulation(accum_t, a.shard, dst=0)      # the ONE collective per output image (RCCL over xGMI)
+        else:
+            host = accum_t.cpu(); reduce_accumulation(host, a.shard, dst=0); accum_t.copy_(host)
+    if world > 1:
+        reduce_image()
     r.reset_stats()
     sync()
     # ---- timed region: exactly K steps (+ the one reduce of the output image for N > 1)
@@ -152,15 +165,15 @@ def main():
         ext_ms += st.ms_extend_last; ext_launches += st.extend_launches_last
         done += k
     if world > 1:
-        r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
-        reduce_accumulation(accum_t, a.shard, dst=0)      # the ONE collective per output image (RCCL over xGMI)
+        reduce_image()
     sync()
     dt = time.perf_counter() - t0
     st = r.stats
     rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
     tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
-        rays = rays.cuda(); tmax = tmax.cuda()
+        if a.dist_backend == "nccl":
+            rays = rays.cuda(); tmax = tmax.cuda()
         dist.all_reduce(rays); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rays = rays.cpu(); tmax = tmax.cpu()
     dt = float(tmax[0])
@@ -201,6 +214,8 @@ def main():
                          "launches_timed": ext_launches},
         }
         if a.png:
+            if world > 1:
+                r.write_accum_from(accum_t.data_ptr(), npix * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
         if world == 1 and not a.no_cpu_baseline:
             cb, ref = cpu_baseline(mrt, scene, w, h, a.bounces, a.cpu_threads)

@@ -163,7 +163,7 @@ SIGNATURES = {
 
 # Frames in flight run on separate HIP streams; the runtime maps streams onto 4 hardware queues by default,
 # which makes lanes collide (measured: 3.6 -> 4.5 Grays/s with 8 queues).  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
