@@ -6,7 +6,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace rc=$?"

@@ -15,7 +15,7 @@ if ks:
             mm = re.search(r"(k_[a-z0-9_]+)", r["Name"]); name = mm.group(1) if mm else r["Name"].split("(")[0]
             f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
     for r in rows:
-        for k in ("k_trace_primary", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+        for k in ("k_trace_primary", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
             if k + "(" in r["Name"] or r["Name"].endswith(k):
                 res.setdefault("kernel_avg_us", {})[k] = float(r["AverageNs"]) / 1e3
                 res.setdefault("kernel_calls", {})[k] = int(r["Calls"])
@@ -24,7 +24,7 @@ def pmc(dirname, counter):
     for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter: continue
-            for k in ("k_trace_primary", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
+            for k in ("k_trace_primary", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
                 if k + "(" in r["Kernel_Name"]: acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
@@ -36,5 +36,13 @@ try:
     res["bench_under_rocprof"] = json.loads(open(out + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
 except Exception as e:
     res["bench_under_rocprof"] = str(e)
+# traversal launches together (what bench.py's roofline object times): call-weighted mean over the trace kernels
+tk = [k for k in res.get("kernel_calls", {}) if k.startswith("k_trace") or k == "k_extend"]
+if tk:
+    calls = sum(res["kernel_calls"][k] for k in tk)
+    res["trace_launch_avg_us"] = sum(res["kernel_avg_us"][k] * res["kernel_calls"][k] for k in tk) / calls
+    hb = res["hbm_traffic_bytes_per_launch"]
+    if all(k in hb and hb[k]["bytes_corrected"] is not None for k in tk):
+        res["trace_launch_hbm_bytes"] = sum(hb[k]["bytes_corrected"] * res["kernel_calls"][k] for k in tk) / calls
 json.dump(res, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "bench_under_rocprof"}, indent=1))
