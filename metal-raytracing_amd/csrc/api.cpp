@@ -346,11 +346,12 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     REQUIRE(r && key, "mrt_renderer_set_option: bad argument");
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
-    else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,8]"); r->r.frames_in_flight = (int)value; }
+    else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
     else if (k == "lds") r->r.use_lds = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
+    else if (k == "wide_top") { REQUIRE(value >= 0 && value <= 1024, "wide_top must be in [0,1024]"); r->r.wide_top = (int)value; }
     else if (k == "persistent") r->r.persistent = value != 0;
     else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }

@@ -19,7 +19,7 @@ struct FrameLane {
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
 };
-constexpr int MAX_FRAMES_IN_FLIGHT = 8;
+constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 
 struct Renderer {
     hipStream_t stream = nullptr;
@@ -39,8 +39,9 @@ struct Renderer {
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
-    int frames_in_flight = 4;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 4 lanes measured best on MI355X
+    int frames_in_flight = 8;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
+    int wide_top = 0;                    // > 0: stage this many top wide nodes (BFS order) in LDS, 4 waves per workgroup
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 256 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_lds = false;                // stage the scene's hot nodes (largest area first) in LDS in the trace kernels

@@ -284,6 +284,36 @@ __global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, 
         });
 }
 
+// Same, four waves per workgroup sharing an LDS copy of the top `n_top` wide nodes (levels 0..2 of the BFS-numbered tree).
+constexpr uint32_t WIDE_TOP_WAVES = 4;
+__global__ void __launch_bounds__(64 * WIDE_TOP_WAVES) k_trace_mixed_wide_stream_top(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t depth, uint32_t n_top) {
+    extern __shared__ float4 lds_dyn[];       // [n_top * 5 float4 | WIDE_TOP_WAVES x depth x 64 uint2]
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if (blockIdx.x * WIDE_TOP_WAVES * WIDE_STREAM_RAYS >= n) return;
+    for (uint32_t k = threadIdx.x; k < n_top * 5u; k += 64 * WIDE_TOP_WAVES) lds_dyn[k] = s.wnodes[k];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint2 *stk = reinterpret_cast<uint2 *>(lds_dyn + n_top * 5u) + (size_t)wave * depth * 64u;
+    const uint32_t begin = (blockIdx.x * WIDE_TOP_WAVES + wave) * WIDE_STREAM_RAYS;
+    if (begin >= n) return;
+    const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
+    traverse_wide_stream(s, begin, end, stk,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
+            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
+            A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
+        },
+        [&](uint32_t i, uint32_t pix, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) {
+                if (!hit) { const uint32_t j = i - n_next; float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+            } else {
+                hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+            }
+        }, lds_dyn, n_top);
+}
+
 // ------------------------------------------------------------------ persistent variants (lane refill)
 __global__ void __launch_bounds__(64) k_extend_persistent(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                           const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
@@ -676,7 +706,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 bool t1 = timed_begin();
-                if (wide_bounce && sv.num_wnodes && wide_stream) hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                if (wide_bounce && sv.num_wnodes && wide_stream && wide_top > 0) {
+                    const uint32_t n_top = std::min<uint32_t>((uint32_t)wide_top, sv.num_wnodes);
+                    const size_t lds = (size_t)n_top * 80u + (size_t)WIDE_TOP_WAVES * scene->wide_depth * 512u;
+                    hipLaunchKernelGGL(k_trace_mixed_wide_stream_top, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS * WIDE_TOP_WAVES)), dim3(64 * WIDE_TOP_WAVES), lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, (uint32_t)scene->wide_depth, n_top);
+                }
+                else if (wide_bounce && sv.num_wnodes && wide_stream) hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);

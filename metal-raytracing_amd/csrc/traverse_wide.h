@@ -116,7 +116,8 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 template <class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint2 *stack, RayFetch fetch, Emit emit) {
+MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint2 *stack, RayFetch fetch, Emit emit,
+                                  const float4 *lds_top = nullptr, uint32_t n_top = 0) {
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // prefetched batch: ray (batch_base + lane)
@@ -197,8 +198,14 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
                     else if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
                 }
             } else {
-                const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
-                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
+                float4 n0, n1, n2, n3, n4;
+                if (pending < n_top) {          // the top levels of the wide tree (BFS numbering) are staged in LDS by the workgroup
+                    const float4 *__restrict__ nd = lds_top + 5u * pending;
+                    n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+                } else {
+                    const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
+                    n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+                }
                 have_pending = false;
                 const uint32_t ew = __float_as_uint(n0.w);
                 const uint32_t imask = ew >> 24;
