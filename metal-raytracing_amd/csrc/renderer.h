@@ -39,7 +39,7 @@ struct Renderer {
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
-    int frames_in_flight = 8;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
+    int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     int wide_top = 0;                    // > 0: stage this many top wide nodes (BFS order) in LDS, 4 waves per workgroup
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 256 consecutive rays)

@@ -376,3 +376,62 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
         rays[:, 7] = 1.5
         assert np.array_equal(r.device_scene.intersect_any(rays), osc.intersect_any(rays))
     r.close()
+
+
+# ---------------------------------------------------------------- more edge cases
+def test_empty_scene_and_tiny_sizes(mrt, orc, gpu_ctx):
+    class Empty(mrt.Scene):
+        pass
+    r = mrt.Renderer((16, 8), Empty((16, 8)), ctx=gpu_ctx)                 # no geometry: every ray misses
+    r.draw(3, wait=True)
+    a = r.accumulation()
+    assert (a[..., :3] == 0).all() and (a[..., 3] == 1).all()
+    assert (r.stats.closest_rays, r.stats.shadow_rays, r.stats.primary_rays) == (3 * 128, 0, 3 * 128)
+    r.close()
+    for (w, h) in [(1, 1), (3, 2), (8, 8), (9, 1)]:
+        sc = mrt.CornellScene((w, h))
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+        r.draw(2, wait=True)
+        ref, cnt = oracle_render(orc, mrt, sc, w, h, 2)
+        assert np.array_equal(r.accumulation(), ref) and (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+        r.close()
+
+
+def test_many_bounces_and_light_update(mrt, orc, gpu_ctx):
+    """max_bounces up to the Halton table's limit (19: dimension 2 + 5*18 + 4 = 96 < 100) and
+    mrt_scene_set_lights after the commit."""
+    w, h = 64, 40
+    sc = mrt.CornellScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, max_bounces=19)
+    r.draw(2, wait=True)
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 2, bounces=19)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    r.close()
+    with pytest.raises(mrt.MRTError):
+        mrt.Renderer((w, h), sc, ctx=gpu_ctx, max_bounces=20)
+    sc2 = mrt.CornellScene((w, h))
+    r = mrt.Renderer((w, h), sc2, ctx=gpu_ctx)
+    sc2.lights = [mrt.Light.pointLight([0.3, 1.5, 0.2], [2, 3, 4]), mrt.Light.sunLight([0.2, -1, 0.1], [0.5, 0.5, 0.5])]
+    r.device_scene.set_lights(sc2.lights)                                  # re-upload on a committed scene
+    r.draw(2, wait=True)
+    ref, _ = oracle_render(orc, mrt, sc2, w, h, 2)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    r.close()
+
+
+def test_two_renderers_share_a_scene_and_resume_from_buffer(mrt, orc, gpu_ctx):
+    """Checkpoint/resume of the accumulation: frames 0-1 on one renderer, its buffer copied into a
+    second renderer that continues at frame index 2 — identical to 4 uninterrupted frames."""
+    import torch
+    w, h = 96, 64
+    sc = mrt.CornellScene((w, h))
+    a = mrt.Renderer((w, h), sc, ctx=gpu_ctx); a.draw(2, wait=True)
+    buf = torch.empty((h, w, 4), dtype=torch.float32, device="cuda:0")
+    a.copy_accum_to(buf.data_ptr(), buf.numel() * 4); a.wait()
+    b = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    b.write_accum_from(buf.data_ptr(), buf.numel() * 4); b.frameIndex = 2
+    b.draw(2, wait=True)
+    ref, _ = oracle_render(orc, mrt, sc, w, h, 4)
+    assert np.array_equal(b.accumulation(), ref)
+    a.close(); b.close()
