@@ -240,6 +240,9 @@ int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height
 /* Diagnostics: per ray {node visits, leaf visits, triangle tests, hit gid, start tick, end tick, 0, 0}
  * (8 x uint32 each; ticks of the 100 MHz wall clock).                                           */
 int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t *out8);
+/* Diagnostics: lane accounting of the wide stream traversal, per wave of `per_wave` rays:
+ * {iterations, sum live lanes, sum node lanes, sum triangle lanes, refills, refilled lanes, hits, rays}.       */
+int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves);
 
 #ifdef __cplusplus
 }

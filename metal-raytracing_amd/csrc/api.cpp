@@ -238,6 +238,15 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
     MRT_CATCH
 }
 
+int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves) {
+    MRT_TRY
+    REQUIRE(scene && rays && out8 && per_wave >= 64 && nwaves * (size_t)per_wave >= n, "mrt_debug_stream_stats: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_debug_stream_stats: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::query_stream_stats(scene->dev, scene->ctx->stream, rays, n, any_hit, per_wave, out8, nwaves);
+    MRT_CATCH
+}
+
 // ---------------------------------------------------------------- host geometry helpers
 int mrt_obj_load(const char *obj_path, MRTMeshData *out) {
     MRT_TRY
@@ -351,6 +360,8 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "lds") r->r.use_lds = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
+    else if (k == "wide_dynamic") r->r.wide_dynamic = value != 0;
+    else if (k == "dyn_waves") { REQUIRE(value >= 64 && value <= 1048576, "dyn_waves out of range"); r->r.dyn_waves = (int)value; }
     else if (k == "wide_top") { REQUIRE(value >= 0 && value <= 1024, "wide_top must be in [0,1024]"); r->r.wide_top = (int)value; }
     else if (k == "persistent") r->r.persistent = value != 0;
     else if (k == "wide") r->r.use_wide = value != 0;

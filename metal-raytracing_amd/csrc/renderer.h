@@ -18,6 +18,7 @@ struct FrameLane {
     DevBuf<float4> sample;               // this frame's radiance per pixel
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
+    DevBuf<uint32_t> shard_counters;            // [bounce][64] batch counters of the dynamic mixed trace, zeroed by k_trace_primary
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 
@@ -41,6 +42,8 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
+    bool wide_dynamic = false;           // mixed trace: persistent waves pull 64-ray batches from 64 shard counters (measured ~2 % slower than static ranges)
+    int dyn_waves = 6144;                // 256 CUs x 24 resident waves
     int wide_top = 0;                    // > 0: stage this many top wide nodes (BFS order) in LDS, 4 waves per workgroup
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 256 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
@@ -77,6 +80,7 @@ struct Renderer {
 int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out);
 int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out);
 int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4);
+int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t per_wave, uint32_t *out8, size_t nwaves);
 int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out);
 int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3);
 int probe_seeds(hipStream_t stream, uint32_t seed, int w, int h, uint32_t *out);

@@ -270,7 +270,38 @@ __global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, 
     const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
     if (begin >= n) return;
     const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
-    traverse_wide_stream(s, begin, end, stk_dyn,
+    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
+            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
+            A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
+        },
+        [&](uint32_t i, uint32_t pix, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) {
+                if (!hit) { const uint32_t j = i - n_next; float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+            } else {
+                hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+            }
+        });
+}
+
+// Dynamic variant (default): a fixed grid of persistent waves; wave w belongs to shard w % WIDE_SHARDS, which owns a
+// contiguous 1/WIDE_SHARDS of the combined queue, and pulls 64-ray batches from the shard's counter.  Measured lane
+// accounting (tools/stream_probe.py): with a static 256-ray range per wave 65 % of the lanes hold a live ray on the
+// diffuse queue (the rest wait for the wave's last rays); with shared batches the wait happens once per shard.
+// One counter word sustains ~88 returning atomics/us (MI355X_MICROARCH.md "dequeue"), hence the shards.
+constexpr uint32_t WIDE_SHARDS = 64;
+__global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_dyn(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ shard_counters) {
+    extern __shared__ uint2 stk_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    const uint32_t shard = blockIdx.x % WIDE_SHARDS;
+    const uint32_t per_shard = ((n + WIDE_SHARDS - 1) / WIDE_SHARDS + 63u) & ~63u;
+    const uint32_t sb = shard * per_shard;
+    if (sb >= n) return;
+    const uint32_t se = min(n, sb + per_shard);
+    traverse_wide_stream(s, SharedBatches{shard_counters + shard, sb, se}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
             const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
             A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
@@ -300,7 +331,7 @@ __global__ void __launch_bounds__(64 * WIDE_TOP_WAVES) k_trace_mixed_wide_stream
     const uint32_t begin = (blockIdx.x * WIDE_TOP_WAVES + wave) * WIDE_STREAM_RAYS;
     if (begin >= n) return;
     const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
-    traverse_wide_stream(s, begin, end, stk,
+    traverse_wide_stream(s, StaticBatches{begin, end}, stk,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
             const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
             A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
@@ -481,7 +512,9 @@ __global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__rest
 // Also the frame's bookkeeping (block 0, thread 0): per-bounce queue counters {next rays, shadow rays} are
 // folded into the running totals and zeroed for the next frame.
 __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst,
-                                                   unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
+                                                   unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary,
+                                                   uint32_t *__restrict__ shard_counters, uint32_t n_shard_counters) {
+    if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < n_shard_counters; k += 64) shard_counters[k] = 0;   // batch counters of this lane's next frame
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long closest = primary, shadow = 0;
         for (int b = 0; b < fp.max_bounces; b++) {
@@ -567,6 +600,26 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
     out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters; out[8 * i + 7] = __float_as_uint(tc.sink);   // 100 MHz ticks
 }
 
+// stream-traversal lane accounting (diagnostics): per wave {iterations, sum of live lanes, node lanes, tri lanes, refills, refilled lanes}
+__global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t per_wave, uint32_t depth, uint32_t *__restrict__ out) {
+    extern __shared__ uint2 stk_dyn[];
+    const uint32_t begin = blockIdx.x * per_wave;
+    if (begin >= n) return;
+    const uint32_t end = min(n, begin + per_wave);
+    StreamStats ss{0, 0, 0, 0, 0, 0};
+    uint32_t sink = 0;
+    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
+            MRTRay r = rays[i];
+            A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
+        },
+        [&](uint32_t, uint32_t, bool, bool hit, const TravHit &) { sink += hit ? 1u : 0u; }, nullptr, 0, &ss);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t *o = out + 8 * (size_t)blockIdx.x;
+        o[0] = ss.iters; o[1] = ss.live_sum; o[2] = ss.node_sum; o[3] = ss.tri_sum; o[4] = ss.refills; o[5] = ss.refill_lanes; o[6] = sink; o[7] = end - begin;
+    }
+}
+
 // ------------------------------------------------------------------ device-function probes
 __global__ void k_probe_halton(const int32_t *i, const int32_t *d, uint32_t n, float *out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -593,6 +646,8 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
         MRT_HIP(L.bounce_counts.alloc(32));
+        MRT_HIP(L.shard_counters.alloc(32 * 64));
+        MRT_HIP(hipMemsetAsync(L.shard_counters.p, 0, L.shard_counters.bytes(), stream));
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -711,6 +766,7 @@ int Renderer::render(int n_frames) {                                   // Render
                     const size_t lds = (size_t)n_top * 80u + (size_t)WIDE_TOP_WAVES * scene->wide_depth * 512u;
                     hipLaunchKernelGGL(k_trace_mixed_wide_stream_top, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS * WIDE_TOP_WAVES)), dim3(64 * WIDE_TOP_WAVES), lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, (uint32_t)scene->wide_depth, n_top);
                 }
+                else if (wide_bounce && sv.num_wnodes && wide_stream && wide_dynamic) hipLaunchKernelGGL(k_trace_mixed_wide_dyn, dim3(std::min<uint32_t>((uint32_t)dyn_waves, cdiv(2 * (size_t)capacity, 64))), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, L.shard_counters.p + (size_t)b * WIDE_SHARDS);
                 else if (wide_bounce && sv.num_wnodes && wide_stream) hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
@@ -740,7 +796,7 @@ int Renderer::render(int n_frames) {                                   // Render
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
         if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels, L.shard_counters.p, (uint32_t)L.shard_counters.n);
         MRT_HIP(hipEventRecord(L.accumulated, st));
         last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334
@@ -846,6 +902,19 @@ int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, s
     if (sc.num_wnodes) hipLaunchKernelGGL(k_query_stats<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
     else hipLaunchKernelGGL(k_query_stats<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
     MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+
+int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t per_wave, uint32_t *out8, size_t nwaves) {
+    if (n == 0 || sc.num_wnodes == 0) return MRT_OK;
+    DevBuf<MRTRay> d_r; DevBuf<uint32_t> d_o;
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * nwaves));
+    MRT_HIP(hipMemsetAsync(d_o.p, 0, 32 * nwaves, stream));
+    MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_query_stream_stats, dim3((uint32_t)nwaves), dim3(64), (size_t)sc.wide_depth * 512u, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
+    MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     return MRT_OK;

@@ -115,15 +115,35 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 #endif
 constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
-template <class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint2 *stack, RayFetch fetch, Emit emit,
-                                  const float4 *lds_top = nullptr, uint32_t n_top = 0) {
+struct StreamStats { uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes; };
+
+// Batch sources for traverse_wide_stream: `next(base, limit)` hands the wave its next (up to) 64 rays [base, min(base+64, limit)).
+struct StaticBatches {          // a fixed range of consecutive rays per wave
+    uint32_t cur, end;
+    MRT_DEV bool next(uint32_t &base, uint32_t &limit) { if (cur >= end) return false; base = cur; limit = end; cur += 64; return true; }
+};
+struct SharedBatches {          // the waves of one shard pull 64-ray batches from a shared counter: no wave idles while its shard has rays left
+    uint32_t *counter; uint32_t begin, end;
+    MRT_DEV bool next(uint32_t &base, uint32_t &limit) {
+        uint32_t b = 0;
+        if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        const unsigned long long off = (unsigned long long)b * 64ull;
+        if (off >= (unsigned long long)(end - begin)) return false;
+        base = begin + (uint32_t)off; limit = end;
+        return true;
+    }
+};
+
+template <class BatchSrc, class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint2 *stack, RayFetch fetch, Emit emit,
+                                  const float4 *lds_top = nullptr, uint32_t n_top = 0, StreamStats *ss = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // prefetched batch: ray (batch_base + lane)
     float4 pA = make_float4(0, 0, 0, 0), pB = pA; float pix_ = 0, piy_ = 0, piz_ = 0; uint32_t p_any = 0;
-    uint32_t batch_base = begin, batch_used = 64;      // wave-uniform; used == 64 -> nothing prefetched
-    uint32_t next_batch = begin;
+    uint32_t batch_base = 0, batch_end = 0, batch_used = 64;      // wave-uniform; used == 64 -> nothing prefetched
+    bool more_batches = true;
     // live ray
     bool live = false; bool any = false;
     uint32_t idx = 0, pixw = 0;
@@ -135,15 +155,16 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         bool refilled = false;
         if (n_idle >= (uint32_t)WIDE_REFILL_AT || m_idle == ~0ull) {
-            if (batch_used >= 64 && next_batch < end) {        // prefetch the next 64 rays (coalesced), all lanes
-                batch_base = next_batch; next_batch += 64; batch_used = 0;
+            if (batch_used >= 64 && more_batches) {            // prefetch the next 64 rays (coalesced), all lanes
+                more_batches = src_batches.next(batch_base, batch_end);
+                if (more_batches) batch_used = 0;
                 const uint32_t i = batch_base + lane;
-                if (i < end) {
+                if (more_batches && i < batch_end) {
                     fetch(i, pA, pB, p_any);
                     pix_ = safe_inv(pB.x); piy_ = safe_inv(pB.y); piz_ = safe_inv(pB.z);
                 }
             }
-            const uint32_t avail = batch_used < 64 ? min(64u - batch_used, end > batch_base + batch_used ? end - (batch_base + batch_used) : 0u) : 0u;
+            const uint32_t avail = batch_used < 64 ? min(64u - batch_used, batch_end > batch_base + batch_used ? batch_end - (batch_base + batch_used) : 0u) : 0u;
             if (avail == 0) { if (m_idle == ~0ull) break; }
             else {
                 const uint32_t rank = (uint32_t)__popcll(m_idle & lt);
@@ -165,9 +186,11 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
                 }
                 batch_used += min(avail, n_idle);
                 refilled = true;
+                if (ss) { ss->refills++; ss->refill_lanes += min(avail, n_idle); }
             }
         }
         if (refilled) continue;
+        if (ss) { ss->iters++; ss->live_sum += (uint32_t)__popcll(__ballot(live)); ss->tri_sum += (uint32_t)__popcll(__ballot(live && t_mask != 0)); ss->node_sum += (uint32_t)__popcll(__ballot(live && t_mask == 0)); }
         if (live) {
             const bool do_tri = t_mask != 0;
             bool finished = false;

@@ -88,6 +88,14 @@ class DeviceScene:
         check(lib.mrt_debug_traversal_stats(self.handle, ptr(rays), rays.shape[0], (1 if any_hit else 0) | (alu_dup << 8) | (mem_dup << 16), ptr(out)))
         return out
 
+    def stream_stats(self, rays, any_hit=False, per_wave=256):
+        """Diagnostics: (nwaves, 8) uint32 lane accounting of the wide stream traversal."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        nw = (rays.shape[0] + per_wave - 1) // per_wave
+        out = np.zeros((nw, 8), np.uint32)
+        check(lib.mrt_debug_stream_stats(self.handle, ptr(rays), rays.shape[0], 1 if any_hit else 0, per_wave, ptr(out), nw))
+        return out
+
     def close(self):
         if self.handle:
             lib.mrt_scene_destroy(self.handle)
