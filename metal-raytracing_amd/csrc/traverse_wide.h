@@ -254,6 +254,15 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
                         else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; tri_hits |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
                     }
                 }
+#ifdef MRT_PROBE_EXTRA_LOADS      // bottleneck probe: extra divergent 16-B loads per node visit (result folded into a never-true test)
+                for (int r = 0; r < MRT_PROBE_EXTRA_LOADS; r++) {
+                    const float4 x = s.wnodes[5 * (size_t)((pending * 2654435761u + 977u * (r + 1)) % s.num_wnodes) + (r % 5)];
+                    if (x.x == 1.2345e-30f) tri_hits |= 1u;
+                }
+#endif
+#ifdef MRT_PROBE_EXTRA_VALU       // bottleneck probe: extra dependent VALU work per node visit
+                { float acc = bx; for (int r = 0; r < MRT_PROBE_EXTRA_VALU; r++) acc = __builtin_fmaf(acc, ax, by); if (acc == 1.2345e-30f) tri_hits |= 1u; }
+#endif
                 if ((g_mask >> 8) != 0) { stack[sp * 64u + lane] = make_uint2(g_base, g_mask); sp++; }
                 g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | imask;
                 t_base = __float_as_uint(n1.y); t_mask = tri_hits;
