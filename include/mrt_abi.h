@@ -171,6 +171,10 @@ int mrt_scene_set_lights(MRTScene scene, const MRTLight *lights, int32_t count);
  * reference's waitUntilCompleted (Utilities.swift:63,83).  builder: 0 = default.               */
 int mrt_scene_commit(MRTScene scene);
 int mrt_scene_set_option(MRTScene scene, const char *key, double value);
+/* Animated transforms: replace one instance's object->world matrix (MTLAccelerationStructureInstanceDescriptor
+ * .transformationMatrix, Renderer.swift:193-200); takes effect at the next mrt_scene_commit, which rebuilds the
+ * world-space BVH on the device (the reference would refit/rebuild its instance AS, Renderer.swift:205-213).   */
+int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const float *transform_colmajor_4x4);
 int mrt_scene_stats(MRTScene scene, MRTSceneStats *out);
 /* 4x3 packed instance transform as the reference stores it (Renderer.swift:193-203).          */
 int mrt_scene_instance_transform(MRTScene scene, int32_t mesh_id, float out_colmajor_4x3[12]);

@@ -126,6 +126,7 @@ SIGNATURES = {
     "mrt_scene_set_lights": (C.c_int, [_P, C.POINTER(Light), _I32]),
     "mrt_scene_commit": (C.c_int, [_P]),
     "mrt_scene_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "mrt_scene_set_instance_transform": (C.c_int, [_P, _I32, _P]),
     "mrt_scene_stats": (C.c_int, [_P, C.POINTER(SceneStats)]),
     "mrt_scene_instance_transform": (C.c_int, [_P, _I32, _PF]),
     "mrt_scene_intersect_closest": (C.c_int, [_P, _P, _SZ, _P]),

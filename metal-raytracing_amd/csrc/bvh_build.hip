@@ -850,9 +850,9 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     out.stats.build_ms = ms;
     out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)n * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
     out.num_wnodes = 0; out.wide_depth = 0;
-    if (opt.wide) {
+    // a wide node addresses its leaf triangles with a 32-bit mask: 8 leaf children x max_leaf triangles must fit
+    if (opt.wide && opt.max_leaf <= 4) {
         // ---- 8-wide compressed layout, level by level (BFS numbering)
-        if (opt.max_leaf > 7) { set_error("wide layout needs max_leaf <= 7"); return MRT_ERR_INVALID_ARGUMENT; }
         const size_t max_w = (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
         MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));

@@ -58,6 +58,14 @@ class DeviceScene:
         self.set_lights(scene.lights)
         check(lib.mrt_scene_commit(self.handle))
 
+    def set_instance_transform(self, mesh_id, transform):
+        """Animated transforms: new object->world matrix for one instance; call commit() afterwards."""
+        xf = np.ascontiguousarray(np.asarray(transform, np.float32).reshape(16))
+        check(lib.mrt_scene_set_instance_transform(self.handle, int(mesh_id), ptr(xf)))
+
+    def commit(self):
+        check(lib.mrt_scene_commit(self.handle))
+
     def set_lights(self, lights):
         arr = (Light * max(1, len(lights)))(*lights)
         check(lib.mrt_scene_set_lights(self.handle, arr, len(lights)))

@@ -437,3 +437,36 @@ def test_two_renderers_share_a_scene_and_resume_from_buffer(mrt, orc, gpu_ctx):
     ref, _ = oracle_render(orc, mrt, sc, w, h, 4)
     assert np.array_equal(b.accumulation(), ref)
     a.close(); b.close()
+
+
+def test_animated_transform_recommit(mrt, orc, gpu_ctx):
+    """Move an instance (new transform + re-commit = on-device rebuild) and keep rendering with the same
+    renderer; the result must equal the oracle on the moved scene."""
+    w, h = 128, 80
+    sc = mrt.CornellScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    r.draw(1, wait=True)
+    sphere = sc.models[-1]
+    moved = mrt.make_transform([0.35, 0.6, -0.2], [0.3, 0.2, 0.1], 0.4)
+    r.device_scene.set_instance_transform(len(sc.meshes) - 1, moved)
+    with pytest.raises(mrt.MRTError):
+        r.draw(1)                                  # scene modified and not re-committed
+    r.device_scene.commit()
+    r.frameIndex = 0
+    r.draw(2, wait=True)
+    sphere.meshes[0].transform = moved
+    ref, _ = oracle_render(orc, mrt, sc, w, h, 2)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    r.close()
+
+
+def test_large_leaf_option_falls_back_to_rope(mrt, orc, gpu_ctx):
+    """max_leaf > 4 cannot be addressed by the wide layout's 32-bit triangle mask: the scene then has no wide
+    layout and every ray uses the rope traversal; the image is unchanged."""
+    w, h = 160, 90
+    sc = mrt.DragonScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"max_leaf": 7})
+    r.draw(2, wait=True)
+    ref, _ = oracle_render(orc, mrt, sc, w, h, 2)
+    assert_parity(r.accumulation(), ref)
+    r.close()
