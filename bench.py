@@ -217,6 +217,15 @@ def main():
             if world > 1:
                 r.write_accum_from(accum_t.data_ptr(), npix * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
+        if world == 1 and a.bounces > 1:
+            # the strict "primary + shadow" figure: the same renderer with max_bounces = 1
+            r.set_option("max_bounces", 1); r.frameIndex = 0
+            r.draw(a.warmup, wait=True); r.reset_stats(); torch.cuda.synchronize()
+            t1 = time.perf_counter(); r.draw(a.steps, wait=True); dt1 = time.perf_counter() - t1
+            s1 = r.stats
+            out["strict_primary_plus_shadow"] = {"value": round((s1.closest_rays + s1.shadow_rays) / dt1 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt1 * 1e3 / a.steps, 4),
+                                                 "rays_per_frame": {"primary": s1.closest_rays / a.steps, "shadow": s1.shadow_rays / a.steps}, "max_bounces": 1}
+            r.set_option("max_bounces", a.bounces)
         if world == 1 and not a.no_cpu_baseline:
             cb, ref = cpu_baseline(mrt, scene, w, h, a.bounces, a.cpu_threads)
             out["cpu_baseline"] = cb

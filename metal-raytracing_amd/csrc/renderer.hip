@@ -263,10 +263,10 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
 constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
 __global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow) {
     extern __shared__ uint2 stk_dyn[];
     const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
     if (begin >= n) return;
     const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
@@ -767,7 +767,10 @@ int Renderer::render(int n_frames) {                                   // Render
                     hipLaunchKernelGGL(k_trace_mixed_wide_stream_top, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS * WIDE_TOP_WAVES)), dim3(64 * WIDE_TOP_WAVES), lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, (uint32_t)scene->wide_depth, n_top);
                 }
                 else if (wide_bounce && sv.num_wnodes && wide_stream && wide_dynamic) hipLaunchKernelGGL(k_trace_mixed_wide_dyn, dim3(std::min<uint32_t>((uint32_t)dyn_waves, cdiv(2 * (size_t)capacity, 64))), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, L.shard_counters.p + (size_t)b * WIDE_SHARDS);
-                else if (wide_bounce && sv.num_wnodes && wide_stream) hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (wide_bounce && sv.num_wnodes && wide_stream) {
+                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
+                    if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                }
                 else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
