@@ -373,6 +373,8 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
     else if (k == "wide_dynamic") r->r.wide_dynamic = value != 0;
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
+    else if (k == "primary_wide") r->r.primary_wide = value != 0;
+    else if (k == "lds_pad") r->r.lds_pad = (int)value < 0 ? 0 : ((int)value > 65536 ? 65536 : (int)value);
     else if (k == "dyn_waves") { REQUIRE(value >= 64 && value <= 1048576, "dyn_waves out of range"); r->r.dyn_waves = (int)value; }
     else if (k == "wide_top") { REQUIRE(value >= 0 && value <= 1024, "wide_top must be in [0,1024]"); r->r.wide_top = (int)value; }
     else if (k == "persistent") r->r.persistent = value != 0;

@@ -882,7 +882,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
         if (h_wc[1] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
         out.stats.build_ms += wms;
         out.wide_depth = depth;
-        if (depth <= WIDE_STACK) out.num_wnodes = total;       // deeper than the LDS stack: keep the rope backend
+        if (depth <= WIDE_STACK && total < (1u << 24)) out.num_wnodes = total;       // deeper than the LDS stack (or child_base beyond its 24 stack bits): keep the rope backend
         out.stats.scene_bytes += (uint64_t)total * 80 + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;

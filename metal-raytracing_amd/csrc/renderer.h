@@ -42,6 +42,8 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
+    int lds_pad = 0;                     // occupancy probe: extra dynamic LDS bytes per wave of the wide stream kernel
+    bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
     bool wide_dynamic = false;           // mixed trace: persistent waves pull 64-ray batches from 64 shard counters (measured ~2 % slower than static ranges)
     int dyn_waves = 6144;                // 256 CUs x 24 resident waves

@@ -206,24 +206,24 @@ __global__ void __launch_bounds__(TRACE_LDS_THREADS) k_trace_mixed_lds(SceneView
 // ------------------------------------------------------------------ wide-BVH backend (LDS stack)
 __global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                     const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
-    __shared__ uint2 stk[WIDE_STACK][64];
+    __shared__ uint32_t stk[WIDE_STACK * WIDE_STACK_LEVEL_BYTES / 4];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     uint32_t n = count ? (uint32_t)*count : capacity;
     if (i >= n) return;
     float4 A = rayA[i], B = rayB[i];
     if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
     TravHit h;
-    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, &stk[0][0]);
+    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
     hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 __global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                     const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
-    __shared__ uint2 stk[WIDE_STACK][64];
+    __shared__ uint32_t stk[WIDE_STACK * WIDE_STACK_LEVEL_BYTES / 4];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= (uint32_t)(*count >> 32)) return;
     float4 A = srayA[i], B = srayB[i];
     TravHit h;
-    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, &stk[0][0]);
+    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
     if (!occluded) {
         uint32_t pix = __float_as_uint(B.w);
         float4 c = scon[i], a = sample[pix];
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *_
 __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                          const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                          const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
-    extern __shared__ uint2 stk_dyn[];        // [wide-tree depth][64]: 512 B per level, sized by the host from the scene's depth
+    extern __shared__ uint32_t stk_dyn[];     // wide-tree depth x WIDE_STACK_LEVEL_BYTES, sized by the host from the scene's depth
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -261,10 +261,13 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
 #define MRT_WIDE_STREAM_RAYS 256
 #endif
 constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
-__global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+#ifndef MRT_WIDE_STREAM_WAVES
+#define MRT_WIDE_STREAM_WAVES 6
+#endif
+__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow) {
-    extern __shared__ uint2 stk_dyn[];
+    extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
@@ -284,6 +287,25 @@ __global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_stream(SceneView s, 
         });
 }
 
+// Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays).
+__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity) {
+    extern __shared__ uint32_t stk_dyn[];
+    const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
+    if (begin >= capacity) return;
+    const uint32_t end = min(capacity, begin + WIDE_STREAM_RAYS);
+    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
+        [&](uint32_t slot, float4 &A, float4 &B, uint32_t &is_any) {
+            int x, y; is_any = 0u;
+            if (slot_to_pixel(fp, slot, x, y)) {
+                f3 org, dir; primary_ray(fp, seeds, x, y, org, dir);
+                A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
+        },
+        [&](uint32_t slot, uint32_t, bool, bool hit, const TravHit &h) {
+            hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        });
+}
+
 // Dynamic variant (default): a fixed grid of persistent waves; wave w belongs to shard w % WIDE_SHARDS, which owns a
 // contiguous 1/WIDE_SHARDS of the combined queue, and pulls 64-ray batches from the shard's counter.  Measured lane
 // accounting (tools/stream_probe.py): with a static 256-ray range per wave 65 % of the lanes hold a live ray on the
@@ -293,7 +315,7 @@ constexpr uint32_t WIDE_SHARDS = 64;
 __global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_dyn(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ shard_counters) {
-    extern __shared__ uint2 stk_dyn[];
+    extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t shard = blockIdx.x % WIDE_SHARDS;
@@ -327,7 +349,7 @@ __global__ void __launch_bounds__(64 * WIDE_TOP_WAVES) k_trace_mixed_wide_stream
     for (uint32_t k = threadIdx.x; k < n_top * 5u; k += 64 * WIDE_TOP_WAVES) lds_dyn[k] = s.wnodes[k];
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6;
-    uint2 *stk = reinterpret_cast<uint2 *>(lds_dyn + n_top * 5u) + (size_t)wave * depth * 64u;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn + n_top * 5u) + (size_t)wave * depth * (WIDE_STACK_LEVEL_BYTES / 4u);
     const uint32_t begin = (blockIdx.x * WIDE_TOP_WAVES + wave) * WIDE_STREAM_RAYS;
     if (begin >= n) return;
     const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
@@ -553,13 +575,13 @@ __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4
 // ------------------------------------------------------------------ query kernels (C-ABI intersect_*)
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, MRTIntersection *__restrict__ out) {
-    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
+    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, &stk[0][0]) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
+    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
     MRTIntersection o;
     o._pad = 0;
     if (hit) {
@@ -573,19 +595,19 @@ __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay 
 }
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int32_t *__restrict__ out) {
-    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
+    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, &stk[0][0]) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
+    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
 }
 
 // per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t *__restrict__ out) {
-    __shared__ uint2 stk[WIDE ? WIDE_STACK : 1][64];
+    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
@@ -593,7 +615,7 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
     tc.alu_dup = (any >> 8) & 0xFF; tc.mem_dup = (any >> 16) & 0xFF; any &= 1;
     f3 o = mk3(r.origin[0], r.origin[1], r.origin[2]), d = mk3(r.direction[0], r.direction[1], r.direction[2]);
     unsigned long long t0 = wall_clock64();
-    if (WIDE) { if (any) traverse_wide<true, true>(s, o, d, r.min_distance, r.max_distance, h, &stk[0][0], &tc); else traverse_wide<false, true>(s, o, d, r.min_distance, r.max_distance, h, &stk[0][0], &tc); }
+    if (WIDE) { if (any) traverse_wide<true, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); else traverse_wide<false, true>(s, o, d, r.min_distance, r.max_distance, h, stk, &tc); }
     else { if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); }
     unsigned long long t1 = wall_clock64();
     out[8 * i + 0] = tc.steps; out[8 * i + 1] = tc.leaves; out[8 * i + 2] = tc.tris; out[8 * i + 3] = h.gid;
@@ -602,7 +624,7 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
 
 // stream-traversal lane accounting (diagnostics): per wave {iterations, sum of live lanes, node lanes, tri lanes, refills, refilled lanes}
 __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t per_wave, uint32_t depth, uint32_t *__restrict__ out) {
-    extern __shared__ uint2 stk_dyn[];
+    extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * per_wave;
     if (begin >= n) return;
     const uint32_t end = min(n, begin + per_wave);
@@ -750,7 +772,8 @@ int Renderer::render(int n_frames) {                                   // Render
             auto timed_end = [&](bool t) { if (t) { (void)hipEventRecord(ev_ext[ext_used].b, st); ext_used++; } };
             fp.bounce = 0;
             bool t0 = timed_begin();
-            if (lds) hipLaunchKernelGGL(k_trace_primary_lds, dim3(cdiv(capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, fp, seeds.p, L.hits.p);
+            if (primary_wide && sv.num_wnodes) hipLaunchKernelGGL(k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, fp, seeds.p, L.hits.p, capacity);
+            else if (lds) hipLaunchKernelGGL(k_trace_primary_lds, dim3(cdiv(capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, fp, seeds.p, L.hits.p);
             else hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             timed_end(t0);
             int q = 0;                                                  // shade(b) writes next rays into queue q
@@ -763,15 +786,15 @@ int Renderer::render(int n_frames) {                                   // Render
                 bool t1 = timed_begin();
                 if (wide_bounce && sv.num_wnodes && wide_stream && wide_top > 0) {
                     const uint32_t n_top = std::min<uint32_t>((uint32_t)wide_top, sv.num_wnodes);
-                    const size_t lds = (size_t)n_top * 80u + (size_t)WIDE_TOP_WAVES * scene->wide_depth * 512u;
+                    const size_t lds = (size_t)n_top * 80u + (size_t)WIDE_TOP_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
                     hipLaunchKernelGGL(k_trace_mixed_wide_stream_top, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS * WIDE_TOP_WAVES)), dim3(64 * WIDE_TOP_WAVES), lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, (uint32_t)scene->wide_depth, n_top);
                 }
-                else if (wide_bounce && sv.num_wnodes && wide_stream && wide_dynamic) hipLaunchKernelGGL(k_trace_mixed_wide_dyn, dim3(std::min<uint32_t>((uint32_t)dyn_waves, cdiv(2 * (size_t)capacity, 64))), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, L.shard_counters.p + (size_t)b * WIDE_SHARDS);
+                else if (wide_bounce && sv.num_wnodes && wide_stream && wide_dynamic) hipLaunchKernelGGL(k_trace_mixed_wide_dyn, dim3(std::min<uint32_t>((uint32_t)dyn_waves, cdiv(2 * (size_t)capacity, 64))), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, L.shard_counters.p + (size_t)b * WIDE_SHARDS);
                 else if (wide_bounce && sv.num_wnodes && wide_stream) {
-                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
+                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (size_t)lds_pad, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
-                else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * 512u, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 timed_end(t1);
@@ -916,7 +939,7 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * nwaves));
     MRT_HIP(hipMemsetAsync(d_o.p, 0, 32 * nwaves, stream));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_query_stream_stats, dim3((uint32_t)nwaves), dim3(64), (size_t)sc.wide_depth * 512u, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
+    hipLaunchKernelGGL(k_query_stream_stats, dim3((uint32_t)nwaves), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());

@@ -42,6 +42,7 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 // Slot bit k set = the child lies on the + side of the node centre along axis k, so children are entered
 // front to back in the order of (slot ^ ray octant).
 constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
+constexpr uint32_t WIDE_STACK_LEVEL_BYTES = 320;   // per wave and level: 64 x 4 B {child_base << 8 | hit bits} + 64 x 1 B {imask}
 
 struct LightDev {            // 96 B, derived once per mrt_scene_set_lights from the 128-B MRTLight
     float4 position;         // .w = type (as int bits)

@@ -348,7 +348,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_dynamic_batches", "hybrid_no_refill", "rope_only", "rope_unfused", "rope_persistent", "rope_lds_nodes", "wide_all", "one_frame_in_flight", "eight_frames_in_flight"])
+@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_dynamic_batches", "hybrid_no_refill", "rope_only", "rope_unfused", "rope_persistent", "rope_lds_nodes", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every traversal backend / scheduling option must give the oracle's image: the default hybrid (stackless
     rope walk for primary rays, 8-wide compressed layout + LDS stack for bounce and shadow rays), rope only,
@@ -364,6 +364,8 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "rope_persistent": r.set_option("persistent", 1); r.set_option("persistent_waves", 97)
     if backend == "rope_lds_nodes": r.set_option("lds", 1)
     if backend == "wide_all": r.set_option("wide", 1)
+    if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
+    if backend == "shadow_on_rope": r.set_option("shadow_rope", 1)
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     r.draw(5, wait=True)
