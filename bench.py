@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="Renderer.maxFramesInFlight (default 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the extra max_bounces=1 (primary + shadow only) measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
@@ -217,7 +218,7 @@ def main():
             if world > 1:
                 r.write_accum_from(accum_t.data_ptr(), npix * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
-        if world == 1 and a.bounces > 1:
+        if world == 1 and a.bounces > 1 and not a.no_strict:
             # the strict "primary + shadow" figure: the same renderer with max_bounces = 1
             r.set_option("max_bounces", 1); r.frameIndex = 0
             r.draw(a.warmup, wait=True); r.reset_stats(); torch.cuda.synchronize()

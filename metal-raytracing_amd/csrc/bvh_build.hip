@@ -567,7 +567,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
         }
         for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
     }
-    const size_t w = 5 * (size_t)(base_in + i);
+    const size_t w = WNODE_STRIDE * (size_t)(base_in + i);
     wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
     wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
     wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
@@ -856,7 +856,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
         const size_t max_w = (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
         MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
-        MRT_HIP(out.wnodes.alloc(5 * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
         MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
         MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
@@ -883,7 +883,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
         out.stats.build_ms += wms;
         out.wide_depth = depth;
         if (depth <= WIDE_STACK && total < (1u << 24)) out.num_wnodes = total;       // deeper than the LDS stack (or child_base beyond its 24 stack bits): keep the rope backend
-        out.stats.scene_bytes += (uint64_t)total * 80 + (uint64_t)n * 48;
+        out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;
     }

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
 // Stream variant of k_trace_mixed_wide: one wave walks WIDE_STREAM_RAYS consecutive rays of the combined queue
 // [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).
 #ifndef MRT_WIDE_STREAM_RAYS
-#define MRT_WIDE_STREAM_RAYS 256
+#define MRT_WIDE_STREAM_RAYS 384
 #endif
 constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
 #ifndef MRT_WIDE_STREAM_WAVES
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64 * WIDE_TOP_WAVES) k_trace_mixed_wide_stream
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
     if (blockIdx.x * WIDE_TOP_WAVES * WIDE_STREAM_RAYS >= n) return;
-    for (uint32_t k = threadIdx.x; k < n_top * 5u; k += 64 * WIDE_TOP_WAVES) lds_dyn[k] = s.wnodes[k];
+    for (uint32_t k = threadIdx.x; k < n_top * 5u; k += 64 * WIDE_TOP_WAVES) lds_dyn[k] = s.wnodes[(k / 5u) * WNODE_STRIDE + k % 5u];
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn + n_top * 5u) + (size_t)wave * depth * (WIDE_STACK_LEVEL_BYTES / 4u);

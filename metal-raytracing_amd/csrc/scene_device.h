@@ -41,6 +41,10 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 //   f4 2: qlo_x[8] qlo_y[8]      f4 3: qlo_z[8] qhi_x[8]      f4 4: qhi_y[8] qhi_z[8]      (empty slot: qlo=255, qhi=0)
 // Slot bit k set = the child lies on the + side of the node centre along axis k, so children are entered
 // front to back in the order of (slot ^ ray octant).
+#ifndef MRT_WNODE_STRIDE
+#define MRT_WNODE_STRIDE 5
+#endif
+constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wide nodes in HBM (5 = packed 80 B; 8 = one 128-B line each)
 constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
 constexpr uint32_t WIDE_STACK_LEVEL_BYTES = 320;   // per wave and level: 64 x 4 B {child_base << 8 | hit bits} + 64 x 1 B {imask}
 

@@ -18,6 +18,10 @@
 namespace mrt {
 namespace {
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+#ifndef MRT_WIDE_PK_FMA
+#define MRT_WIDE_PK_FMA 0   // measured: the operand pairs cost ~3 VGPRs -> spills at the 80-register budget; -2.6 %
+#endif
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
 
 // LDS stack of one wave: per tree level 64 words {child_base << 8 | remaining hit bits} followed by 64 bytes {imask}
@@ -74,7 +78,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
                 if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
             }
         } else {
-            const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
+            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
             const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
             have_pending = false;
             const uint32_t ew = __float_as_uint(n0.w);
@@ -243,7 +247,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
             uint32_t k = 0;
             if (has_tri) { k = (uint32_t)__ffs((int)t_mask) - 1u; t_mask &= t_mask - 1u; tri_pk = t_base + k; }
             const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
-            const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
+            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
             n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
@@ -263,7 +267,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
         }
         if (want_node) {
             if (pending < n_top) { const float4 *__restrict__ nd = lds_top + 5u * pending; n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4]; }
-            else { const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending; n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4]; }
+            else { const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending; n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4]; }
         }
 #endif
         if (has_tri) {
@@ -290,10 +294,18 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int w = i >> 2, k = i & 3;
+#if MRT_WIDE_PK_FMA        // near and far plane of an axis in one v_pk_fma_f32 (packed fp32 runs at twice the scalar rate)
+                const float2v px = __builtin_elementwise_fma(float2v{ubyte_f(nrx[w], k), ubyte_f(frx[w], k)}, float2v{ax, ax}, float2v{bx, bx});
+                const float2v py = __builtin_elementwise_fma(float2v{ubyte_f(nry[w], k), ubyte_f(fry[w], k)}, float2v{ay, ay}, float2v{by, by});
+                const float2v pz = __builtin_elementwise_fma(float2v{ubyte_f(nrz[w], k), ubyte_f(frz[w], k)}, float2v{az, az}, float2v{bz, bz});
+                const float tn = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, 0.0f));
+                const float tf = fminf(fminf(fminf(px.y, py.y), pz.y) * 1.0000005f, h.t);
+#else
                 const float tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
                                        fmaxf(__builtin_fmaf(ubyte_f(nrz[w], k), az, bz), 0.0f));
                 const float tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
                                              __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, h.t);
+#endif
                 if (tn <= tf) {
                     if ((imask >> i) & 1u) node_hits |= 1u << ((uint32_t)i ^ oct);
                     else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; tri_hits |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
@@ -301,7 +313,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
             }
 #ifdef MRT_PROBE_EXTRA_LOADS      // bottleneck probe: extra divergent 16-B loads per node visit (result folded into a never-true test)
             for (int r = 0; r < MRT_PROBE_EXTRA_LOADS; r++) {
-                const float4 x = s.wnodes[5 * (size_t)((pending * 2654435761u + 977u * (r + 1)) % s.num_wnodes) + (r % 5)];
+                const float4 x = s.wnodes[WNODE_STRIDE * (size_t)((pending * 2654435761u + 977u * (r + 1)) % s.num_wnodes) + (r % 5)];
                 if (x.x == 1.2345e-30f) tri_hits |= 1u;
             }
 #endif
@@ -337,7 +349,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
                     const float4 *__restrict__ nd = lds_top + 5u * pending;
                     n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
                 } else {
-                    const float4 *__restrict__ nd = s.wnodes + 5 * (size_t)pending;
+                    const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
                     n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
                 }
                 const uint32_t ew = __float_as_uint(n0.w);
@@ -366,7 +378,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, BatchSrc src_batches, uint
                 }
 #ifdef MRT_PROBE_EXTRA_LOADS      // bottleneck probe: extra divergent 16-B loads per node visit (result folded into a never-true test)
                 for (int r = 0; r < MRT_PROBE_EXTRA_LOADS; r++) {
-                    const float4 x = s.wnodes[5 * (size_t)((pending * 2654435761u + 977u * (r + 1)) % s.num_wnodes) + (r % 5)];
+                    const float4 x = s.wnodes[WNODE_STRIDE * (size_t)((pending * 2654435761u + 977u * (r + 1)) % s.num_wnodes) + (r % 5)];
                     if (x.x == 1.2345e-30f) tri_hits |= 1u;
                 }
 #endif
