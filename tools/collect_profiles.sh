@@ -8,10 +8,12 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-strict > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace rc=$?"
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-strict --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch rc=$?"
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-strict --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
 echo "write rc=$?"
+timeout -k 10 200 rocprofv3 --pmc VALUBusy VALUUtilization --output-format csv -d $OUT/pmc_valu -- python3 $R/bench.py --no-cpu-baseline --no-strict --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_valu.err
+echo "valu rc=$?"
 cd $R && python3 tools/summarize_profiles.py $OUT $TAG

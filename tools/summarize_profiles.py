@@ -28,6 +28,8 @@ def pmc(dirname, counter):
                 if k + "(" in r["Kernel_Name"]: acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+res["valu_busy_pct"] = pmc("pmc_valu", "VALUBusy")                 # % of cycles the VALU is issuing (kernels serialised by the profiler)
+res["valu_lane_utilization_pct"] = pmc("pmc_valu", "VALUUtilization")   # % of lanes active in an average VALU instruction
 # units: KB (1024 B) per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes
 # of wide coalesced reads -> x2; other access widths are uncalibrated, so this is an upper estimate for gathers.
 res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": fetch.get(k), "write_KB": write.get(k),
