@@ -368,18 +368,11 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
-    else if (k == "lds") r->r.use_lds = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
-    else if (k == "wide_dynamic") r->r.wide_dynamic = value != 0;
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
     else if (k == "primary_wide") r->r.primary_wide = value != 0;
-    else if (k == "lds_pad") r->r.lds_pad = (int)value < 0 ? 0 : ((int)value > 65536 ? 65536 : (int)value);
-    else if (k == "dyn_waves") { REQUIRE(value >= 64 && value <= 1048576, "dyn_waves out of range"); r->r.dyn_waves = (int)value; }
-    else if (k == "wide_top") { REQUIRE(value >= 0 && value <= 1024, "wide_top must be in [0,1024]"); r->r.wide_top = (int)value; }
-    else if (k == "persistent") r->r.persistent = value != 0;
     else if (k == "wide") r->r.use_wide = value != 0;
-    else if (k == "persistent_waves") { REQUIRE(value >= 1 && value <= 1048576, "persistent_waves out of range"); r->r.persistent_waves = (int)value; }
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     return MRT_OK;

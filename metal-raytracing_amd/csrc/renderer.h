@@ -18,7 +18,6 @@ struct FrameLane {
     DevBuf<float4> sample;               // this frame's radiance per pixel
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
-    DevBuf<uint32_t> shard_counters;            // [bounce][64] batch counters of the dynamic mixed trace, zeroed by k_trace_primary
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 
@@ -42,18 +41,11 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
-    int lds_pad = 0;                     // occupancy probe: extra dynamic LDS bytes per wave of the wide stream kernel
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
-    bool wide_dynamic = false;           // mixed trace: persistent waves pull 64-ray batches from 64 shard counters (measured ~2 % slower than static ranges)
-    int dyn_waves = 6144;                // 256 CUs x 24 resident waves
-    int wide_top = 0;                    // > 0: stage this many top wide nodes (BFS order) in LDS, 4 waves per workgroup
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 256 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
-    bool use_lds = false;                // stage the scene's hot nodes (largest area first) in LDS in the trace kernels
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)
-    bool persistent = false;             // persistent wavefronts with lane refill for the two traversal kernels
-    int persistent_waves = 8192;         // 256 CUs x 32 waves
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
 

@@ -150,59 +150,6 @@ __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *_
     }
 }
 
-// ---- the same two kernels with the hot top of the tree staged in LDS ("LDS-staged BVH nodelets"): workgroups of
-// TRACE_LDS_THREADS threads copy nodes [0, hot) (64 B each, largest surface area first) into LDS once and then
-// serve every visit of those nodes from LDS instead of the L1/TA path.
-constexpr int TRACE_LDS_THREADS = 512;
-
-MRT_DEV void stage_hot_nodes(const SceneView &s, float4 *lds) {
-    const uint32_t words = s.hot_nodes * 4u;
-    for (uint32_t k = threadIdx.x; k < words; k += TRACE_LDS_THREADS) lds[k] = s.nodes[k];
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(TRACE_LDS_THREADS) k_trace_primary_lds(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits) {
-    extern __shared__ float4 lds_nodes[];
-    stage_hot_nodes(s, lds_nodes);
-    uint32_t slot = blockIdx.x * TRACE_LDS_THREADS + threadIdx.x;
-    int x, y;
-    if (!slot_to_pixel(fp, slot, x, y)) {
-        if ((int)(slot >> 6) < fp.tiles_local) hits[slot] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        return;
-    }
-    f3 org, dir;
-    primary_ray(fp, seeds, x, y, org, dir);
-    TravHit h;
-    bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h, nullptr, false, lds_nodes, s.hot_nodes);
-    hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-}
-
-__global__ void __launch_bounds__(TRACE_LDS_THREADS) k_trace_mixed_lds(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
-                                                                       const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                       const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
-    extern __shared__ float4 lds_nodes[];
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
-    if (blockIdx.x * TRACE_LDS_THREADS >= n_next + n_shadow) return;          // whole workgroup beyond the queues: nothing to stage for
-    stage_hot_nodes(s, lds_nodes);
-    uint32_t i = blockIdx.x * TRACE_LDS_THREADS + threadIdx.x;
-    if (i >= n_next + n_shadow) return;
-    const bool shadow = i >= n_next;
-    const uint32_t j = shadow ? i - n_next : i;
-    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
-    TravHit h;
-    bool hit = traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow, lds_nodes, s.hot_nodes);
-    if (shadow) {
-        if (!hit) {
-            uint32_t pix = __float_as_uint(B.w);
-            float4 cc = scon[j], a = sample[pix];
-            sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f);
-        }
-    } else {
-        hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-    }
-}
-
 // ------------------------------------------------------------------ wide-BVH backend (LDS stack)
 __global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
                                                     const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
@@ -256,13 +203,15 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
 }
 
 // Stream variant of k_trace_mixed_wide: one wave walks WIDE_STREAM_RAYS consecutive rays of the combined queue
-// [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).
+// [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).  384 rays per wave measured best
+// (256: -2 %, 512: -1 %, 1024: -7 %): longer ranges amortise the drain at the end of a wave's range, shorter ones
+// keep the launch's tail short.
 #ifndef MRT_WIDE_STREAM_RAYS
 #define MRT_WIDE_STREAM_RAYS 384
 #endif
 constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
 #ifndef MRT_WIDE_STREAM_WAVES
-#define MRT_WIDE_STREAM_WAVES 6
+#define MRT_WIDE_STREAM_WAVES 7
 #endif
 __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
@@ -272,120 +221,37 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
     if (begin >= n) return;
-    const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
-    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
-            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
-            A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
+    traverse_wide_stream(s, begin, min(n, begin + WIDE_STREAM_RAYS), stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
         },
-        [&](uint32_t i, uint32_t pix, bool is_any, bool hit, const TravHit &h) {
+        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
-                if (!hit) { const uint32_t j = i - n_next; float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
             } else {
-                hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
             }
         });
 }
 
-// Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays).
+// Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
+// equal on the full frame, 7 % slower on the primary + shadow workload).
 __global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
     if (begin >= capacity) return;
-    const uint32_t end = min(capacity, begin + WIDE_STREAM_RAYS);
-    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
-        [&](uint32_t slot, float4 &A, float4 &B, uint32_t &is_any) {
-            int x, y; is_any = 0u;
+    traverse_wide_stream(s, begin, min(capacity, begin + WIDE_STREAM_RAYS), stk_dyn,
+        [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
                 f3 org, dir; primary_ray(fp, seeds, x, y, org, dir);
                 A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
             } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
         },
-        [&](uint32_t slot, uint32_t, bool, bool hit, const TravHit &h) {
+        [&](uint32_t slot, bool, bool hit, const TravHit &h) {
             hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
         });
-}
-
-// Dynamic variant (default): a fixed grid of persistent waves; wave w belongs to shard w % WIDE_SHARDS, which owns a
-// contiguous 1/WIDE_SHARDS of the combined queue, and pulls 64-ray batches from the shard's counter.  Measured lane
-// accounting (tools/stream_probe.py): with a static 256-ray range per wave 65 % of the lanes hold a live ray on the
-// diffuse queue (the rest wait for the wave's last rays); with shared batches the wait happens once per shard.
-// One counter word sustains ~88 returning atomics/us (MI355X_MICROARCH.md "dequeue"), hence the shards.
-constexpr uint32_t WIDE_SHARDS = 64;
-__global__ void __launch_bounds__(64, 6) k_trace_mixed_wide_dyn(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
-                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ shard_counters) {
-    extern __shared__ uint32_t stk_dyn[];
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
-    const uint32_t shard = blockIdx.x % WIDE_SHARDS;
-    const uint32_t per_shard = ((n + WIDE_SHARDS - 1) / WIDE_SHARDS + 63u) & ~63u;
-    const uint32_t sb = shard * per_shard;
-    if (sb >= n) return;
-    const uint32_t se = min(n, sb + per_shard);
-    traverse_wide_stream(s, SharedBatches{shard_counters + shard, sb, se}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
-            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
-            A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
-        },
-        [&](uint32_t i, uint32_t pix, bool is_any, bool hit, const TravHit &h) {
-            if (is_any) {
-                if (!hit) { const uint32_t j = i - n_next; float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
-            } else {
-                hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-            }
-        });
-}
-
-// Same, four waves per workgroup sharing an LDS copy of the top `n_top` wide nodes (levels 0..2 of the BFS-numbered tree).
-constexpr uint32_t WIDE_TOP_WAVES = 4;
-__global__ void __launch_bounds__(64 * WIDE_TOP_WAVES) k_trace_mixed_wide_stream_top(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
-                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t depth, uint32_t n_top) {
-    extern __shared__ float4 lds_dyn[];       // [n_top * 5 float4 | WIDE_TOP_WAVES x depth x 64 uint2]
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
-    if (blockIdx.x * WIDE_TOP_WAVES * WIDE_STREAM_RAYS >= n) return;
-    for (uint32_t k = threadIdx.x; k < n_top * 5u; k += 64 * WIDE_TOP_WAVES) lds_dyn[k] = s.wnodes[(k / 5u) * WNODE_STRIDE + k % 5u];
-    __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn + n_top * 5u) + (size_t)wave * depth * (WIDE_STACK_LEVEL_BYTES / 4u);
-    const uint32_t begin = (blockIdx.x * WIDE_TOP_WAVES + wave) * WIDE_STREAM_RAYS;
-    if (begin >= n) return;
-    const uint32_t end = min(n, begin + WIDE_STREAM_RAYS);
-    traverse_wide_stream(s, StaticBatches{begin, end}, stk,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
-            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
-            A = sh ? srayA[j] : rayA[j]; B = sh ? srayB[j] : rayB[j]; is_any = sh ? 1u : 0u;
-        },
-        [&](uint32_t i, uint32_t pix, bool is_any, bool hit, const TravHit &h) {
-            if (is_any) {
-                if (!hit) { const uint32_t j = i - n_next; float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
-            } else {
-                hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-            }
-        }, lds_dyn, n_top);
-}
-
-// ------------------------------------------------------------------ persistent variants (lane refill)
-__global__ void __launch_bounds__(64) k_extend_persistent(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                                                          const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
-    const uint32_t n = count ? (uint32_t)*count : capacity;
-    if (blockIdx.x * 64u >= n) return;
-    traverse_queue<false>(s, rayA, rayB, n, blockIdx.x, gridDim.x, [&](uint32_t idx, uint32_t, bool hit, const TravHit &h) {
-        hits[idx] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-    });
-}
-__global__ void __launch_bounds__(64) k_shadow_persistent(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                          const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
-    const uint32_t n = (uint32_t)(*count >> 32);
-    if (blockIdx.x * 64u >= n) return;
-    traverse_queue<true>(s, srayA, srayB, n, blockIdx.x, gridDim.x, [&](uint32_t idx, uint32_t pix, bool occluded, const TravHit &) {
-        if (!occluded) {
-            float4 c = scon[idx], a = sample[pix];
-            sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);
-        }
-    });
 }
 
 // Queue compaction.  Lanes ballot, waves post their two counts to LDS, and ONE packed 64-bit atomic per
@@ -537,9 +403,7 @@ __global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__rest
 // Also the frame's bookkeeping (block 0, thread 0): per-bounce queue counters {next rays, shadow rays} are
 // folded into the running totals and zeroed for the next frame.
 __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst,
-                                                   unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary,
-                                                   uint32_t *__restrict__ shard_counters, uint32_t n_shard_counters) {
-    if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < n_shard_counters; k += 64) shard_counters[k] = 0;   // batch counters of this lane's next frame
+                                                   unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long closest = primary, shadow = 0;
         for (int b = 0; b < fp.max_bounces; b++) {
@@ -633,12 +497,12 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     const uint32_t end = min(n, begin + per_wave);
     StreamStats ss{0, 0, 0, 0, 0, 0};
     uint32_t sink = 0;
-    traverse_wide_stream(s, StaticBatches{begin, end}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &is_any) {
-            MRTRay r = rays[i];
+    traverse_wide_stream(s, begin, end, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
             A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
         },
-        [&](uint32_t, uint32_t, bool, bool hit, const TravHit &) { sink += hit ? 1u : 0u; }, nullptr, 0, &ss);
+        [&](uint32_t, bool, bool hit, const TravHit &) { sink += hit ? 1u : 0u; }, &ss);
     if ((threadIdx.x & 63) == 0) {
         uint32_t *o = out + 8 * (size_t)blockIdx.x;
         o[0] = ss.iters; o[1] = ss.live_sum; o[2] = ss.node_sum; o[3] = ss.tri_sum; o[4] = ss.refills; o[5] = ss.refill_lanes; o[6] = sink; o[7] = end - begin;
@@ -671,8 +535,6 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
         MRT_HIP(L.bounce_counts.alloc(32));
-        MRT_HIP(L.shard_counters.alloc(32 * 64));
-        MRT_HIP(hipMemsetAsync(L.shard_counters.p, 0, L.shard_counters.bytes(), stream));
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -754,7 +616,6 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     const bool wide = use_wide && sv.num_wnodes > 0;
-    const uint32_t grid_p = std::max<uint32_t>(1u, std::min<uint32_t>(grid, (uint32_t)persistent_waves));
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
@@ -767,16 +628,16 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229
         fp.sampleIndex = frame_index + sample_offset;
-        if (fused && !wide && !persistent) {
+        if (fused && !wide) {
+            // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
             const uint32_t grid_mixed = 2 * grid;
-            const bool lds = use_lds && sv.hot_nodes > 0;
-            const uint32_t lds_bytes = sv.hot_nodes * 64u;
+            const bool on_wide = wide_bounce && sv.num_wnodes > 0;
+            const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
             auto timed_begin = [&]() -> bool { bool t = ext_used < (int)ev_ext.size(); if (t) (void)hipEventRecord(ev_ext[ext_used].a, st); return t; };
             auto timed_end = [&](bool t) { if (t) { (void)hipEventRecord(ev_ext[ext_used].b, st); ext_used++; } };
             fp.bounce = 0;
             bool t0 = timed_begin();
-            if (primary_wide && sv.num_wnodes) hipLaunchKernelGGL(k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, fp, seeds.p, L.hits.p, capacity);
-            else if (lds) hipLaunchKernelGGL(k_trace_primary_lds, dim3(cdiv(capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, fp, seeds.p, L.hits.p);
+            if (primary_wide && sv.num_wnodes) hipLaunchKernelGGL(k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
             else hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             timed_end(t0);
             int q = 0;                                                  // shade(b) writes next rays into queue q
@@ -787,24 +648,18 @@ int Renderer::render(int n_frames) {                                   // Render
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 bool t1 = timed_begin();
-                if (wide_bounce && sv.num_wnodes && wide_stream && wide_top > 0) {
-                    const uint32_t n_top = std::min<uint32_t>((uint32_t)wide_top, sv.num_wnodes);
-                    const size_t lds = (size_t)n_top * 80u + (size_t)WIDE_TOP_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
-                    hipLaunchKernelGGL(k_trace_mixed_wide_stream_top, dim3(cdiv(2 * (size_t)capacity, WIDE_STREAM_RAYS * WIDE_TOP_WAVES)), dim3(64 * WIDE_TOP_WAVES), lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, (uint32_t)scene->wide_depth, n_top);
-                }
-                else if (wide_bounce && sv.num_wnodes && wide_stream && wide_dynamic) hipLaunchKernelGGL(k_trace_mixed_wide_dyn, dim3(std::min<uint32_t>((uint32_t)dyn_waves, cdiv(2 * (size_t)capacity, 64))), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, L.shard_counters.p + (size_t)b * WIDE_SHARDS);
-                else if (wide_bounce && sv.num_wnodes && wide_stream) {
-                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (size_t)lds_pad, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
+                if (on_wide && wide_stream) {
+                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
-                else if (wide_bounce && sv.num_wnodes) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-                else if (lds) hipLaunchKernelGGL(k_trace_mixed_lds, dim3(cdiv(2 * (size_t)capacity, TRACE_LDS_THREADS)), dim3(TRACE_LDS_THREADS), lds_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (on_wide) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 timed_end(t1);
                 q = 1 - q;
             }
         } else {
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
+            // unfused sequence: raygen -> per bounce { extend, shade, shadow }
+            hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
             int q = 0;
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
@@ -812,20 +667,18 @@ int Renderer::render(int n_frames) {                                   // Render
                 bool timed = ext_used < (int)ev_ext.size();
                 if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
                 if (wide) hipLaunchKernelGGL(k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                else if (persistent) hipLaunchKernelGGL(k_extend_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                    L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-                else if (persistent) hipLaunchKernelGGL(k_shadow_persistent, dim3(grid_p), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 q = 1 - q;
             }
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
         if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels, L.shard_counters.p, (uint32_t)L.shard_counters.n);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels);
         MRT_HIP(hipEventRecord(L.accumulated, st));
         last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334

@@ -47,8 +47,7 @@ struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0,
 // slowest lane) x (round-trip latency); a split inner-node / leaf loop made the slowest wave iterate
 // 4x more often than any of its lanes needed.
 template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
-MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false,
-                      const float4 *lds_nodes = nullptr, uint32_t hot = 0) {
+MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_nodes == 0) return false;
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
@@ -67,17 +66,9 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
         if (!do_tri && cur == NODE_TERM) break;
         if (STATS) { if (do_tri) tc->tris++; else tc->steps++; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc->wave_iters++; }
         const uint32_t off = do_tri ? pk0 + tri * 48u : cur << 6;
-        float4 r0, r1, r2;
-        if (!do_tri && cur < hot) {
-            // the `hot` largest-area nodes (the top of the tree, visited by most rays) are staged in LDS by the
-            // kernel: these steps bypass the vector-memory path, which is what bounds the bulk of the kernel
-            const float4 *__restrict__ ln = lds_nodes + 4u * cur;
-            r0 = ln[0]; r1 = ln[1]; r2 = ln[esc_off >> 4];
-        } else {
-            r0 = *reinterpret_cast<const float4 *>(base + off);
-            r1 = *reinterpret_cast<const float4 *>(base + off + 16u);
-            r2 = *reinterpret_cast<const float4 *>(base + off + (do_tri ? 32u : esc_off));
-        }
+        const float4 r0 = *reinterpret_cast<const float4 *>(base + off);
+        const float4 r1 = *reinterpret_cast<const float4 *>(base + off + 16u);
+        const float4 r2 = *reinterpret_cast<const float4 *>(base + off + (do_tri ? 32u : esc_off));
         if (do_tri) {
             tri++;
             float t, U, V, ad;
@@ -118,119 +109,6 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
         }
     }
     return h.gid != 0xFFFFFFFFu;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent wavefronts: lane refill + postponed leaves (BASELINE.json configs[4]: "persistent-wavefront
-// + ray compaction").
-//
-// Measured on MI355X (tools/bottleneck_probe.py, rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU): with one
-// ray per lane the bulk of the traversal kernels is VALU-issue bound while only ~28 % of the lanes of an
-// average VALU instruction are active.  Two causes: (1) box lanes and triangle lanes of a wave execute two
-// different instruction streams one after the other; (2) the rays of a wave have very different lengths
-// (diffuse bounce rays: mean 23 steps, wave maximum 67).  This loop removes both:
-//   * a lane that reaches a leaf only RECORDS it (LEAF_SLOTS per lane) and keeps walking boxes; the wave
-//     switches to a triangle phase — every lane tests its recorded triangles, one per iteration — when
-//     enough lanes are full or nobody can walk.  The order of triangle tests does not matter for the
-//     result (closest hit = global minimum t with an id tie-break; any hit is a boolean).
-//   * a fixed set of W waves walks the queue: wave w owns the 64-ray chunks w, w+W, ... (round-robin, no
-//     atomics — one counter word sustains only ~88 returning atomics/us on gfx950); lanes whose ray has
-//     finished emit the result through `sink` and take the next ray of the wave's stream.
-constexpr int REFILL_MIN = 12;     // refill when at least this many lanes are idle
-constexpr int FULL_MIN = 12;       // start a triangle phase when at least this many lanes have both leaf slots taken
-
-template <bool ANY, class Sink>
-MRT_DEV void traverse_queue(const SceneView &s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                            uint32_t n, uint32_t wave, uint32_t nwaves, Sink sink) {
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t p_next = 0;                       // wave-uniform: position in this wave's ray stream
-    bool live = false;                         // lane holds a ray in flight
-    uint32_t idx = 0xFFFFFFFFu, pix = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-    float ix = 0, iy = 0, iz = 0;
-    uint32_t oct = 0, esc_quad = 2, esc_lane = 0;
-    uint32_t cur = NODE_TERM;
-    uint32_t leaf0 = 0, leaf1 = 0;             // postponed leaves: (count << 27) | first packet, 0 = empty
-    TravHit h; h.t = 0; h.U = 0; h.V = 0; h.ad = 1; h.gid = 0xFFFFFFFFu;
-    bool occluded = false;
-    for (;;) {
-        const bool walking = live && cur != NODE_TERM && leaf1 == 0;
-        const bool pending = live && leaf0 != 0;
-        const bool finished = live && cur == NODE_TERM && leaf0 == 0;
-        const unsigned long long m_walk = __ballot(walking), m_pend = __ballot(pending), m_idle = __ballot(!live || finished);
-        const unsigned long long m_full = __ballot(live && leaf1 != 0);
-        const bool stream_left = ((p_next >> 6) * nwaves + wave) * 64u < n;      // wave-uniform
-        if (m_pend != 0ull && (m_walk == 0ull || __popcll(m_full) >= FULL_MIN)) {
-            // ---- triangle phase: every lane drains its postponed leaves, one packet per iteration
-            uint32_t tri = 0, tri_end = 0;
-            for (;;) {
-                if (tri >= tri_end && leaf0 != 0) { tri = leaf0 & 0x07FFFFFFu; tri_end = tri + (leaf0 >> 27); leaf0 = leaf1; leaf1 = 0; }
-                const bool has = tri < tri_end;
-                if (__ballot(has) == 0ull) break;
-                if (has) {
-                    const float4 *__restrict__ pk = s.packets + 3 * (size_t)tri;
-                    const float4 r0 = pk[0], r1 = pk[1], r2 = pk[2];
-                    tri++;
-                    float t, U, V, ad;
-                    if (tri_test(r0, r1, r2, o, d, 0.0f, h.t, t, U, V, ad)) {
-                        if (ANY) { occluded = true; cur = NODE_TERM; tri = tri_end; leaf0 = 0; leaf1 = 0; }
-                        else {
-                            const uint32_t gid = __float_as_uint(r0.w);
-                            if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }
-                        }
-                    }
-                }
-            }
-            continue;
-        }
-        if (m_walk == 0ull || (stream_left && __popcll(m_idle) >= REFILL_MIN)) {
-            // ---- retire finished rays, refill idle lanes (here no lane has postponed leaves unless others still walk)
-            if (finished) { sink(idx, pix, ANY ? occluded : (h.gid != 0xFFFFFFFFu), h); live = false; }
-            if (!stream_left) { if (__ballot(live) == 0ull) break; if (m_walk == 0ull && m_pend == 0ull) continue; }
-            else {
-                const unsigned long long m_take = __ballot(!live);
-                const uint32_t p = p_next + (uint32_t)__popcll(m_take & lt);
-                p_next += (uint32_t)__popcll(m_take);
-                if (!live) {
-                    const uint32_t i = ((p >> 6) * nwaves + wave) * 64u + (p & 63u);
-                    if (i < n) {
-                        const float4 A = rayA[i], B = rayB[i];
-                        idx = i; pix = __float_as_uint(B.w);
-                        o = mk3(A); d = mk3(B);
-                        ix = safe_inv(d.x); iy = safe_inv(d.y); iz = safe_inv(d.z);
-                        oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-                        esc_quad = 2u + (oct >> 2); esc_lane = oct & 3u;
-                        h.t = A.w; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
-                        occluded = false;
-                        const bool dead = pix == 0xFFFFFFFFu || s.num_nodes == 0;    // partial-tile slot / empty scene: immediate miss
-                        cur = dead ? NODE_TERM : 0u; leaf0 = 0; leaf1 = 0;
-                        live = true;
-                    }
-                }
-                continue;
-            }
-        }
-        // ---- box step for every walking lane
-        if (walking) {
-            const float4 *__restrict__ rec = s.nodes + 4 * (size_t)cur;
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[esc_quad];
-            float tx0 = (r0.x - o.x) * ix, tx1 = (r1.x - o.x) * ix;
-            float ty0 = (r0.y - o.y) * iy, ty1 = (r1.y - o.y) * iy;
-            float tz0 = (r0.z - o.z) * iz, tz1 = (r1.z - o.z) * iz;
-            float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-            float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000005f;
-            tf = fminf(tf, h.t);
-            const uint32_t a = __float_as_uint(r0.w), b = __float_as_uint(r1.w);
-            const float escf = esc_lane == 0 ? r2.x : esc_lane == 1 ? r2.y : esc_lane == 2 ? r2.z : r2.w;
-            const uint32_t esc = __float_as_uint(escf);
-            const bool hit = tn <= tf;
-            const bool leaf = (a & NODE_LEAF) != 0;
-            const uint32_t child = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
-            cur = (hit && !leaf) ? child : esc;
-            if (hit && leaf) { const uint32_t e = (b << 27) | (a & 0x07FFFFFFu); if (leaf0 == 0) leaf0 = e; else leaf1 = e; }
-        }
-    }
 }
 
 }  // namespace

@@ -348,21 +348,18 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_dynamic_batches", "hybrid_no_refill", "rope_only", "rope_unfused", "rope_persistent", "rope_lds_nodes", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight"])
+@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_no_refill", "rope_only", "rope_unfused", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every traversal backend / scheduling option must give the oracle's image: the default hybrid (stackless
     rope walk for primary rays, 8-wide compressed layout + LDS stack for bounce and shadow rays), rope only,
-    the unfused kernel sequence, the persistent-wavefront variant (lane refill + postponed leaves), LDS-staged
-    hot nodes, wide layout for everything, and any number of frames in flight."""
+    the unfused kernel sequence, the wide layout without lane refill, the wide layout for everything (primary rays
+    too), shadow rays on the rope kernel, and any number of frames in flight."""
     w, h = 256, 144
     sc = mrt.DragonScene((w, h))
     sopt = {"wide": 0} if backend.startswith("rope") else None
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
-    if backend == "hybrid_dynamic_batches": r.set_option("wide_dynamic", 1); r.set_option("dyn_waves", 200)
     if backend == "hybrid_no_refill": r.set_option("wide_stream", 0)
     if backend == "rope_unfused": r.set_option("fused", 0)
-    if backend == "rope_persistent": r.set_option("persistent", 1); r.set_option("persistent_waves", 97)
-    if backend == "rope_lds_nodes": r.set_option("lds", 1)
     if backend == "wide_all": r.set_option("wide", 1)
     if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
     if backend == "shadow_on_rope": r.set_option("shadow_rope", 1)
