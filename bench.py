@@ -65,12 +65,12 @@ def measured_traffic():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(files[-1]))
-        return d["trace_launch_hbm_bytes"], os.path.relpath(files[-1], ROOT)
+        return d["trace_launch_hbm_bytes"], os.path.relpath(files[-1], ROOT), d.get("trace_launch_avg_us")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(mrt, scene, w, h, bounces, threads):
@@ -194,7 +194,7 @@ def main():
         avg_ms = ext_ms / max(1, ext_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = st.bytes_alg / max(1, st.frames)
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src, prof_avg_us = measured_traffic()
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -212,6 +212,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
+                         # the live figure spans end-of-previous-command .. end-of-kernel on the launching stream, i.e. it includes the dispatch gap,
+                         # which grows with the frames in flight; the committed rocprofv3 kernel time of the same command:
+                         "avg_launch_ms_rocprof": round(prof_avg_us / 1e3, 4) if prof_avg_us else None,
                          "launches_timed": ext_launches},
         }
         if a.png:

@@ -16,6 +16,7 @@
 //   rayA = {origin.xyz, tmax}   rayB = {direction.xyz, pixel}   thr = {throughput.rgb, -}   (path rays)
 //   hit  = {t, U/|det|, V/|det|, gid}                                                        (16 B)
 //   shadow rays reuse rayA/rayB with tmax = lightDistance - 1e-3; con = {Lc*throughput, -}
+#include <hip/hip_ext.h>
 #include "renderer.h"
 #include "device_math.h"
 #include "traverse.h"
@@ -523,6 +524,13 @@ __global__ void k_probe_hemisphere(const float *u2, const float *n3, uint32_t n,
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Launch with the kernel's own start/stop events when `ev` is given (bench.py's live roofline measurement).
+template <class... KArgs, class... Args>
+static inline void launch_timed(EvPair *ev, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, st, ev->a, ev->b, 0, static_cast<KArgs>(args)...);
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, st, static_cast<KArgs>(args)...);
+}
+
 }  // namespace
 
 // ====================================================================== Renderer (host)
@@ -633,13 +641,13 @@ int Renderer::render(int n_frames) {                                   // Render
             const uint32_t grid_mixed = 2 * grid;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
-            auto timed_begin = [&]() -> bool { bool t = ext_used < (int)ev_ext.size(); if (t) (void)hipEventRecord(ev_ext[ext_used].a, st); return t; };
-            auto timed_end = [&](bool t) { if (t) { (void)hipEventRecord(ev_ext[ext_used].b, st); ext_used++; } };
+            // traversal launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the
+            // same clock rocprofv3 reads): plain hipEventRecord pairs on a stream also count the time a launch waits behind the
+            // other frames in flight (+12 % at 12 frames)
+            auto timed = [&]() -> EvPair * { return ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr; };
             fp.bounce = 0;
-            bool t0 = timed_begin();
-            if (primary_wide && sv.num_wnodes) hipLaunchKernelGGL(k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
-            else hipLaunchKernelGGL(k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
-            timed_end(t0);
+            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
+            else launch_timed(timed(), k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
@@ -647,14 +655,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
-                bool t1 = timed_begin();
                 if (on_wide && wide_stream) {
-                    hipLaunchKernelGGL(k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p, shadow_rope ? 1 : 0);
+                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
-                else if (on_wide) hipLaunchKernelGGL(k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-                else hipLaunchKernelGGL(k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-                timed_end(t1);
+                else if (on_wide) launch_timed(timed(), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
+                else launch_timed(timed(), k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 q = 1 - q;
             }
         } else {
@@ -664,11 +670,9 @@ int Renderer::render(int n_frames) {                                   // Render
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
-                bool timed = ext_used < (int)ev_ext.size();
-                if (timed) MRT_HIP(hipEventRecord(ev_ext[ext_used].a, st));
-                if (wide) hipLaunchKernelGGL(k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                else hipLaunchKernelGGL((k_extend), dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                if (timed) { MRT_HIP(hipEventRecord(ev_ext[ext_used].b, st)); ext_used++; }
+                EvPair *ev = ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr;
+                if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
+                else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                    L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
