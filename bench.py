@@ -39,8 +39,8 @@ BYTES_PER_SHADOW_RAY = 72
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "dragon4", "garden"])
@@ -158,13 +158,12 @@ def main():
     t0 = time.perf_counter()
     done = 0
     ext_ms, ext_launches = 0.0, 0
-    while done < a.steps:
-        k = min(64, a.steps - done)          # 64 frames x 3 bounces = 192 per-launch event pairs per batch
-        r.draw(k)
-        r.wait()
-        st = r.stats
-        ext_ms += st.ms_extend_last; ext_launches += st.extend_launches_last
-        done += k
+    # all K steps are enqueued at once: the renderer carries them in batches of `frame_batch` frames on `frames_in_flight` streams;
+    # its first 512 traversal launches carry start/stop events (the live roofline measurement)
+    r.draw(a.steps)
+    r.wait()
+    st = r.stats
+    ext_ms += st.ms_extend_last; ext_launches += st.extend_launches_last
     if world > 1:
         reduce_image()
     sync()
@@ -186,8 +185,10 @@ def main():
         # dominant kernels: the traversal launches (k_trace_primary + k_trace_mixed; k_extend in the unfused pipeline).
         # Algorithmic bytes per launch = (96 B x closest-hit rays + 72 B x shadow rays) / traversal launches;
         # the fused launches carry both kinds, the unfused k_extend only the 96-B rays.
-        launches_per_frame = max(1.0, ext_launches / a.steps) if ext_launches < 512 else float(a.bounces + 1)
-        fused = launches_per_frame > a.bounces + 0.5
+        fused = r.get_option("fused") != 0 and r.get_option("wide") == 0
+        frame_batch = int(r.get_option("frame_batch")) if fused else 1
+        passes = (a.steps + frame_batch - 1) // frame_batch              # one pass of the pipeline = frame_batch frames
+        launches_per_frame = (a.bounces + 1 if fused else a.bounces) * passes / a.steps
         traced_bytes = BYTES_PER_CLOSEST_RAY * st.closest_rays + (BYTES_PER_SHADOW_RAY * st.shadow_rays if fused else 0)
         bytes_per_launch = traced_bytes / (a.steps * launches_per_frame)
         rays_per_launch = (st.closest_rays + (st.shadow_rays if fused else 0)) / (a.steps * launches_per_frame)
@@ -206,6 +207,7 @@ def main():
                        "bvh_build_ms": round(sst.build_ms, 3), "sah_cost": round(sst.sah_cost, 3),
                        "rays_per_frame": {"closest": closest / steps_total, "shadow": shadow / steps_total, "primary": primary / steps_total},
                        "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
+                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")),
                        "frame_bytes_alg": frame_bytes, "frame_alg_GBps": round(frame_bytes * st.frames / dt / 1e9, 2),
                        "device": r.ctx.device_name},
             "roofline": {"bound": "hbm", "kernel": "k_trace_primary+k_trace_mixed" if fused else "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -213,7 +213,11 @@ int mrt_renderer_destroy(MRTRenderer r);
 int mrt_renderer_resize(MRTRenderer r, int32_t width, int32_t height);
 /* Default camera = Scene.setupCamera(size) recomputed from the size (Scene.swift:36-57).       */
 int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
+/* Tuning knobs of this implementation (no counterpart in the reference beyond maxFramesInFlight, Renderer.swift:33):
+ * "max_bounces", "frames_in_flight" (HIP streams carrying frame batches concurrently), "frame_batch" (frames carried through
+ * the pipeline per pass), "fused", "wide_bounce", "wide_stream", "primary_wide", "shadow_rope", "wide", "sample_offset".      */
 int mrt_renderer_set_option(MRTRenderer r, const char *key, double value);
+int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value);
 /* Screen-tile shard for multi-GPU: this renderer owns 8x8 tiles with (tile_id % world) == rank;
  * other pixels stay 0 in its targets so that a sum-reduce assembles the frame.                 */
 int mrt_renderer_set_shard(MRTRenderer r, int32_t rank, int32_t world);

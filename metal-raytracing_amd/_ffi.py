@@ -145,6 +145,7 @@ SIGNATURES = {
     "mrt_renderer_resize": (C.c_int, [_P, _I32, _I32]),
     "mrt_renderer_set_camera": (C.c_int, [_P, C.POINTER(Camera)]),
     "mrt_renderer_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "mrt_renderer_get_option": (C.c_int, [_P, C.c_char_p, _P]),
     "mrt_renderer_set_shard": (C.c_int, [_P, _I32, _I32]),
     "mrt_renderer_set_frame_index": (C.c_int, [_P, _U32]),
     "mrt_renderer_frame_index": (C.c_int, [_P, _PU32]),

@@ -367,6 +367,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
+    else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,8]"); r->r.frame_batch = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
@@ -375,6 +376,24 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
+    MRT_TRY
+    REQUIRE(r && key && value, "mrt_renderer_get_option: bad argument");
+    std::string k(key);
+    if (k == "max_bounces") *value = r->r.max_bounces;
+    else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
+    else if (k == "frame_batch") *value = r->r.frame_batch;
+    else if (k == "fused") *value = r->r.fused ? 1 : 0;
+    else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
+    else if (k == "wide_stream") *value = r->r.wide_stream ? 1 : 0;
+    else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;
+    else if (k == "primary_wide") *value = r->r.primary_wide ? 1 : 0;
+    else if (k == "wide") *value = r->r.use_wide ? 1 : 0;
+    else if (k == "sample_offset") *value = r->r.sample_offset;
+    else { mrt::set_error("mrt_renderer_get_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     return MRT_OK;
     MRT_CATCH
 }

@@ -57,11 +57,30 @@ MRT_DEV float halton_dev(int i, int d) {
         while (i > 0) { f = f * invB; r = r + f * (float)(i % b); i = i / b; }
         return r;
     }
-    const uint32_t M = 0xFFFFFFFFu / (uint32_t)b + 1u;     // one emulated divide per call, outside the digit loop
     uint32_t u = (uint32_t)i;
+    if (b <= 23) {
+        // two digits per trip: b^2 <= 529 keeps mulhi(u, M2) the exact quotient u / b^2 for u < 2^22 (u * (M2*b^2 - 2^32) < 2^32);
+        // the two-digit remainder r2 < 529 splits with full-rate 24-bit multiplies: d1 = (r2 * M1) >> 20 is exact because
+        // r2 * (M1*b - 2^20) < 529 * 23 < 2^20.  An odd digit count ends with d1 = 0: r + f*0 == r.
+        // (32-bit integer multiplies run at quarter rate on gfx950; per digit this loop costs ~36 cycles of VALU issue instead of ~60.)
+        const uint32_t b2 = (uint32_t)(b * b);
+        const uint32_t M2 = 0xFFFFFFFFu / b2 + 1u;
+        const uint32_t M1 = (1u << 20) / (uint32_t)b + 1u;
+        while (u > 0) {
+            const uint32_t q = __umulhi(u, M2);
+            const uint32_t r2 = u - __umul24(q, b2);
+            const uint32_t d1 = __umul24(r2, M1) >> 20;
+            const uint32_t d0 = r2 - __umul24(d1, (uint32_t)b);
+            f = f * invB; r = r + f * (float)d0;
+            f = f * invB; r = r + f * (float)d1;
+            u = q;
+        }
+        return r;
+    }
+    const uint32_t M = 0xFFFFFFFFu / (uint32_t)b + 1u;     // one emulated divide per call, outside the digit loop
     while (u > 0) {
         const uint32_t q = __umulhi(u, M);
-        const uint32_t rem = u - q * (uint32_t)b;
+        const uint32_t rem = u - __umul24(q, (uint32_t)b);  // q < 2^22, b < 2^10: the 24-bit multiply is exact (and full rate)
         f = f * invB;
         r = r + f * (float)rem;
         u = q;

@@ -20,6 +20,7 @@ struct FrameLane {
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
+constexpr int MAX_FRAME_BATCH = 8;
 
 struct Renderer {
     hipStream_t stream = nullptr;
@@ -40,6 +41,8 @@ struct Renderer {
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
+    int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
+    int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel

@@ -36,6 +36,11 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     int32_t shard_rank, shard_world;
     int32_t tiles_x, tiles_local;
     int32_t bounce, max_bounces;
+    // frame batching: one pass of the pipeline carries `batch` consecutive frames.  Sub-frame s uses Halton index
+    // sampleIndex + s (the offset is baked into its copy of the seed table), slots [s * capacity, (s + 1) * capacity)
+    // of the primary queue and sample buffer entries [s * npix, (s + 1) * npix); k_accumulate applies the sub-frames in order.
+    uint32_t npix, capacity;
+    int32_t batch;
 };
 
 constexpr uint32_t DEAD_PIXEL = 0xFFFFFFFFu;
@@ -50,16 +55,17 @@ MRT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, int &x, int &y)
     return x < fp.width && y < fp.height;
 }
 
+// seeds[s * n + i] = hash(seed, i) + s: sub-frame s of a batch reads its Halton offset with the sub-frame index already added
 __global__ void k_seed(uint32_t *__restrict__ seeds, uint32_t n, uint32_t seed) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) seeds[i] = seed_hash_dev(seed, i);
+    if (i < n) seeds[(size_t)blockIdx.y * n + i] = seed_hash_dev(seed, i) + blockIdx.y;
 }
 
 // ------------------------------------------------------------------ primary rays
 // Raytracing.metal:175, :202-221
-MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, int x, int y, f3 &org, f3 &dir) {
+MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, uint32_t sub, int x, int y, f3 &org, f3 &dir) {
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
-    uint32_t offset = seeds[pix];                                        // :175
+    uint32_t offset = seeds[sub * fp.npix + pix];                        // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
     float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
     float px = (float)x + r0, py = (float)y + r1;                        // :204
@@ -115,17 +121,18 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
 //                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
 //                     the loop; a shadow lane simply stops at its first hit.
 __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits) {
-    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x, sub = blockIdx.y;      // grid = (local tiles, sub-frames of the batch)
+    float4 *__restrict__ hits_s = hits + (size_t)sub * fp.capacity;
     int x, y;
     if (!slot_to_pixel(fp, slot, x, y)) {
-        if ((int)(slot >> 6) < fp.tiles_local) hits[slot] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        if ((int)(slot >> 6) < fp.tiles_local) hits_s[slot] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
         return;
     }
     f3 org, dir;
-    primary_ray(fp, seeds, x, y, org, dir);
+    primary_ray(fp, seeds, sub, x, y, org, dir);
     TravHit h;
     bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
-    hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    hits_s[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 
 __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
@@ -240,13 +247,14 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
 // equal on the full frame, 7 % slower on the primary + shadow workload).
 __global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity) {
     extern __shared__ uint32_t stk_dyn[];
-    const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
+    const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS, sub = blockIdx.y;
     if (begin >= capacity) return;
+    hits += (size_t)sub * capacity;
     traverse_wide_stream(s, begin, min(capacity, begin + WIDE_STREAM_RAYS), stk_dyn,
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
-                f3 org, dir; primary_ray(fp, seeds, x, y, org, dir);
+                f3 org, dir; primary_ray(fp, seeds, sub, x, y, org, dir);
                 A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
             } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
         },
@@ -275,13 +283,18 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
                                               float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */) {
     __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES];
     __shared__ unsigned long long blk_base;
-    uint32_t i = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
+    const uint32_t sub = sample_primary ? blockIdx.y : 0u;
+    const uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    const uint32_t i = sub * capacity + slot;
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
-    bool active = i < n;
+    bool active = slot < n;
     int px_x = 0, px_y = 0;
+    uint32_t spix = 0;                   // sample-buffer index = sub * npix + pixel
     if (sample_primary) {
-        active = active && slot_to_pixel(fp, i, px_x, px_y);
-        if (active) sample_primary[(uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // Raytracing.metal:227
+        active = active && slot_to_pixel(fp, slot, px_x, px_y);
+        spix = sub * fp.npix + (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+        if (active) sample_primary[spix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // Raytracing.metal:227
     }
     float4 H = active ? hits[i] : make_float4(-1, 0, 0, 0);
     uint32_t gid = __float_as_uint(H.w);
@@ -293,9 +306,9 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         float4 A, B, C;
         if (sample_primary) {
             f3 org, dir;
-            primary_ray(fp, seeds, px_x, px_y, org, dir);
+            primary_ray(fp, seeds, sub, px_x, px_y, org, dir);
             A = make_float4(org.x, org.y, org.z, __builtin_inff());
-            B = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x));
+            B = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
         } else { A = rayA[i]; B = rayB[i]; C = thr[i]; }
         pix = __float_as_uint(B.w);
@@ -311,7 +324,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
                      (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
         nrm = normalize3(n_w);                                           // :268
         f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
-        int idx = (int)(seeds[pix] + fp.sampleIndex);
+        int idx = (int)(seeds[pix] + fp.sampleIndex);                  // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
         float ls = halton_dev(idx, dim0 + 0);                            // :272
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
@@ -419,12 +432,16 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
     int x, y;
     if (!slot_to_pixel(fp, slot, x, y)) return;
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
-    float4 c = sample[pix];
-    if (fp.frameIndex > 0) {
-        float4 p = prev[pix];
-        float fi = (float)fp.frameIndex;
-        float den = (float)(fp.frameIndex + 1);
-        c.x = (c.x + p.x * fi) / den; c.y = (c.y + p.y * fi) / den; c.z = (c.z + p.z * fi) / den;
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
+        const float4 sm = sample[(size_t)sub * fp.npix + pix];
+        const uint32_t frame = fp.frameIndex + (uint32_t)sub;
+        if (frame > 0) {
+            const float4 p = sub == 0 ? prev[pix] : c;
+            float fi = (float)frame;
+            float den = (float)(frame + 1);
+            c.x = (sm.x + p.x * fi) / den; c.y = (sm.y + p.y * fi) / den; c.z = (sm.z + p.z * fi) / den;
+        } else c = sm;
     }
     dst[pix] = make_float4(c.x, c.y, c.z, 1.0f);
 }
@@ -564,12 +581,14 @@ Renderer::~Renderer() {
 int Renderer::resize(int w, int h) {                                   // Renderer.swift:353-356 → createTextures :231-275
     width = w; height = h;
     const size_t npix = (size_t)w * h;
-    MRT_HIP(seeds.alloc(npix));
+    const int B = std::max(1, std::min(frame_batch, MAX_FRAME_BATCH));
+    alloc_batch = B;
+    MRT_HIP(seeds.alloc(npix * B));
     MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix));
     MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
     MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
-    for (auto &L : lanes) { MRT_HIP(L.sample.alloc(npix)); MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream)); }
-    hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256)), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
+    for (auto &L : lanes) { MRT_HIP(L.sample.alloc(npix * B)); MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream)); }
+    hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256), B), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
     default_camera(w, h, &camera);
     frame_index = 0; cur = 0;
     MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
@@ -583,9 +602,10 @@ int Renderer::alloc_queues() {
     tiles_local = (tiles - shard_rank + shard_world - 1) / shard_world;
     if (tiles_local < 0) tiles_local = 0;
     capacity = (uint32_t)tiles_local * 64u;
+    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
     for (auto &L : lanes) {
-        for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(capacity)); MRT_HIP(L.rayB[k].alloc(capacity)); MRT_HIP(L.thr[k].alloc(capacity)); }
-        MRT_HIP(L.hits.alloc(capacity)); MRT_HIP(L.srayA.alloc(capacity)); MRT_HIP(L.srayB.alloc(capacity)); MRT_HIP(L.scon.alloc(capacity));
+        for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); MRT_HIP(L.thr[k].alloc(qcap)); }
+        MRT_HIP(L.hits.alloc(qcap)); MRT_HIP(L.srayA.alloc(qcap)); MRT_HIP(L.srayB.alloc(qcap)); MRT_HIP(L.scon.alloc(qcap));
     }
     // pixels owned by this shard (edge tiles may be partial)
     uint64_t owned = 0;
@@ -629,16 +649,39 @@ int Renderer::render(int n_frames) {                                   // Render
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
     MRT_HIP(hipEventRecord(ev_fork, stream));
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
+    if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
+        MRT_HIP(hipStreamSynchronize(stream));
+        const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
+        DevBuf<float4> keep; MRT_HIP(keep.alloc(accum[cur].n));
+        MRT_HIP(hipMemcpyAsync(keep.p, accum[cur].p, accum[cur].bytes(), hipMemcpyDeviceToDevice, stream));
+        const MRTCamera keep_cam = camera;
+        unsigned long long keep_totals[3] = {0, 0, 0};
+        MRT_HIP(hipMemcpy(keep_totals, totals.p, sizeof keep_totals, hipMemcpyDeviceToHost));
+        int rc = resize(width, height); if (rc) return rc;
+        MRT_HIP(hipMemcpyAsync(totals.p, keep_totals, sizeof keep_totals, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipMemcpyAsync(accum[keep_cur].p, keep.p, keep.bytes(), hipMemcpyDeviceToDevice, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; camera = keep_cam;
+        return render(n_frames);
+    }
+    // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
+    // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
+    const int batch_max = (fused && !wide) ? alloc_batch : 1;
+    fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
     hipEvent_t last_acc = nullptr;
-    for (int f = 0; f < n_frames; f++) {
-        FrameLane &L = lanes[f % F];
+    int pass = 0;
+    for (int f = 0; f < n_frames; pass++) {
+        const int B = std::min(batch_max, n_frames - f);
+        f += B;
+        fp.batch = B;
+        FrameLane &L = lanes[pass % F];
         hipStream_t st = L.stream;
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
-        fp.frameIndex = frame_index;                                    // updateUniforms :216-229
+        fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
         if (fused && !wide) {
             // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
-            const uint32_t grid_mixed = 2 * grid;
+            const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
             // traversal launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the
@@ -646,18 +689,20 @@ int Renderer::render(int n_frames) {                                   // Render
             // other frames in flight (+12 % at 12 frames)
             auto timed = [&]() -> EvPair * { return ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr; };
             fp.bounce = 0;
-            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
-            else launch_timed(timed(), k_trace_primary, dim3(grid), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
+            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
+            else launch_timed(timed(), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
-                hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
+                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
+                hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 if (on_wide && wide_stream) {
-                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0);
-                    if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0);
+                    if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
                 else if (on_wide) launch_timed(timed(), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 else launch_timed(timed(), k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
@@ -682,14 +727,14 @@ int Renderer::render(int n_frames) {                                   // Render
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
         if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)owned_pixels);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
         MRT_HIP(hipEventRecord(L.accumulated, st));
         last_acc = L.accumulated;
-        cur = 1 - cur;                                                  // ping-pong swap :332-334
-        frame_index++; frames_rendered++;
+        cur = 1 - cur;                                                  // ping-pong swap :332-334 (once per batch: the batch's frames are applied in one kernel)
+        frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
     }
     // join: the main stream continues after every lane has drained
-    for (int k = 0; k < std::min(F, n_frames); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
+    for (int k = 0; k < std::min(F, pass); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
     MRT_HIP(hipEventRecord(ev_end, stream));
     MRT_HIP(hipGetLastError());
     pending_timing = true;

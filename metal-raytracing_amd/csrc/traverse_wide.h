@@ -19,6 +19,12 @@ namespace mrt {
 namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+#ifndef MRT_WIDE_NODE_MIN
+#define MRT_WIDE_NODE_MIN 0
+#endif
+#ifndef MRT_WIDE_DUAL_TRI
+#define MRT_WIDE_DUAL_TRI 0   // measured: trace launches 13 % shorter, frame rate -1.5 % — the frame is bound by VALU issue in aggregate, and this adds instructions
+#endif
 #ifndef MRT_WIDE_PK_FMA
 #define MRT_WIDE_PK_FMA 0   // measured: the operand pairs cost ~3 VGPRs -> spills at the 80-register budget; -2.6 %
 #endif
@@ -226,8 +232,20 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
         // (Measured, full frame: node-or-triangle per iteration 6.90, node then triangle with two round trips 7.24,
         // this loop 7.44 Grays/s.)
         const bool has_tri = live && t_mask != 0;
-        bool want_node = live && (t_mask & (t_mask - 1u)) == 0u;
-        uint32_t pending = 0, tri_pk = 0;
+        const uint32_t t_rest = t_mask & (t_mask - 1u);         // triangles left after this iteration's first one
+        bool want_node = live && t_rest == 0u;
+#if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
+        {
+            const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
+            if (n_busy != 0u && n_want < (uint32_t)MRT_WIDE_NODE_MIN) want_node = false;
+        }
+#endif
+#if MRT_WIDE_DUAL_TRI
+        const bool has_tri2 = live && t_rest != 0u;             // two or more pending: test two this iteration (the node registers carry the second packet)
+#else
+        const bool has_tri2 = false;
+#endif
+        uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
         if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
                 const uint32_t sp = g_mask >> 16;
@@ -249,27 +267,34 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
         asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
         r1.w = 0.0f; r2.w = 0.0f;
         if (has_tri) {
-            const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
-            t_mask &= t_mask - 1u;
-            tri_pk = t_base + k;
+            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u;
+            t_mask = t_rest;
             const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
+        }
+        if (has_tri2) {
+            tri_pk2 = t_base + (uint32_t)__ffs((int)t_rest) - 1u;
+            t_mask = t_rest & (t_rest - 1u);
+            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk2;
+            n0 = pk[0]; n1 = pk[1]; n2 = pk[2];
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
             n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
-        if (has_tri) {
+        auto consider = [&](const float4 q0, const float4 q1, const float4 q2, const uint32_t pk_index) {
             float t, U, V, ad;
-            if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
-                if ((tagw >> 31) != 0) { best_pk = tri_pk; live = false; unreported = true; }   // any-hit ray: done
+            if (tri_test(q0, q1, q2, o, d, 0.0f, best_t, t, U, V, ad)) {
+                if ((tagw >> 31) != 0) { best_pk = pk_index; live = false; unreported = true; }   // any-hit ray: done
                 else {
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                    if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // t == best_t: ties go to the lowest id (rare)
-                    if (better) { best_t = t; best_pk = tri_pk; }
+                    if (!better) better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // t == best_t: ties go to the lowest id (rare)
+                    if (better) { best_t = t; best_pk = pk_index; }
                 }
             }
-        }
+        };
+        if (has_tri) consider(r0, r1, r2, tri_pk);
+        if (has_tri2 && live) consider(n0, n1, n2, tri_pk2);
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);

@@ -147,6 +147,11 @@ class Renderer:
     def set_option(self, key, value):
         check(lib.mrt_renderer_set_option(self.handle, key.encode(), float(value)))
 
+    def get_option(self, key):
+        v = C.c_double(0.0)
+        check(lib.mrt_renderer_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
     def set_shard(self, rank, world):
         check(lib.mrt_renderer_set_shard(self.handle, int(rank), int(world)))
 

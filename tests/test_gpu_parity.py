@@ -43,7 +43,9 @@ def oracle_render(orc, mrt, sc, w, h, frames, bounces=3, seed=1, shard=None, sta
 def test_device_halton_bit_exact(mrt, orc, gpu_ctx):
     import ctypes as C
     rng = np.random.default_rng(3)
-    i = np.concatenate([rng.integers(0, (1 << 20) + 4096, 20000), [0, 1, 2, 1048575, (1 << 24) - 1, 1 << 24, (1 << 24) + 12345]]).astype(np.int32)
+    # the device takes digits two at a time for bases <= 23, one at a time up to i < 2^22, and runs the plain loop beyond
+    i = np.concatenate([rng.integers(0, (1 << 20) + 4096, 20000), rng.integers(1 << 20, (1 << 22) + 64, 6000), [(1 << 22) - 2, (1 << 22) - 1, 1 << 22, (1 << 22) + 1, 528, 529, 530, 9 ** 6 - 1, 9 ** 6],
+                        [0, 1, 2, 1048575, (1 << 24) - 1, 1 << 24, (1 << 24) + 12345]]).astype(np.int32)
     d = rng.integers(0, 22, len(i)).astype(np.int32); d[-8:] = [0, 1, 2, 16, 21, 99, 3, 50]
     out = np.zeros(len(i), np.float32)
     mrt._ffi.check(mrt.lib.mrt_debug_halton(gpu_ctx.handle, mrt._ffi.ptr(i), mrt._ffi.ptr(d), len(i), mrt._ffi.ptr(out)))
@@ -348,7 +350,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_no_refill", "rope_only", "rope_unfused", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight"])
+@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_no_refill", "rope_only", "rope_unfused", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every traversal backend / scheduling option must give the oracle's image: the default hybrid (stackless
     rope walk for primary rays, 8-wide compressed layout + LDS stack for bounce and shadow rays), rope only,
@@ -365,6 +367,7 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "shadow_on_rope": r.set_option("shadow_rope", 1)
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
+    if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 4: 5 frames = 4 + 1
     r.draw(5, wait=True)
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
     assert_parity(r.accumulation(), ref)
@@ -376,6 +379,25 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
         assert np.array_equal(g["primitive_id"], o["primitive_id"]) and np.array_equal(g["distance"].view(np.uint32), o["distance"].view(np.uint32))
         rays[:, 7] = 1.5
         assert np.array_equal(r.device_scene.intersect_any(rays), osc.intersect_any(rays))
+    r.close()
+
+
+def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
+    """Frames travel through the pipeline in batches (frame_batch per pass); the running average must not depend on how
+    the frames were grouped, nor on the option changing between draws (the buffers are re-sized, the image is kept)."""
+    w, h = 200, 120
+    sc = mrt.CornellScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    assert r.get_option("frame_batch") == 4
+    r.draw(3, wait=True)                       # one pass of 3
+    r.set_option("frame_batch", 2); r.draw(5, wait=True)    # 2 + 2 + 1
+    r.set_option("frame_batch", 8); r.draw(3, wait=True)    # one pass of 3
+    assert r.frameIndex == 11
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 11)
+    assert_parity(r.accumulation(), ref)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    with pytest.raises(mrt.MRTError):
+        r.set_option("frame_batch", 9)
     r.close()
 
 
