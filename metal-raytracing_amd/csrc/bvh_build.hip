@@ -575,37 +575,6 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
 }
 
-// ------------------------------------------------------------------ hot-first renumbering
-// The K nodes with the largest surface area — the ones rays visit most, closed under "parent of" since a
-// parent's box contains its child's — get indices 0..K-1 in descending-area order so that the traversal
-// kernels can keep them in LDS; every other node keeps its preorder position behind them.
-__global__ void k_hot_keys(TreeArrays t, uint32_t nnodes, const uint32_t *__restrict__ new_index, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nd >= nnodes) return;
-    uint32_t pre = new_index[nd];
-    uint64_t k = ~0ull;
-    if (pre != NONE) {
-        uint32_t ab = __float_as_uint(box_area(t.lo[nd], t.hi[nd]));         // non-negative float: bit order == value order
-        k = pre == 0 ? 0ull : (((uint64_t)(0xFFFFFFFFu - ab)) << 32) | pre;   // root first, then descending area, ties by preorder
-    }
-    keys[nd] = k; vals[nd] = nd;
-}
-__global__ void k_hot_mark(const uint32_t *__restrict__ sorted_vals, uint32_t k_hot, const uint32_t *__restrict__ new_index, uint32_t *__restrict__ hot_rank, uint32_t *__restrict__ flag_by_pre) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= k_hot) return;
-    uint32_t nd = sorted_vals[r];
-    hot_rank[nd] = r;
-    flag_by_pre[new_index[nd]] = 1u;
-}
-__global__ void k_hot_renumber(uint32_t nnodes, uint32_t k_hot, const uint32_t *__restrict__ hot_rank, const uint32_t *__restrict__ hot_before, uint32_t *__restrict__ new_index) {
-    uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nd >= nnodes) return;
-    uint32_t pre = new_index[nd];
-    if (pre == NONE) return;
-    uint32_t r = hot_rank[nd];
-    new_index[nd] = r != NONE ? r : k_hot + pre - hot_before[pre];
-}
-
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
 }  // namespace
@@ -614,7 +583,6 @@ SceneView DeviceScene::view() const {
     SceneView v{};
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
-    v.hot_nodes = hot_nodes;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
@@ -788,34 +756,6 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     }
     hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo.p, leaf_hi.p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
-    uint32_t k_hot = 0;
-    if (opt.lds_nodes > 0) {
-        // hot-first renumbering (see k_hot_keys): sort surviving nodes by descending surface area
-        DevBuf<uint64_t> hk_a, hk_b; DevBuf<uint32_t> hv_a, hv_b, hhist, hot_rank, flag, hot_before, bsum2, dummy;
-        MRT_HIP(hk_a.alloc(nnodes)); MRT_HIP(hk_b.alloc(nnodes)); MRT_HIP(hv_a.alloc(nnodes)); MRT_HIP(hv_b.alloc(nnodes));
-        MRT_HIP(hhist.alloc(256 * (size_t)cdiv(nnodes, SORT_TILE))); MRT_HIP(hot_rank.alloc(nnodes)); MRT_HIP(flag.alloc(nnodes)); MRT_HIP(hot_before.alloc(nnodes));
-        MRT_HIP(bsum2.alloc(cdiv(nnodes, 1024) + 1)); MRT_HIP(dummy.alloc(1));
-        uint32_t h_surv = 0;                                   // surviving nodes = size[root]; root = the node with preorder 0
-        {
-            std::vector<uint32_t> h_idx(nnodes);
-            MRT_HIP(hipMemcpyAsync(h_idx.data(), new_index.p, nnodes * 4, hipMemcpyDeviceToHost, stream));
-            MRT_HIP(hipStreamSynchronize(stream));
-            for (uint32_t i = 0; i < nnodes; i++) if (h_idx[i] != NONE) h_surv++;
-        }
-        k_hot = std::min<uint32_t>((uint32_t)opt.lds_nodes, h_surv);
-        hipLaunchKernelGGL(k_hot_keys, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, hk_a.p, hv_a.p);
-        radix_sort(hk_a.p, hk_b.p, hv_a.p, hv_b.p, nnodes, hhist.p);
-        MRT_HIP(hipMemsetAsync(hot_rank.p, 0xFF, hot_rank.bytes(), stream));
-        MRT_HIP(hipMemsetAsync(flag.p, 0, flag.bytes(), stream));
-        hipLaunchKernelGGL(k_hot_mark, dim3(cdiv(k_hot, B)), dim3(B), 0, stream, hv_a.p, k_hot, new_index.p, hot_rank.p, flag.p);
-        const uint32_t nb2 = cdiv(nnodes, 1024);
-        hipLaunchKernelGGL(k_scan_block, dim3(nb2), dim3(1024), 0, stream, flag.p, hot_before.p, bsum2.p, nnodes);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum2.p, nb2);
-        hipLaunchKernelGGL(k_scan_add, dim3(nb2), dim3(1024), 0, stream, hot_before.p, bsum2.p, nnodes, dummy.p, flag.p);
-        hipLaunchKernelGGL(k_hot_renumber, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, nnodes, k_hot, hot_rank.p, hot_before.p, new_index.p);
-        MRT_HIP(hipStreamSynchronize(stream));                 // scratch dies at scope exit
-    }
-    out.hot_nodes = k_hot;
     // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
     // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
     // one allocation: [nodes (worst case 2n-1) | packets], so the traversal addresses both from one base

@@ -70,7 +70,6 @@ struct SceneView {           // passed by value to kernels
     const float4 *wnodes;        // 5 x float4 per wide node
     const float4 *wpackets;      // 3 x float4 per triangle, grouped per wide node
     uint32_t num_wnodes;
-    uint32_t hot_nodes;          // nodes [0, hot_nodes) are the largest-area ones: the traversal kernels stage them in LDS
     uint32_t num_nodes;
     uint32_t num_tris;
     int32_t light_count;
@@ -107,14 +106,12 @@ struct BuildOptions {
     float cost_trav = 1.0f;   // SAH constants
     float cost_isect = 1.0f;
     int ploc_radius = 16;
-    int lds_nodes = 512;      // hot-first numbering: this many largest-area nodes come first (LDS-staged by the trace kernels)
     int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
 };
 
 struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
-    uint32_t hot_nodes = 0;
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;
     DevBuf<uint32_t> geom_base;
