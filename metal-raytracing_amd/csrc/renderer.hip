@@ -210,26 +210,34 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
     }
 }
 
-// Stream variant of k_trace_mixed_wide: one wave walks WIDE_STREAM_RAYS consecutive rays of the combined queue
-// [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).  384 rays per wave measured best
-// (256: -2 %, 512: -1 %, 1024: -7 %): longer ranges amortise the drain at the end of a wave's range, shorter ones
-// keep the launch's tail short.
-#ifndef MRT_WIDE_STREAM_RAYS
-#define MRT_WIDE_STREAM_RAYS 384
+// Stream variant of k_trace_mixed_wide: one wave walks `rays_per_wave` consecutive rays of the combined queue
+// [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).  Longer ranges amortise the drain at the end
+// of a wave's range, shorter ones keep the launch's tail short and the grid large; the host picks the range from the
+// size of the launch (stream_rays_per_wave): one frame per pass (4 M slots): 384 measured best (256: -2 %, 512: -1 %,
+// 1024: -7 %); four frames per pass (17 M slots): 1024 (384: -4.5 %, 768: -1.5 %, 2048: equal on the full frame, -3 % on
+// primary + shadow).
+#ifdef MRT_WIDE_STREAM_RAYS
+constexpr uint32_t WIDE_STREAM_RAYS_FIXED = MRT_WIDE_STREAM_RAYS;     // tuning builds
+#else
+constexpr uint32_t WIDE_STREAM_RAYS_FIXED = 0;
 #endif
-constexpr uint32_t WIDE_STREAM_RAYS = MRT_WIDE_STREAM_RAYS;
+static inline uint32_t stream_rays_per_wave(size_t slots) {
+    if (WIDE_STREAM_RAYS_FIXED) return WIDE_STREAM_RAYS_FIXED;
+    const size_t batches = slots / 64 / 10240;                             // 64-ray batches per wave if the launch had ~10 K waves
+    return 64u * (uint32_t)std::min<size_t>(16, std::max<size_t>(6, batches));
+}
 #ifndef MRT_WIDE_STREAM_WAVES
 #define MRT_WIDE_STREAM_WAVES 7
 #endif
 __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
-    const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS;
+    const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    traverse_wide_stream(s, begin, min(n, begin + WIDE_STREAM_RAYS), stk_dyn,
+    traverse_wide_stream(s, begin, min(n, begin + rays_per_wave), stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
@@ -245,12 +253,12 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
 
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
-__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity) {
+__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
-    const uint32_t begin = blockIdx.x * WIDE_STREAM_RAYS, sub = blockIdx.y;
+    const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
     hits += (size_t)sub * capacity;
-    traverse_wide_stream(s, begin, min(capacity, begin + WIDE_STREAM_RAYS), stk_dyn,
+    traverse_wide_stream(s, begin, min(capacity, begin + rays_per_wave), stk_dyn,
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
@@ -689,7 +697,8 @@ int Renderer::render(int n_frames) {                                   // Render
             // other frames in flight (+12 % at 12 frames)
             auto timed = [&]() -> EvPair * { return ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr; };
             fp.bounce = 0;
-            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, WIDE_STREAM_RAYS), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity);
+            const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
+            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity, rpw_p);
             else launch_timed(timed(), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
@@ -701,7 +710,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 if (on_wide && wide_stream) {
-                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, WIDE_STREAM_RAYS)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0);
+                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
                 else if (on_wide) launch_timed(timed(), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
