@@ -2,17 +2,20 @@
 """bench.py — BASELINE.json's metric on MI355X: Mrays/s (closest-hit + shadow rays) and ms/frame,
 DragonScene 1920x1080 spp=1 (configs[1]).
 
-A "step" is one frame (one pass of the hot path over all pixels at 1 spp): raygen, then per bounce
-extend / shade / shadow, then accumulate — `Renderer.draw(in:)` of the reference
-(Renderer.swift:284-351).  Inputs (scene, BVH, seeds) are resident in HBM before the timed region.
+A "step" is one frame (one pass of the hot path over all pixels at 1 spp): primary rays, then per bounce
+shade / trace (closest hit for the bounce rays + any hit for the shadow rays), then accumulate —
+`Renderer.draw(in:)` of the reference (Renderer.swift:284-351).  Inputs (scene, BVH, seeds) are resident in HBM
+before the timed region.  The renderer carries the K steps in batches of `frame_batch` frames on
+`frames_in_flight` HIP streams (the reference keeps 3 frames in flight, Renderer.swift:33); every frame is
+rendered in full and the running average is applied in frame order.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU; the image is sharded by 8x8 screen tile (tile_id % N == rank), the K
-frames are accumulated locally and ONE RCCL reduce of the RGBA32F radiance buffer assembles the
-image on rank 0 inside the timed region.  Total work is fixed → "strong" scaling.
-`--shard sample` instead gives every rank full frames of a disjoint frame-index range ("weak").
+N > 1: one process per GPU, scene + BVH replicated.  Default `--shard sample`: every rank renders full frames of a
+disjoint Halton index range (per-GPU work fixed → "weak" scaling); `--shard tile`: the image is sharded by 8x8
+screen tile (tile_id % N == rank, total work fixed → "strong").  Either way the K frames are accumulated locally and
+ONE RCCL reduce of the RGBA32F radiance buffer assembles the image on rank 0 inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -200,7 +203,7 @@ def main():
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak" if (a.shard == "sample" and world > 1) else "strong",
+            "scaling": "weak" if a.shard == "sample" else "strong",     # per-GPU work fixed as N grows (sample sharding, the default) vs total work fixed (tile sharding)
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene {w}x{h} spp=1, {a.bounces} bounces, closest-hit + shadow rays counted on device",
                        "scene_sources": scene.describe(), "triangles": int(sst.triangles), "bvh_nodes": int(sst.bvh_nodes),
