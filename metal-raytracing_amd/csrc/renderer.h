@@ -42,6 +42,7 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
+    int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
@@ -64,6 +65,7 @@ struct Renderer {
     int init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed, int max_bounces);
     int resize(int w, int h);
     int alloc_queues();
+    int alloc_lane(FrameLane &L);
     int set_shard(int rank, int world);
     int render(int n_frames);
     int wait();

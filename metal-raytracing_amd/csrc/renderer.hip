@@ -595,7 +595,6 @@ int Renderer::resize(int w, int h) {                                   // Render
     MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix));
     MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
     MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
-    for (auto &L : lanes) { MRT_HIP(L.sample.alloc(npix * B)); MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream)); }
     hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256), B), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
     default_camera(w, h, &camera);
     frame_index = 0; cur = 0;
@@ -610,10 +609,11 @@ int Renderer::alloc_queues() {
     tiles_local = (tiles - shard_rank + shard_world - 1) / shard_world;
     if (tiles_local < 0) tiles_local = 0;
     capacity = (uint32_t)tiles_local * 64u;
-    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
+    // lanes get their buffers when first used (alloc_lane): 16 lanes x 4-frame queues would pin 23 GB at 1080p, 94 GB at 4K
+    lanes_ready = 0;
     for (auto &L : lanes) {
-        for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); MRT_HIP(L.thr[k].alloc(qcap)); }
-        MRT_HIP(L.hits.alloc(qcap)); MRT_HIP(L.srayA.alloc(qcap)); MRT_HIP(L.srayB.alloc(qcap)); MRT_HIP(L.scon.alloc(qcap));
+        for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
+        L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release();
     }
     // pixels owned by this shard (edge tiles may be partial)
     uint64_t owned = 0;
@@ -623,6 +623,15 @@ int Renderer::alloc_queues() {
         owned += (uint64_t)pw * ph;
     }
     owned_pixels = owned;
+    return MRT_OK;
+}
+
+int Renderer::alloc_lane(FrameLane &L) {
+    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); MRT_HIP(L.thr[k].alloc(qcap)); }
+    MRT_HIP(L.hits.alloc(qcap)); MRT_HIP(L.srayA.alloc(qcap)); MRT_HIP(L.srayB.alloc(qcap)); MRT_HIP(L.scon.alloc(qcap));
+    MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
+    MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     return MRT_OK;
 }
 
@@ -652,11 +661,6 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     const bool wide = use_wide && sv.num_wnodes > 0;
-    ext_used = 0;
-    MRT_HIP(hipEventRecord(ev_begin, stream));
-    // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
-    MRT_HIP(hipEventRecord(ev_fork, stream));
-    for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
     if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
         const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
@@ -672,6 +676,12 @@ int Renderer::render(int n_frames) {                                   // Render
         frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; camera = keep_cam;
         return render(n_frames);
     }
+    for (; lanes_ready < F; lanes_ready++) { int rc = alloc_lane(lanes[lanes_ready]); if (rc) return rc; }      // the first draw sizes the lanes in use
+    ext_used = 0;
+    MRT_HIP(hipEventRecord(ev_begin, stream));
+    // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
+    MRT_HIP(hipEventRecord(ev_fork, stream));
+    for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
     // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
     // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
     const int batch_max = (fused && !wide) ? alloc_batch : 1;
