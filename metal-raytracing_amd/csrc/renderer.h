@@ -8,14 +8,14 @@ namespace mrt {
 
 struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
 
-// One frame in flight (Renderer.maxFramesInFlight = 3, Renderer.swift:33): its own HIP stream, ray /
-// hit / shadow queues, per-pixel sample buffer and per-bounce queue counters.  Frames on different
-// lanes overlap on the GPU (one frame's straggler waves are covered by the next frame's bulk); only the
-// accumulate step is ordered frame to frame, by an event.
+// One pass in flight (the reference keeps 3 frames in flight, Renderer.maxFramesInFlight, Renderer.swift:33): its
+// own HIP stream, ray / hit / shadow queues, per-pixel sample buffers and per-bounce queue counters, all sized for
+// a batch of `frame_batch` consecutive frames.  Passes on different lanes overlap on the GPU (one pass's straggler
+// waves are covered by the next pass's bulk); only the accumulate step is ordered pass to pass, by an event.
 struct FrameLane {
     hipStream_t stream = nullptr;
     hipEvent_t accumulated = nullptr;    // recorded after this lane's k_accumulate
-    DevBuf<float4> sample;               // this frame's radiance per pixel
+    DevBuf<float4> sample;               // [sub-frame][pixel] radiance of the batch's frames
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
 };
