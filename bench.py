@@ -68,12 +68,12 @@ def measured_traffic():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
-        return None, None, None
+        return None, None, None, None
     try:
         d = json.load(open(files[-1]))
-        return d["trace_launch_hbm_bytes"], os.path.relpath(files[-1], ROOT), d.get("trace_launch_avg_us")
+        return d["trace_launch_hbm_bytes"], os.path.relpath(files[-1], ROOT), d.get("trace_launch_avg_us"), d.get("valu_wave_insts_per_frame")
     except Exception:
-        return None, None, None
+        return None, None, None, None
 
 
 def cpu_baseline(mrt, scene, w, h, bounces, threads):
@@ -198,7 +198,7 @@ def main():
         avg_ms = ext_ms / max(1, ext_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = st.bytes_alg / max(1, st.frames)
-        traffic, traffic_src, prof_avg_us = measured_traffic()
+        traffic, traffic_src, prof_avg_us, valu_insts = measured_traffic()
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -222,6 +222,14 @@ def main():
                          "avg_launch_ms_rocprof": round(prof_avg_us / 1e3, 4) if prof_avg_us else None,
                          "launches_timed": ext_launches},
         }
+        if valu_insts and world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3):
+            # what actually bounds the frame: VALU issue.  Wave-instructions per frame from the committed SQ_INSTS_VALU pass
+            # (a property of the workload) over the NOMINAL issue capacity of the timed frame: 256 CUs x 4 SIMDs x one wave64 instruction per
+            # 4 cycles at 2.4 GHz.  The counter also counts instructions that retire early with an empty EXEC mask, so frac can read > 1.
+            VALU_PEAK = 256 * 2.4e9
+            out["valu_issue"] = {"wave_insts_per_frame": round(valu_insts), "achieved_Ginst_per_s": round(valu_insts / (dt / a.steps) / 1e9, 1),
+                                 "nominal_peak_Ginst_per_s": VALU_PEAK / 1e9, "frac": round(valu_insts / (dt / a.steps) / VALU_PEAK, 4), "clock_GHz_assumed": 2.4,
+                                 "source": traffic_src}
         if a.png:
             if world > 1:
                 r.write_accum_from(accum_t.data_ptr(), npix * 16)      # show the assembled image, not this rank's shard

@@ -16,4 +16,6 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wri
 echo "write rc=$?"
 timeout -k 10 200 rocprofv3 --pmc VALUBusy VALUUtilization --output-format csv -d $OUT/pmc_valu -- python3 $R/bench.py --no-cpu-baseline --no-strict --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_valu.err
 echo "valu rc=$?"
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc_insts -- python3 $R/bench.py --no-cpu-baseline --no-strict --steps 8 --warmup 2 > /dev/null 2> $OUT/pmc_insts.err
+echo "insts rc=$?"
 cd $R && python3 tools/summarize_profiles.py $OUT $TAG

@@ -34,6 +34,14 @@ res["valu_lane_utilization_pct"] = pmc("pmc_valu", "VALUUtilization")   # % of l
 # of wide coalesced reads -> x2; other access widths are uncalibrated, so this is an upper estimate for gathers.
 res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": fetch.get(k), "write_KB": write.get(k),
                                            "bytes_corrected": (2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 if k in fetch else None} for k in set(fetch) | set(write)}
+# VALU wave-instructions per frame: every dispatch of the render kernels in the 10-frame counter run (8 steps + 2 warm-up)
+insts = 0.0
+for f in glob.glob(out + "/pmc_insts/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "SQ_INSTS_VALU" and any(k in r["Kernel_Name"] for k in ("k_trace", "k_shade", "k_accumulate")):
+            insts += float(r["Counter_Value"])
+if insts > 0:
+    res["valu_wave_insts_per_frame"] = insts / 10.0
 try:
     res["bench_under_rocprof"] = json.loads(open(out + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
 except Exception as e:
