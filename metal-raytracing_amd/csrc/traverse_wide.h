@@ -28,6 +28,11 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_PK_FMA
 #define MRT_WIDE_PK_FMA 0   // measured: the operand pairs cost ~3 VGPRs -> spills at the 80-register budget; -2.6 %
 #endif
+#ifndef MRT_WIDE_FLAT_HITS
+#define MRT_WIDE_FLAT_HITS 1
+#endif
+// ((1 << width) - 1) << offset in one instruction (width, offset taken mod 32)
+MRT_DEV uint32_t bfm_b32(uint32_t width, uint32_t offset) { uint32_t r; asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset)); return r; }
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
 
 // LDS stack of one wave: per tree level 64 words {child_base << 8 | remaining hit bits} followed by 64 bytes {imask}
@@ -79,8 +84,13 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
                                      __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, tmax);
 #endif
         if (tn <= tf) {
+#if MRT_WIDE_FLAT_HITS      // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
+            nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
+            th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
+#else
             if ((imask >> i) & 1u) nh |= 1u << ((uint32_t)i ^ oct);
             else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; th |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
+#endif
         }
     }
     node_hits = nh; tri_hits = th;
