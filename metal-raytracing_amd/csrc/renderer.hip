@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
 //   k_trace_mixed   : one launch over two queues — the next-bounce rays (closest hit -> hit records) and the
 //                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
 //                     the loop; a shadow lane simply stops at its first hit.
-__global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits) {
+__global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, sub = blockIdx.y;      // grid = (local tiles, sub-frames of the batch)
     float4 *__restrict__ hits_s = hits + (size_t)sub * fp.capacity;
     int x, y;
@@ -130,6 +130,9 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
     }
     f3 org, dir;
     primary_ray(fp, seeds, sub, x, y, org, dir);
+    // the direction goes to HBM (16 B per pixel: the memory system has headroom, the vector ALUs do not — k_shade reads it back
+    // instead of repeating two Halton values, two divisions and a normalisation per pixel)
+    dirs[(size_t)sub * fp.capacity + slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));
     TravHit h;
     bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
     hits_s[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
@@ -253,17 +256,18 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
 
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
-__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, uint32_t capacity, uint32_t rays_per_wave) {
+__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
-    hits += (size_t)sub * capacity;
+    hits += (size_t)sub * capacity; dirs += (size_t)sub * capacity;
     traverse_wide_stream(s, begin, min(capacity, begin + rays_per_wave), stk_dyn,
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
                 f3 org, dir; primary_ray(fp, seeds, sub, x, y, org, dir);
                 A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                dirs[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));   // read back by k_shade
             } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
         },
         [&](uint32_t slot, bool, bool hit, const TravHit &h) {
@@ -313,10 +317,8 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
     if (active) {
         float4 A, B, C;
         if (sample_primary) {
-            f3 org, dir;
-            primary_ray(fp, seeds, sub, px_x, px_y, org, dir);
-            A = make_float4(org.x, org.y, org.z, __builtin_inff());
-            B = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
+            A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
+            B = rayB[i];                                                 // direction | sample index, written by the primary trace
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
         } else { A = rayA[i]; B = rayB[i]; C = thr[i]; }
         pix = __float_as_uint(B.w);
@@ -708,8 +710,8 @@ int Renderer::render(int n_frames) {                                   // Render
             auto timed = [&]() -> EvPair * { return ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr; };
             fp.bounce = 0;
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
-            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, capacity, rpw_p);
-            else launch_timed(timed(), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p);
+            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
+            else launch_timed(timed(), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
