@@ -7,8 +7,8 @@
 // memory path (TA/L1 request rate on divergent 16-B gathers) and by the length of the dependent chain of
 // the slowest ray — not by arithmetic.  One 80-byte wide node tests eight quantised child boxes per
 // round trip: ~4x fewer 16-B requests per box and ~3x fewer round trips per ray.  The stack holds
-// (child_base, hit mask | imask) pairs, 8 B per entry, at most one entry per tree level; it lives in LDS
-// ([entry][lane], conflict free), never in scratch or HBM.
+// (child_base, remaining hit bits, imask) entries, 5 B each, at most one entry per tree level; it lives in LDS
+// ([level][lane], conflict free), never in scratch or HBM.
 //
 // The result is identical to the rope backend bit for bit: the closest hit is the global minimum t
 // with ties to the lowest triangle id, and the quantised boxes only ever grow.
@@ -19,17 +19,18 @@ namespace mrt {
 namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+// Compile-time switches kept for A/B builds (tools/build_variant.sh); the defaults are the measured best.
 #ifndef MRT_WIDE_NODE_MIN
-#define MRT_WIDE_NODE_MIN 0
+#define MRT_WIDE_NODE_MIN 0   // > 0: take the node branch only when this many lanes want it (-2 % for every value tried)
 #endif
 #ifndef MRT_WIDE_DUAL_TRI
 #define MRT_WIDE_DUAL_TRI 0   // measured: trace launches 13 % shorter, frame rate -1.5 % — the frame is bound by VALU issue in aggregate, and this adds instructions
 #endif
 #ifndef MRT_WIDE_PK_FMA
-#define MRT_WIDE_PK_FMA 0   // measured: the operand pairs cost ~3 VGPRs -> spills at the 80-register budget; -2.6 %
+#define MRT_WIDE_PK_FMA 0   // v_pk_fma_f32 plane evaluation: -1.5 ... -2.6 % (no spills at 72 VGPRs either: the packed form is not cheaper to issue here)
 #endif
 #ifndef MRT_WIDE_FLAT_HITS
-#define MRT_WIDE_FLAT_HITS 1
+#define MRT_WIDE_FLAT_HITS 1   // hit children recorded without an inner node/leaf branch: +0.8 % / +1.8 %
 #endif
 // ((1 << width) - 1) << offset in one instruction (width, offset taken mod 32)
 MRT_DEV uint32_t bfm_b32(uint32_t width, uint32_t offset) { uint32_t r; asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset)); return r; }
