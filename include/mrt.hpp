@@ -154,6 +154,9 @@ class Renderer {                                                     // Renderer
     void wait() { check(mrt_renderer_wait(r_)); }
     void drawableSizeWillChange(int width, int height) { w_ = width; h_ = height; check(mrt_renderer_resize(r_, width, height)); }   // :353-356
     uint32_t frameIndex() const { uint32_t f = 0; check(mrt_renderer_frame_index(r_, &f)); return f; }
+    // implementation knobs (mrt_abi.h): "frames_in_flight" (HIP streams, default 12), "frame_batch" (frames per pass, default 4), ...
+    void setOption(const char *key, double value) { check(mrt_renderer_set_option(r_, key, value)); }
+    double option(const char *key) const { double v = 0; check(mrt_renderer_get_option(r_, key, &v)); return v; }
     std::vector<float> accumulation() { std::vector<float> a((size_t)w_ * h_ * 4); check(mrt_renderer_read_accum(r_, a.data(), a.size() * 4)); return a; }
     std::vector<uint8_t> tonemapped() { std::vector<uint8_t> a((size_t)w_ * h_ * 4); check(mrt_renderer_read_tonemapped_rgba8(r_, a.data(), a.size())); return a; }
     MRTRenderStats stats() { MRTRenderStats s; check(mrt_renderer_stats(r_, &s)); return s; }
