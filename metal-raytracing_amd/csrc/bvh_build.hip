@@ -568,7 +568,8 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
         for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
     }
     const size_t w = WNODE_STRIDE * (size_t)(base_in + i);
-    wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24)));
+    // exponents are stored unbiased (int8, e - 127): the traversal scales 1/direction with v_ldexp_f32
+    wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24)));
     wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
     wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));

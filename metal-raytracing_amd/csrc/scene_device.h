@@ -35,7 +35,7 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 
 // ---- wide node: 80 B = 5 x float4, eight children with 8-bit quantised boxes (after Ylitie, Karras, Laine
 // 2017, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"):
-//   f4 0: origin p.xyz | ex | ey<<8 | ez<<16 | imask<<24      child box = p + q * 2^(e-127); imask bit i = child i is a node
+//   f4 0: origin p.xyz | ex | ey<<8 | ez<<16 | imask<<24      child box = p + q * 2^e (e: int8); imask bit i = child i is a node
 //   f4 1: child_base | tri_base | meta[0..3] | meta[4..7]      node child i -> child_base + popc(imask & ((1<<i)-1));
 //                                                              leaf child i -> packets tri_base + (meta&31) .. + (meta>>5) - 1
 //   f4 2: qlo_x[8] qlo_y[8]      f4 3: qlo_z[8] qhi_x[8]      f4 4: qhi_y[8] qhi_z[8]      (empty slot: qlo=255, qhi=0)

@@ -58,7 +58,8 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
                             const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
     const uint32_t ew = __float_as_uint(n0.w);
     const uint32_t imask = ew >> 24;
-    const float ax = __uint_as_float((ew & 0xFFu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xFFu) << 23) * iy, az = __uint_as_float(((ew >> 16) & 0xFFu) << 23) * iz;
+    // 2^e * idir: sign-extended exponent byte (v_bfe_i32) + v_ldexp_f32 — two instructions per axis instead of shift, mask, multiply
+    const float ax = __builtin_ldexpf(ix, (int)(int8_t)(ew & 0xFFu)), ay = __builtin_ldexpf(iy, (int)(int8_t)((ew >> 8) & 0xFFu)), az = __builtin_ldexpf(iz, (int)(int8_t)((ew >> 16) & 0xFFu));
     const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
     // near / far plane bytes per axis: swap lo and hi where the direction is negative
     const uint32_t lx0 = __float_as_uint(n2.x), lx1 = __float_as_uint(n2.y), ly0 = __float_as_uint(n2.z), ly1 = __float_as_uint(n2.w);
