@@ -251,6 +251,10 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
 /* Diagnostics: lane accounting of the wide stream traversal, per wave of `per_wave` rays:
  * {iterations, sum live lanes, sum node lanes, sum triangle lanes, refills, refilled lanes, hits, rays}.       */
 int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves);
+/* Calibration of the ceilings the render kernels are priced against (bench.py): out4 = {wave64 VALU instructions/s with
+ * 8 waves per SIMD, the same with one wave per SIMD, bytes/s of divergent 16-byte gathers from a table of about
+ * table_bytes, bytes/s of divergent 80-byte records (the wide-node fetch) from such a table}.                          */
+int mrt_debug_calibrate(MRTContext ctx, size_t table_bytes, double *out4);
 
 #ifdef __cplusplus
 }

@@ -485,4 +485,12 @@ int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height
     MRT_CATCH
 }
 
+int mrt_debug_calibrate(MRTContext ctx, size_t table_bytes, double *out3) {
+    MRT_TRY
+    REQUIRE(ctx && out3 && table_bytes >= 4096 && table_bytes <= ((size_t)1 << 34), "mrt_debug_calibrate: bad argument");
+    int rc = bind_device(ctx); if (rc) return rc;
+    return mrt::calibrate(ctx->stream, table_bytes, out3);
+    MRT_CATCH
+}
+
 }  // extern "C"

@@ -84,5 +84,6 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
 int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out);
 int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3);
 int probe_seeds(hipStream_t stream, uint32_t seed, int w, int h, uint32_t *out);
+int calibrate(hipStream_t stream, size_t table_bytes, double *out3);   // calibrate.hip
 
 }  // namespace mrt
