@@ -38,8 +38,8 @@ enum {
 
 /* ---------------------------------------------------------------- data contract
  * Bit layout of ShaderTypes.h:60-107.  `vector_float3` is 16-byte sized and aligned, hence the
- * explicit pad word.  Offsets are static_assert-ed in csrc/abi_check.h and tested in
- * tests/test_abi_layout.py.                                                                    */
+ * explicit pad word.  Sizes and offsets are static_assert-ed in metal-raytracing_amd/csrc/abi_check.h
+ * (compiled into the library) and checked through ctypes in tests/test_abi_and_host.py.         */
 typedef struct { float x, y, z, _pad; } MRTFloat3;                    /* simd vector_float3     */
 
 typedef struct {                                                      /* ShaderTypes.h:60-65    */
@@ -251,6 +251,9 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
 /* Diagnostics: lane accounting of the wide stream traversal, per wave of `per_wave` rays:
  * {iterations, sum live lanes, sum node lanes, sum triangle lanes, refills, refilled lanes, hits, rays}.       */
 int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves);
+/* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of
+ * `triangles` triangles whose BVH keeps `nodes` nodes (0 = unknown) cannot be addressed by the traversal layouts.      */
+int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes);
 /* Calibration of the ceilings the render kernels are priced against (bench.py): out4 = {wave64 VALU instructions/s with
  * 8 waves per SIMD, the same with one wave per SIMD, bytes/s of divergent 16-byte gathers from a table of about
  * table_bytes, bytes/s of divergent 80-byte records (the wide-node fetch) from such a table}.                          */

@@ -2,6 +2,7 @@
 // catches C++ exceptions and returns a status code; nothing throws or aborts across the ABI.
 // There is no CPU fallback: without a HIP device mrt_context_create fails (MRT_ERR_NO_DEVICE).
 #include "renderer.h"
+#include "abi_check.h"
 #include <cstring>
 #include <cstdio>
 #include <memory>
@@ -465,7 +466,7 @@ int mrt_renderer_reset_stats(MRTRenderer r) {
 int mrt_debug_halton(MRTContext ctx, const int32_t *i, const int32_t *d, size_t n, float *out) {
     MRT_TRY
     REQUIRE(ctx && (n == 0 || (i && d && out)), "mrt_debug_halton: bad argument");
-    for (size_t k = 0; k < n; k++) REQUIRE(d[k] >= 0 && d[k] < 100 && i[k] >= 0, "mrt_debug_halton: i >= 0 and 0 <= d < 100 required");
+    for (size_t k = 0; k < n; k++) REQUIRE(d[k] >= 0 && d[k] < 100, "mrt_debug_halton: 0 <= d < 100 required");
     int rc = bind_device(ctx); if (rc) return rc;
     return mrt::probe_halton(ctx->stream, i, d, n, out);
     MRT_CATCH
@@ -485,6 +486,11 @@ int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height
     MRT_CATCH
 }
 
+int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes) {
+    MRT_TRY
+    return mrt::layout_limits(triangles, nodes);
+    MRT_CATCH
+}
 int mrt_debug_calibrate(MRTContext ctx, size_t table_bytes, double *out3) {
     MRT_TRY
     REQUIRE(ctx && out3 && table_bytes >= 4096 && table_bytes <= ((size_t)1 << 34), "mrt_debug_calibrate: bad argument");

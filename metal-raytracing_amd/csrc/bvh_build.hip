@@ -615,6 +615,19 @@ int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceS
     return MRT_OK;
 }
 
+// What the rope layout can address (scene_device.h): a child index is 24 bits wide (k_emit_nodes packs the right child as
+// near-mask << 24 | index, NODE_INDEX_MASK), and traverse.h reaches nodes and packets through ONE 32-bit byte offset from the
+// node base: packet k lives at 64 * (2T - 1) + 48 * k.  `nodes` = surviving node count after the SAH collapse (0 = not known
+// yet: only the triangle-count bound is checked).
+int layout_limits(uint64_t triangles, uint64_t nodes) {
+    if (triangles >= (1ull << 26)) { set_error("scene too large: the builder supports fewer than 2^26 triangles"); return MRT_ERR_UNSUPPORTED; }
+    if (triangles > 0 && 64ull * (2 * triangles - 1) + 48ull * triangles > 0xFFFFFFFFull) {
+        set_error("scene too large: nodes + packets exceed the 32-bit byte offset of the rope traversal (about 24.4 M triangles)"); return MRT_ERR_UNSUPPORTED;
+    }
+    if (nodes > (uint64_t)NODE_INDEX_MASK) { set_error("scene too large: the BVH has more nodes than the 24-bit child index of the rope layout can address"); return MRT_ERR_UNSUPPORTED; }
+    return MRT_OK;
+}
+
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
     // ---- host-side concatenation (one upload per array)
     size_t V = 0, T = 0, NI = 0; int max_sub = 1;
@@ -624,7 +637,8 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
         for (auto &s : m.sub_indices) { T += s.size() / 3; NI += s.size(); }
     }
     const size_t I = meshes.size();
-    if (T >= (1u << 26) || V >= 0xFFFFFFF0ull || I >= 65536 || max_sub >= 65536) { set_error("scene too large (limits: 2^26 triangles, 65535 instances/submeshes)"); return MRT_ERR_UNSUPPORTED; }
+    if (V >= 0xFFFFFFF0ull || I >= 65536 || max_sub >= 65536) { set_error("scene too large (limits: 2^32 - 16 vertices, 65535 instances / submeshes)"); return MRT_ERR_UNSUPPORTED; }
+    if (int rc = layout_limits(T, 0)) return rc;                // before any device work: what no tree of T triangles can satisfy
     std::vector<float> h_pos(std::max<size_t>(V * 3, 3));
     std::vector<float4> h_nrm(std::max<size_t>(V, 1));
     std::vector<uint32_t> h_idx(std::max<size_t>(NI, 3));
@@ -691,8 +705,12 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     MRT_HIP(ntri.alloc(nnodes)); MRT_HIP(size.alloc(nnodes)); MRT_HIP(cost.alloc(nnodes)); MRT_HIP(collapsed.alloc(nnodes)); MRT_HIP(mask.alloc(nnodes));
     MRT_HIP(new_index.alloc(nnodes)); MRT_HIP(leaf_offset.alloc(nnodes)); MRT_HIP(stat.alloc(4));
 
-    hipEvent_t ev0, ev1;
-    MRT_HIP(hipEventCreate(&ev0)); MRT_HIP(hipEventCreate(&ev1));
+    struct EventPair {           // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evs;
+    MRT_HIP(hipEventCreate(&evs.a)); MRT_HIP(hipEventCreate(&evs.b));
+    const hipEvent_t ev0 = evs.a, ev1 = evs.b;
     MRT_HIP(hipMemcpyAsync(d_pos.p, h_pos.data(), h_pos.size() * 4, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(d_idx.p, h_idx.data(), h_idx.size() * 4, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(SubRec), hipMemcpyHostToDevice, stream));
@@ -782,6 +800,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     MRT_HIP(hipMemcpy(&rlo, node_lo.p + root, 16, hipMemcpyDeviceToHost));
     MRT_HIP(hipMemcpy(&rhi, node_hi.p + root, 16, hipMemcpyDeviceToHost));
     MRT_HIP(hipMemcpy(h_stat, stat.p, 16, hipMemcpyDeviceToHost));
+    if (int rc = layout_limits(T, h_size)) return rc;           // the surviving node count must fit the 24-bit child index
     float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
     float area = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.stats.bvh_nodes = h_size;
@@ -828,7 +847,6 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;
     }
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
     return MRT_OK;
 }
 

@@ -46,9 +46,10 @@ static __constant__ short c_primes[100] = {
 //     result equals the bit reversal of i scaled by 2^-32 — two instructions instead of 21 loop trips;
 //   * other bases: q = mulhi(i, M) with M = floor(2^32 / b) + 1 is the exact quotient for i * b_err < 2^32, i.e.
 //     for every i < 2^22 and b <= 541 (error term M*b - 2^32 <= b);
-//   * i >= 2^22 (more than 3 M accumulated frames): the plain loop.
+//   * i >= 2^22 (more than 3 M accumulated frames): the plain loop; i <= 0: 0, as the reference's loop gives.
 // All three produce the same digits, hence the same floats, as the loop in the oracle.
 MRT_DEV float halton_dev(int i, int d) {
+    if (i <= 0) return 0.0f;       // the reference's `while (i > 0)` never runs (Raytracing.metal:46): seed offset + frame index wrapped past 2^31
     if (d == 0 && i < (1 << 24)) return (float)__brev((uint32_t)i) * 2.3283064365386963e-10f;   // exact: <= 24 significant bits
     const int b = c_primes[d];
     const float invB = 1.0f / (float)b;

@@ -1,5 +1,5 @@
 // scene_device.h — HBM data layout of a committed scene, shared by the BVH builder (bvh_build.hip)
-// and the render kernels (render_kernels.hip).  DESIGN.md §4 documents every array.
+// and the render kernels (renderer.hip, traverse.h, traverse_wide.h).  DESIGN.md §4 documents every array.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -122,6 +122,7 @@ struct DeviceScene {
 };
 
 // bvh_build.hip
+int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out);
 

@@ -154,3 +154,17 @@ def test_dragon_scene_definition(mrt):
     assert abs(sc.lights[1].coneAngle - 25 / 180 * math.pi) < 1e-6
     g = np.load(os.path.join(ROOT, "tests", "golden", "dragonscene_setup.npz"))
     assert np.array_equal(np.stack([m.transform for m in sc.meshes]), g["transforms"])
+
+
+def test_layout_limits_reject_scenes_the_traversal_cannot_address(mrt):
+    """mrt_scene_commit's size check (bvh_build.hip layout_limits): the rope layout packs a child index into 24 bits and
+    addresses nodes + packets through one 32-bit byte offset, so a scene beyond either must be refused, not traversed."""
+    L = mrt.lib.mrt_debug_layout_limits
+    OK, UNSUPPORTED = 0, mrt._ffi.MRT_ERR_UNSUPPORTED
+    assert L(0, 0) == OK and L(1, 1) == OK and L(885194, 137314) == OK
+    assert L(1 << 23, 0) == OK                                   # 2n-1 < 2^24 nodes, 176 n < 2^32
+    assert L(24_000_000, (1 << 24) - 1) == OK                    # fits the byte offset; node count is what the collapse leaves
+    assert L(24_000_000, 1 << 24) == UNSUPPORTED                 # one node too many for the 24-bit child index
+    assert L(24_500_000, 0) == UNSUPPORTED                       # 64 (2n-1) + 48 n > 2^32
+    assert L(1 << 26, 0) == UNSUPPORTED
+    assert b"too large" in mrt.lib.mrt_last_error()

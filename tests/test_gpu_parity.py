@@ -45,8 +45,10 @@ def test_device_halton_bit_exact(mrt, orc, gpu_ctx):
     rng = np.random.default_rng(3)
     # the device takes digits two at a time for bases <= 23, one at a time up to i < 2^22, and runs the plain loop beyond
     i = np.concatenate([rng.integers(0, (1 << 20) + 4096, 20000), rng.integers(1 << 20, (1 << 22) + 64, 6000), [(1 << 22) - 2, (1 << 22) - 1, 1 << 22, (1 << 22) + 1, 528, 529, 530, 9 ** 6 - 1, 9 ** 6],
-                        [0, 1, 2, 1048575, (1 << 24) - 1, 1 << 24, (1 << 24) + 12345]]).astype(np.int32)
-    d = rng.integers(0, 22, len(i)).astype(np.int32); d[-8:] = [0, 1, 2, 16, 21, 99, 3, 50]
+                        # non-positive indices (seed offset + frame index wrapped past 2^31): the reference's `while (i > 0)` gives 0
+                        [-1, -2, -(1 << 20), -(1 << 31), 0, (1 << 31) - 1, (1 << 31) - 2, 1 << 30],
+                        [0, 1, 2, 1048575, (1 << 24) - 1, 1 << 24, (1 << 24) + 12345]]).astype(np.int64).astype(np.int32)
+    d = rng.integers(0, 22, len(i)).astype(np.int32); d[-8:] = [0, 1, 2, 16, 21, 99, 3, 50]; d[-16:-8] = [0, 1, 5, 21, 0, 0, 7, 2]
     out = np.zeros(len(i), np.float32)
     mrt._ffi.check(mrt.lib.mrt_debug_halton(gpu_ctx.handle, mrt._ffi.ptr(i), mrt._ffi.ptr(d), len(i), mrt._ffi.ptr(out)))
     ref = np.array([orc.halton(int(a), int(b)) for a, b in zip(i, d)], np.float32)
