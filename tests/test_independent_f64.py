@@ -1,0 +1,96 @@
+"""The CPU oracle against an INDEPENDENT float64 formulation (tests/f64_reference.py): plane intersection + Gram-system
+barycentrics over all triangles instead of the oracle's fused fp32 Möller–Trumbore / BVH, numpy transcendental functions,
+exact-digit Halton.  Tolerances, not bits: the two sides share no arithmetic.
+
+This tightens the oracle's pin as far as the environment allows (VERDICT r1 "weak 1"); parity against the Metal renderer
+itself stays UNPINNED — the reference has no fixtures and cannot run here."""
+import numpy as np
+import pytest
+
+import f64_reference as F
+
+
+def _random_rays(rng, n, lo, hi):
+    c, r = (lo + hi) / 2, np.linalg.norm(hi - lo) / 2 + 1e-3
+    o = c + rng.normal(size=(n, 3)) * r * 1.5
+    t = lo + rng.random((n, 3)) * (hi - lo)
+    d = t - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = o; rays[:, 4:7] = d; rays[:, 7] = np.inf
+    return rays
+
+
+@pytest.mark.parametrize("name", ["plane", "plane-back", "sphere", "train", "treefir", "teapot"])
+def test_oracle_intersector_matches_float64_plane_formulation(orc, mrt, name):
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            self.models = [mrt.Model(name=name, position=[0.1, -0.2, 0.3], rotation=[0.2, 0.5, -0.1], scale=1.3)]
+    sc = S((8, 8))
+    flat = mrt.flatten_scene(sc)
+    osc = orc.OracleScene(flat, sc.lights)
+    tris = F.Triangles(flat)
+    assert len(tris) == osc.triangles
+    w = np.concatenate([tris.v0, tris.v1, tris.v2])
+    rays = _random_rays(np.random.default_rng(11), 600 if name != "teapot" else 250, w.min(0), w.max(0))
+    o, d = rays[:, 0:3].astype(np.float64), rays[:, 4:7].astype(np.float64)
+    t, u, v, ti, t2 = tris.intersect(o, d, np.full(len(o), np.inf))
+    for brute in (True, False):
+        h = osc.intersect_closest(rays, brute=brute)
+        hit64 = ti >= 0
+        # a ray is "decided" when it is clear of triangle edges and of a second surface at the same distance
+        edge = np.where(hit64, np.minimum(np.minimum(u, v), 1 - u - v), 1.0)
+        with np.errstate(invalid="ignore"):
+            sep = np.where(hit64, (t2 - t) / np.maximum(t, 1e-9), 1.0)
+        decided = (edge > 1e-4) & (sep > 1e-4)
+        assert decided.mean() > 0.9
+        # misses in float64 that graze an edge may be hits in fp32 and vice versa: only decided rays must agree on hit / miss
+        agree = (h["type"] == 1) == hit64
+        assert agree[decided].all(), f"{(~agree & decided).sum()} decided rays disagree on hit/miss"
+        assert agree.mean() > 0.995
+        m = decided & hit64
+        assert m.sum() > 20
+        assert np.allclose(h["distance"][m], t[m], rtol=2e-5, atol=1e-6)
+        assert np.abs(h["u"][m] - u[m]).max() < 5e-4 and np.abs(h["v"][m] - v[m]).max() < 5e-4
+        ids = tris.ids[ti[m]]
+        assert np.array_equal(h["instance_id"][m], ids[:, 0]) and np.array_equal(h["geometry_id"][m], ids[:, 1]) and np.array_equal(h["primitive_id"][m], ids[:, 2])
+    # any-hit with a finite tmax
+    rays[:, 7] = 2.0
+    t, u, v, ti, t2 = tris.intersect(o, d, np.full(len(o), 2.0))
+    a = osc.intersect_any(rays, brute=True)
+    edge = np.where(ti >= 0, np.minimum(np.minimum(u, v), 1 - u - v), 1.0)
+    near_tmax = np.abs(t - 2.0) < 1e-4
+    ok = (edge > 1e-4) & ~near_tmax
+    # any-hit is a boolean over ALL triangles: a grazing hit elsewhere may flip it, so allow a few
+    assert ((a == 1) == (ti >= 0))[ok].mean() > 0.995
+
+
+def test_oracle_image_matches_float64_restatement_on_a_cornell_crop(orc, mrt):
+    """trace_pixel in float64 (brute force over all 4 910 triangles) for a 16x16 block of the 64x64 Cornell frame,
+    two accumulated frames, against the oracle's fp32 image."""
+    W = H = 64
+    sc = mrt.CornellScene((W, H))
+    flat = mrt.flatten_scene(sc)
+    osc = orc.OracleScene(flat, sc.lights)
+    r = orc.OracleRenderer(osc, W, H, seed=1, max_bounces=3, camera=sc.camera)
+    r.render(1); img0 = r.accumulation().copy()
+    r.render(1); img1 = r.accumulation().copy()
+    tris = F.Triangles(flat)
+    seeds = np.array([orc.seed_hash(1, i) for i in range(W * H)], np.int64).reshape(H, W)
+    assert seeds.max() < (1 << 20)
+    pix = [(x, y) for y in range(20, 36) for x in range(24, 40)]       # covers the sphere's silhouette, its shadow and the floor
+    f0, m0 = F.render_frame(tris, sc.lights, sc.camera, W, H, seeds, 0, pix)
+    f1, m1 = F.render_frame(tris, sc.lights, sc.camera, W, H, seeds, 1, pix)
+    ref0 = f0
+    ref1 = (f1 + f0 * 1.0) / 2.0                                       # Raytracing.metal:394-401 with frameIndex = 1
+    ys, xs = np.array([p[1] for p in pix]), np.array([p[0] for p in pix])
+    for img, ref, margin in ((img0, ref0, m0), (img1, ref1, np.minimum(m0, m1))):
+        got = img[ys, xs, :3].astype(np.float64)
+        assert np.all(img[ys, xs, 3] == 1.0)
+        d = np.abs(got - ref).max(1)
+        safe = margin > 1e-3                                           # paths that stayed clear of every discrete decision boundary
+        assert safe.mean() > 0.7
+        # measured: max 2.5e-6 over all 256 pixels, median 7e-8 (fp32 rounding of radiance values up to 3.4)
+        assert (d[safe] <= 2e-5).mean() >= 0.97, f"{(d[safe] > 2e-5).sum()} of {safe.sum()} safe pixels differ by more than 2e-5 (max {d[safe].max():.3g})"
+        assert np.median(d) < 1e-6
+        assert ref.max() > 0.5 and (ref.sum(1) > 0).mean() > 0.5       # the crop is lit: the comparison is not vacuous
