@@ -254,10 +254,11 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
 /* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of
  * `triangles` triangles whose BVH keeps `nodes` nodes (0 = unknown) cannot be addressed by the traversal layouts.      */
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes);
-/* Calibration of the ceilings the render kernels are priced against (bench.py): out4 = {wave64 VALU instructions/s with
- * 8 waves per SIMD, the same with one wave per SIMD, bytes/s of divergent 16-byte gathers from a table of about
- * table_bytes, bytes/s of divergent 80-byte records (the wide-node fetch) from such a table}.                          */
-int mrt_debug_calibrate(MRTContext ctx, size_t table_bytes, double *out4);
+/* Calibration of the ceilings the render kernels are priced against (bench.py): out5 = {wave64 v_fma_f32 instructions/s
+ * with every SIMD holding 8 waves, the same for v_pk_fma_f32, bytes/s of divergent 16-byte gathers from a table of about
+ * table_bytes, bytes/s of divergent 80-byte records (the wide-node fetch) from such a table, the shader clock in Hz
+ * observed during the v_fma_f32 loop}.                                                                                 */
+int mrt_debug_calibrate(MRTContext ctx, size_t table_bytes, double *out5);
 
 #ifdef __cplusplus
 }

@@ -367,8 +367,9 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= 19, "max_bounces must be in [1,19]"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
-    else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,8]"); r->r.frame_batch = (int)value; }
+    else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
+    else if (k == "shade_priority") r->r.shade_priority = value != 0;
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
@@ -387,6 +388,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
     else if (k == "frame_batch") *value = r->r.frame_batch;
     else if (k == "fused") *value = r->r.fused ? 1 : 0;
+    else if (k == "shade_priority") *value = r->r.shade_priority ? 1 : 0;
     else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
     else if (k == "wide_stream") *value = r->r.wide_stream ? 1 : 0;
     else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;

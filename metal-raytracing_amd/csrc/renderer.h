@@ -14,13 +14,15 @@ struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
 // waves are covered by the next pass's bulk); only the accumulate step is ordered pass to pass, by an event.
 struct FrameLane {
     hipStream_t stream = nullptr;
+    hipStream_t hi = nullptr;            // high-priority companion stream (option shade_priority): k_shade / k_accumulate jump the dispatch queue
+    hipEvent_t ev_x = nullptr;           // hand-over between the two streams
     hipEvent_t accumulated = nullptr;    // recorded after this lane's k_accumulate
     DevBuf<float4> sample;               // [sub-frame][pixel] radiance of the batch's frames
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
-constexpr int MAX_FRAME_BATCH = 8;
+constexpr int MAX_FRAME_BATCH = 32;
 
 struct Renderer {
     hipStream_t stream = nullptr;
@@ -44,6 +46,7 @@ struct Renderer {
     int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
+    bool shade_priority = false;         // experiment: shade + accumulate on a high-priority stream per lane
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel

@@ -568,6 +568,8 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &e : ev_ext) { MRT_HIP(hipEventCreate(&e.a)); MRT_HIP(hipEventCreate(&e.b)); }
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        { int lo = 0, hi = 0; MRT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); MRT_HIP(hipStreamCreateWithPriority(&L.hi, hipStreamNonBlocking, hi)); }
+        MRT_HIP(hipEventCreateWithFlags(&L.ev_x, hipEventDisableTiming));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
         MRT_HIP(L.bounce_counts.alloc(32));
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
@@ -584,6 +586,8 @@ Renderer::~Renderer() {
     for (auto &e : ev_ext) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
     for (auto &L : lanes) {
         if (L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
+        if (L.hi) { (void)hipStreamSynchronize(L.hi); (void)hipStreamDestroy(L.hi); }
+        if (L.ev_x) (void)hipEventDestroy(L.ev_x);
         if (L.accumulated) (void)hipEventDestroy(L.accumulated);
     }
 }
@@ -719,8 +723,11 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                const hipStream_t ss = shade_priority ? L.hi : st;
+                if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, st)); MRT_HIP(hipStreamWaitEvent(ss, L.ev_x, 0)); }
+                hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
+                if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, ss)); MRT_HIP(hipStreamWaitEvent(st, L.ev_x, 0)); }
                 if (on_wide && wide_stream) {
                     launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
