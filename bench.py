@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "dragon4", "garden"])
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_irregular", "cornell", "dragon4", "garden"])
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--shard", default="sample", choices=["tile", "sample"], help="N > 1: sample-index sharding (weak scaling, default) or 8x8 screen-tile sharding (strong scaling)")
     ap.add_argument("--builder", type=int, default=None)

@@ -277,6 +277,15 @@ int mrt_dragon_proxy(MRTMeshData *out) {
     return MRT_OK;
     MRT_CATCH
 }
+int mrt_dragon_proxy_irregular(MRTMeshData *out) {
+    MRT_TRY
+    REQUIRE(out, "mrt_dragon_proxy_irregular: out is NULL");
+    std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
+    mrt::make_dragon_proxy_irregular(m->m);
+    *out = m.release();
+    return MRT_OK;
+    MRT_CATCH
+}
 int mrt_bunny_proxy(MRTMeshData *out) {
     MRT_TRY
     REQUIRE(out, "mrt_bunny_proxy: out is NULL");

@@ -337,6 +337,112 @@ void make_dragon_proxy(MeshData &out) {
     finish(pm, half, "Dragon", mat, out);
 }
 
+// Second dragon stand-in with IRREGULAR connectivity (sensitivity check for the benchmark geometry: the tube proxy above is a
+// regular grid of near-square quads).  An assembly of subdivided, noise-displaced, tangentially jittered icospheres (plus a few
+// small closed solids that make the count exact) laid along the same spine, inside the same extents, with the same material:
+//   2 x 327 680 + 2 x 81 920 + 2 x 20 480 + 2 x 5 120 + 3 x 320 + 2 x 20 + 8 + 6 = 871 414 triangles.
+// Triangle sizes vary by more than 10x across a blob (a nonlinear warp of the sphere before projection), vertices are jittered
+// along the surface by up to 0.3 edge lengths, and both the vertex numbering and the triangle order are shuffled.
+namespace {
+struct Rng { uint64_t s; uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); } double uni() { return next() / 2147483648.0; } };
+
+static void icosphere(int level, std::vector<P3> &v, std::vector<uint32_t> &f) {
+    const double t = (1.0 + sqrt(5.0)) / 2.0;
+    const double base[12][3] = {{-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t}, {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1}};
+    const int faces[20][3] = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4}, {11, 10, 2}, {10, 7, 6}, {7, 1, 8},
+                              {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8}, {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+    v.clear(); f.clear();
+    for (auto &b : base) v.push_back(normd(P3{b[0], b[1], b[2]}));
+    for (auto &t3 : faces) { f.push_back(t3[0]); f.push_back(t3[1]); f.push_back(t3[2]); }
+    for (int l = 0; l < level; l++) {
+        std::unordered_map<uint64_t, uint32_t> mid;
+        mid.reserve(f.size());
+        auto midpoint = [&](uint32_t a, uint32_t b) -> uint32_t {
+            const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+            auto it = mid.find(key);
+            if (it != mid.end()) return it->second;
+            v.push_back(normd((v[a] + v[b]) * 0.5));
+            return mid[key] = (uint32_t)v.size() - 1;
+        };
+        std::vector<uint32_t> g; g.reserve(f.size() * 4);
+        for (size_t k = 0; k < f.size(); k += 3) {
+            const uint32_t a = f[k], b = f[k + 1], c = f[k + 2], ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+            const uint32_t q[12] = {a, ab, ca, b, bc, ab, c, ca, bc, ab, bc, ca};
+            g.insert(g.end(), q, q + 12);
+        }
+        f.swap(g);
+    }
+}
+}  // namespace
+
+void make_dragon_proxy_irregular(MeshData &out) {
+    const double PI = 3.14159265358979323846;
+    ProcMesh pm;
+    pm.v.reserve(440000); pm.idx.reserve(871414 * 3);
+    Rng rng{0x9E3779B97F4A7C15ull};
+    auto spine = [&](double s) -> P3 {
+        double x = -1.0 + 2.0 * s;
+        return P3{x, 0.18 * sin(2.2 * PI * s + 0.4) + 0.55 * s * s * s - 0.05, 0.22 * sin(3.0 * PI * s) * (1.0 - 0.5 * s)};
+    };
+    std::vector<P3> sv; std::vector<uint32_t> sf;
+    // one blob: unit directions -> nonlinear warp (uneven triangle sizes) -> ellipsoid radii * (1 + noise) -> tangential jitter
+    auto blob = [&](int level, P3 c, P3 radii, double warp, double bump, double freq) {
+        icosphere(level, sv, sf);
+        const double edge = 1.2 / (double)(1 << level);                       // ~ edge length on the unit sphere
+        const uint32_t base = (uint32_t)pm.v.size();
+        for (auto &d0 : sv) {
+            P3 d = normd(P3{d0.x + warp * d0.x * d0.x * d0.x + 0.35 * warp * d0.y * d0.z, d0.y + warp * d0.y * fabs(d0.y) * 0.8, d0.z + 0.6 * warp * d0.z * d0.x});
+            const P3 j = P3{rng.uni() - 0.5, rng.uni() - 0.5, rng.uni() - 0.5} * (0.35 * edge);
+            d = normd(d + j);                                                  // jitter along the surface (renormalised)
+            const double n = sin(freq * d.x + 1.3) * sin(freq * 1.31 * d.y + 0.2) * sin(freq * 0.83 * d.z + 2.1) + 0.5 * sin(2.7 * freq * d.x * d.y + 3.0 * d.z);
+            const double r = 1.0 + bump * n;
+            pm.add(P3{c.x + radii.x * r * d.x, c.y + radii.y * r * d.y, c.z + radii.z * r * d.z});
+        }
+        for (size_t k = 0; k < sf.size(); k += 3) pm.tri(base + sf[k], base + sf[k + 1], base + sf[k + 2]);
+    };
+    blob(7, spine(0.30), P3{0.42, 0.30, 0.26}, 0.55, 0.10, 9.0);                // chest
+    blob(7, spine(0.62), P3{0.40, 0.26, 0.24}, 0.45, 0.12, 11.0);               // belly / hind
+    blob(6, spine(0.93), P3{0.16, 0.14, 0.12}, 0.50, 0.08, 7.0);                // head
+    blob(6, spine(0.08), P3{0.20, 0.08, 0.07}, 0.60, 0.10, 6.0);                // tail
+    for (int l = 0; l < 2; l++) { P3 r = spine(0.30); blob(5, P3{r.x + 0.05, r.y - 0.42, r.z + (l ? 0.22 : -0.22)}, P3{0.07, 0.26, 0.07}, 0.40, 0.06, 5.0); }   // fore legs
+    for (int l = 0; l < 2; l++) { P3 r = spine(0.62); blob(4, P3{r.x - 0.03, r.y - 0.40, r.z + (l ? 0.20 : -0.20)}, P3{0.07, 0.24, 0.07}, 0.40, 0.06, 5.0); }   // hind legs
+    for (int k = 0; k < 3; k++) { P3 r = spine(0.35 + 0.2 * k); blob(2, P3{r.x, r.y + 0.34, r.z}, P3{0.03, 0.09, 0.03}, 0.2, 0.0, 1.0); }                        // dorsal spikes
+    for (int k = 0; k < 2; k++) { P3 r = spine(0.96); blob(0, P3{r.x - 0.02, r.y + 0.17, r.z + (k ? 0.05 : -0.05)}, P3{0.02, 0.08, 0.02}, 0.0, 0.0, 1.0); }     // horns
+    {   // an octahedron (8) and a triangular bipyramid (6) make the count exact
+        P3 c = spine(0.995); c.x += 0.05;
+        uint32_t o[6]; const double e = 0.02;
+        const P3 ov[6] = {{e, 0, 0}, {-e, 0, 0}, {0, e, 0}, {0, -e, 0}, {0, 0, e}, {0, 0, -e}};
+        for (int k = 0; k < 6; k++) o[k] = pm.add(c + ov[k]);
+        const int of[8][3] = {{0, 2, 4}, {2, 1, 4}, {1, 3, 4}, {3, 0, 4}, {2, 0, 5}, {1, 2, 5}, {3, 1, 5}, {0, 3, 5}};
+        for (auto &t3 : of) pm.tri(o[t3[0]], o[t3[1]], o[t3[2]]);
+        P3 c2 = spine(0.0); c2.x -= 0.04;
+        uint32_t b[5];
+        for (int k = 0; k < 3; k++) b[k] = pm.add(P3{c2.x, c2.y + e * cos(2 * PI * k / 3), c2.z + e * sin(2 * PI * k / 3)});
+        b[3] = pm.add(P3{c2.x - 2 * e, c2.y, c2.z}); b[4] = pm.add(P3{c2.x + 2 * e, c2.y, c2.z});
+        for (int k = 0; k < 3; k++) { pm.tri(b[k], b[(k + 1) % 3], b[4]); pm.tri(b[(k + 1) % 3], b[k], b[3]); }
+    }
+    // shuffle the vertex numbering and the triangle order (Fisher-Yates, fixed seed)
+    {
+        const uint32_t nv = (uint32_t)pm.v.size(); const size_t nt = pm.idx.size() / 3;
+        std::vector<uint32_t> perm(nv);
+        for (uint32_t i = 0; i < nv; i++) perm[i] = i;
+        for (uint32_t i = nv - 1; i > 0; i--) std::swap(perm[i], perm[rng.next() % (i + 1)]);
+        std::vector<P3> nvv(nv);
+        for (uint32_t i = 0; i < nv; i++) nvv[perm[i]] = pm.v[i];
+        pm.v.swap(nvv);
+        for (auto &ix : pm.idx) ix = perm[ix];
+        for (size_t i = nt - 1; i > 0; i--) {
+            const size_t j = rng.next() % (i + 1);
+            for (int k = 0; k < 3; k++) std::swap(pm.idx[3 * i + k], pm.idx[3 * j + k]);
+        }
+    }
+    MRTMaterial mat; memset(&mat, 0, sizeof mat);                 // Resources/dragon.mtl, as make_dragon_proxy
+    mat.baseColor = MRTFloat3{1.0f, 0.0f, 0.0f, 0}; mat.specular = MRTFloat3{0.2f, 0.2f, 0.2f, 0};
+    mat.specularExponent = 37.254902f; mat.refractionIndex = 1.0f; mat.dissolve = 1.0f;
+    const double half[3] = {0.45, 0.317, 0.20};
+    finish(pm, half, "Dragon", mat, out);
+}
+
 // Bunny stand-in: 65 792 + 3 264 + 395 = 69 451 triangles (Stanford bunny count).
 void make_bunny_proxy(MeshData &out) {
     const double PI = 3.14159265358979323846;

@@ -568,7 +568,6 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &e : ev_ext) { MRT_HIP(hipEventCreate(&e.a)); MRT_HIP(hipEventCreate(&e.b)); }
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        { int lo = 0, hi = 0; MRT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); MRT_HIP(hipStreamCreateWithPriority(&L.hi, hipStreamNonBlocking, hi)); }
         MRT_HIP(hipEventCreateWithFlags(&L.ev_x, hipEventDisableTiming));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
         MRT_HIP(L.bounce_counts.alloc(32));
@@ -723,6 +722,9 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
+                if (shade_priority && !L.hi) {      // created on demand: every extra stream takes a share of the 16 hardware queues away from the lanes (measured: 28 streams halve the frame rate)
+                    int lo = 0, hi = 0; MRT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); MRT_HIP(hipStreamCreateWithPriority(&L.hi, hipStreamNonBlocking, hi));
+                }
                 const hipStream_t ss = shade_priority ? L.hi : st;
                 if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, st)); MRT_HIP(hipStreamWaitEvent(ss, L.ev_x, 0)); }
                 hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,

@@ -109,6 +109,15 @@ def dragon_proxy():
         lib.mrt_meshdata_free(h)
 
 
+def dragon_proxy_irregular():
+    h = C.c_void_p()
+    check(lib.mrt_dragon_proxy_irregular(C.byref(h)))
+    try:
+        return _meshdata_to_python(h, "dragon-irregular")
+    finally:
+        lib.mrt_meshdata_free(h)
+
+
 def bunny_proxy():
     h = C.c_void_p()
     check(lib.mrt_bunny_proxy(C.byref(h)))
@@ -118,7 +127,7 @@ def bunny_proxy():
         lib.mrt_meshdata_free(h)
 
 
-_PROXIES = {"dragon": dragon_proxy, "bunny": bunny_proxy}
+_PROXIES = {"dragon": dragon_proxy, "dragon-irregular": dragon_proxy_irregular, "bunny": bunny_proxy}
 _mesh_cache = {}
 
 
@@ -199,6 +208,17 @@ class DragonScene(Scene):
         ]
 
 
+class IrregularDragonScene(DragonScene):
+    """DragonScene with the second dragon stand-in (irregular connectivity, uneven triangle sizes, shuffled order): the headline
+    number must not be a property of the regular tube grid of the first stand-in (assets/README.md)."""
+
+    def __init__(self, size):
+        super().__init__(size)
+        d = self.models[1]
+        assert d.name == "dragon"
+        self.models[1] = Model(name="dragon-irregular", position=d.position, rotation=d.rotation, scale=d.scale)
+
+
 class CornellScene(Scene):
     """BASELINE.json configs[0]: plane.obj x5 + sphere.obj, one area light.  Not a
     reference scene — built from reference assets for the CPU-runnable plumbing case."""
@@ -254,7 +274,7 @@ class GardenScene(Scene):
         ]
 
 
-SCENES = {"dragon": DragonScene, "cornell": CornellScene, "dragon4": InstancedDragonScene, "garden": GardenScene}
+SCENES = {"dragon": DragonScene, "dragon_irregular": IrregularDragonScene, "cornell": CornellScene, "dragon4": InstancedDragonScene, "garden": GardenScene}
 
 
 def flatten_scene(scene):

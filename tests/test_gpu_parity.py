@@ -399,7 +399,7 @@ def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     with pytest.raises(mrt.MRTError):
-        r.set_option("frame_batch", 9)
+        r.set_option("frame_batch", 33)
     r.close()
 
 
