@@ -379,6 +379,9 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
     else if (k == "fused") r->r.fused = value != 0;
     else if (k == "shade_priority") r->r.shade_priority = value != 0;
+    else if (k == "persistent") r->r.persistent = value != 0;
+    else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
+    else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
@@ -398,6 +401,9 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "frame_batch") *value = r->r.frame_batch;
     else if (k == "fused") *value = r->r.fused ? 1 : 0;
     else if (k == "shade_priority") *value = r->r.shade_priority ? 1 : 0;
+    else if (k == "persistent") *value = r->r.persistent ? 1 : 0;
+    else if (k == "persist_chunk") *value = r->r.persist_chunk;
+    else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
     else if (k == "wide_stream") *value = r->r.wide_stream ? 1 : 0;
     else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;

@@ -50,6 +50,11 @@ struct Renderer {
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
+    bool persistent = true;              // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter
+    int persist_chunk = 512;             // rays per pull
+    int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
+    bool wave_slots_user = false;        // set through the option: keep it
+    size_t slots_for_stack = ~(size_t)0;
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)

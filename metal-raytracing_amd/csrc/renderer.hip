@@ -240,8 +240,31 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    traverse_wide_stream(s, begin, min(n, begin + rays_per_wave), stk_dyn,
+    traverse_wide_stream(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
+        },
+        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) {
+                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+            } else {
+                hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+            }
+        });
+}
+
+// Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
+// `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
+__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk) {
+    extern __shared__ uint32_t stk_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
+    traverse_wide_stream(s, SharedCounter{work, n, chunk}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
         },
@@ -261,7 +284,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
     hits += (size_t)sub * capacity; dirs += (size_t)sub * capacity;
-    traverse_wide_stream(s, begin, min(capacity, begin + rays_per_wave), stk_dyn,
+    traverse_wide_stream(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
@@ -435,6 +458,7 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
             if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
             shadow += c >> 32;
             bounce_counts[b] = 0;
+            bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
     }
@@ -525,7 +549,7 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     const uint32_t end = min(n, begin + per_wave);
     StreamStats ss{0, 0, 0, 0, 0, 0};
     uint32_t sink = 0;
-    traverse_wide_stream(s, begin, end, stk_dyn,
+    traverse_wide_stream(s, OneRange{begin, end}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
             A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
@@ -570,7 +594,7 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.ev_x, hipEventDisableTiming));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
-        MRT_HIP(L.bounce_counts.alloc(32));
+        MRT_HIP(L.bounce_counts.alloc(64));       // [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -707,6 +731,13 @@ int Renderer::render(int n_frames) {                                   // Render
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
+            if (on_wide && persistent && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
+                int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+                MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
+                MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist, 64, stack_bytes));
+                if (!wave_slots_user) wave_slots = std::max(1, per_cu) * prop.multiProcessorCount;
+                slots_for_stack = stack_bytes;
+            }
             // traversal launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the
             // same clock rocprofv3 reads): plain hipEventRecord pairs on a stream also count the time a launch waits behind the
             // other frames in flight (+12 % at 12 frames)
@@ -730,7 +761,13 @@ int Renderer::render(int n_frames) {                                   // Render
                 hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, ss)); MRT_HIP(hipStreamWaitEvent(st, L.ev_x, 0)); }
-                if (on_wide && wide_stream) {
+                if (on_wide && wide_stream && persistent) {
+                    const size_t slots = 2 * (size_t)capacity * B;
+                    const uint32_t waves = (uint32_t)std::min<size_t>(cdiv(slots, persist_chunk), (size_t)wave_slots);
+                    launch_timed(timed(), k_trace_mixed_wide_persist, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), (uint32_t)persist_chunk);
+                }
+                else if (on_wide && wide_stream) {
                     launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }

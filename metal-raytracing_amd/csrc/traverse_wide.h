@@ -175,14 +175,37 @@ constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 struct StreamStats { uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes; };
 
-template <class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t end, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr) {
+// A wave's supply of rays: consecutive chunks [b, e) of the queue.  `next(b, e)` is called by the whole wave (wave-uniform
+// result) when the current chunk is used up and returns false when there is nothing left.
+struct OneRange {            // the static split: the wave owns one range
+    uint32_t b, e; bool used = false;
+    MRT_DEV bool operator()(uint32_t &ob, uint32_t &oe) { if (used) return false; used = true; ob = b; oe = e; return b < e; }
+};
+// The dynamic split ("persistent waves"): every resident wave keeps pulling `chunk` rays from a shared counter until the queue is
+// empty, so all waves of a launch end within one chunk of each other instead of the last round of a static grid running on a
+// half-empty chip (rocprofv3, serialised 4-frame launches: 16 K static waves of 1024 rays on 7 168 wave slots held 47 % of them
+// on average).  One returning atomic per chunk: a counter word sustains ~88 of them per microsecond (MI355X_MICROARCH.md "dequeue").
+struct SharedCounter {
+    uint32_t *counter; uint32_t n, chunk;
+    MRT_DEV bool operator()(uint32_t &ob, uint32_t &oe) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, chunk);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) return false;
+        ob = base; oe = min(n, base + chunk);
+        return true;
+    }
+};
+
+template <class Chunks, class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // prefetched batch: ray (batch_base + lane); pB.w = tag | any-hit flag << 31
+    // prefetched batch: rays batch_base .. batch_base + batch_n - 1, one per lane; pB.w = tag | any-hit flag << 31
     float4 pA = make_float4(0, 0, 0, 0), pB = pA;
-    uint32_t batch_base = begin, batch_used = 64;     // wave-uniform; used == 64 -> nothing prefetched
-    uint32_t next_batch = begin;
+    uint32_t batch_n = 0, batch_used = 0;             // wave-uniform; used == n -> nothing prefetched
+    uint32_t cur = 0, end = 0;                        // unfetched part of the current chunk
+    bool more = true;                                 // the chunk source may have more
     // live ray
     bool live = false, unreported = false;            // unreported: the lane's ray is finished, its result not yet emitted
     uint32_t tagw = 0;                                // tag | any-hit flag << 31
@@ -205,16 +228,17 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, uint32_t begin, uint32_t e
                 }
                 emit(tagw & 0x7FFFFFFFu, was_any, was_hit, h); unreported = false;
             }
-            if (batch_used >= 64 && next_batch < end) {        // prefetch the next 64 rays (coalesced), all lanes
-                batch_base = next_batch; next_batch += 64; batch_used = 0;
-                const uint32_t i = batch_base + lane;
-                if (i < end) {
+            if (batch_used >= batch_n) {                        // prefetch the next (up to) 64 rays (coalesced), all lanes
+                if (cur >= end && more) more = next_chunk(cur, end);
+                batch_n = cur < end ? min(64u, end - cur) : 0u; batch_used = 0;
+                if (lane < batch_n) {
                     uint32_t tag = 0, is_any = 0;
-                    fetch(i, pA, pB, tag, is_any);
+                    fetch(cur + lane, pA, pB, tag, is_any);
                     pB.w = __uint_as_float((tag & 0x7FFFFFFFu) | (is_any << 31));
                 }
+                cur += batch_n;
             }
-            const uint32_t avail = batch_used < 64 ? min(64u - batch_used, end > batch_base + batch_used ? end - (batch_base + batch_used) : 0u) : 0u;
+            const uint32_t avail = batch_n - batch_used;
             if (avail == 0) { if (m_idle == ~0ull) break; }
             else {
                 const uint32_t rank = (uint32_t)__popcll(m_idle & lt);
