@@ -5,23 +5,33 @@ DragonScene 1920x1080 spp=1 (configs[1]).
 A "step" is one frame (one pass of the hot path over all pixels at 1 spp): primary rays, then per bounce
 shade / trace (closest hit for the bounce rays + any hit for the shadow rays), then accumulate —
 `Renderer.draw(in:)` of the reference (Renderer.swift:284-351).  Inputs (scene, BVH, seeds) are resident in HBM
-before the timed region.  The renderer carries the K steps in batches of `frame_batch` frames on
+before the timed region.  The renderer carries the K steps in passes of `frame_batch` frames on
 `frames_in_flight` HIP streams (the reference keeps 3 frames in flight, Renderer.swift:33); every frame is
 rendered in full and the running average is applied in frame order.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU, scene + BVH replicated.  Default `--shard sample`: every rank renders full frames of a
-disjoint Halton index range (per-GPU work fixed → "weak" scaling); `--shard tile`: the image is sharded by 8x8
-screen tile (tile_id % N == rank, total work fixed → "strong").  Either way the K frames are accumulated locally and
-ONE RCCL reduce of the RGBA32F radiance buffer assembles the image on rank 0 inside the timed region.
+N > 1: one process per GPU, scene + BVH replicated.  Default `--shard tile` (BASELINE.json north_star): the image is
+sharded by 8x8 screen tile (tile_id % N == rank, total work fixed -> "strong" scaling); `--shard sample`: every rank
+renders full frames of a disjoint Halton index range (per-GPU work fixed -> "weak").  Either way the K frames are
+accumulated locally and ONE RCCL reduce of the RGBA32F radiance buffer assembles the image on rank 0 inside the timed
+region.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the driver's keys:
+  roofline        dominant kernel (bounce + shadow traversal) of the TIMED region: algorithmic bytes per launch / its average
+                  launch duration (the kernel's own start/stop events on its launching stream) against HBM 8 TB/s; `frame` is
+                  SURVEY §8(d)'s frame-level figure bytes_alg / t_frame.
+  latency         SURVEY §8(d)'s ms/frame: device time of all kernels of ONE frame (frames_in_flight = 1, frame_batch = 1,
+                  median of 24), the serialised per-kernel times, and the reference's own mode (3 frames in flight).
+  valu_issue      what actually bounds the frame: wave64 VALU instructions per frame (committed SQ_INSTS_VALU pass) against
+                  the v_fma_f32 issue rate CALIBRATED on this chip in this run (mrt_debug_calibrate).
+  cpu_baseline    the CPU oracle on the host cores, one full frame (reported, not the target).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -42,46 +52,51 @@ BYTES_PER_SHADOW_RAY = 72
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)
-    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_irregular", "cornell", "dragon4", "garden"])
     ap.add_argument("--bounces", type=int, default=3)
-    ap.add_argument("--shard", default="sample", choices=["tile", "sample"], help="N > 1: sample-index sharding (weak scaling, default) or 8x8 screen-tile sharding (strong scaling)")
+    ap.add_argument("--shard", default="tile", choices=["tile", "sample"], help="N > 1: 8x8 screen-tile sharding (north_star, strong scaling, default) or sample-index sharding (weak scaling)")
     ap.add_argument("--builder", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
     ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=None, help="Renderer.maxFramesInFlight (default 3)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 12; the reference keeps 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra max_bounces=1 (primary + shadow only) measurement")
+    ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
+    ap.add_argument("--dump-accum", default=None, help="write the assembled RGBA32F accumulation buffer (warm-up + timed frames) here as .npy (rank 0)")
     return ap.parse_args()
 
 
-def measured_traffic():
-    """HBM bytes per traversal launch (call-weighted over k_trace_*) from the rocprofv3 PMC passes kept under profiles/ (tools/collect_profiles.sh:
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
-    gfx950; gather widths are uncalibrated, so this is an upper estimate).  None if no profile is present."""
+def committed_profile():
+    """Per-dispatch HBM bytes of the dominant kernel and VALU instructions per frame from the rocprofv3 PMC passes kept under
+    profiles/ (tools/collect_profiles.sh; FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950; gather widths uncalibrated, so an upper estimate).  {} if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
-        return None, None, None, None
+        return {}
     try:
         d = json.load(open(files[-1]))
-        return d["trace_launch_hbm_bytes"], os.path.relpath(files[-1], ROOT), d.get("trace_launch_avg_us"), d.get("valu_wave_insts_per_frame")
+        d["_source"] = os.path.relpath(files[-1], ROOT)
+        return d
     except Exception:
-        return None, None, None, None
+        return {}
 
 
 def cpu_baseline(mrt, scene, w, h, bounces, threads):
     """The oracle (CPU restatement, kind 'port') on the GPU box's host cores: one full frame of the
-    same workload, same seeds.  Reported, never the thing shipped."""
+    same workload, same seeds.  Reported, never the thing shipped.  (SURVEY §8(d) asks for -O3 -march=native on all cores;
+    the oracle is built -O2 -march=x86-64-v3 so that one binary runs on every box, and uses min(nproc, 16) threads — the GPU
+    box's CPU share for one GPU.  It is the stated non-target baseline; nothing rides on the ratio.)"""
     import oracle as O
     O.build_oracle()
-    threads = threads or min(os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU is 16 cores
+    threads = threads or min(os.cpu_count() or 1, 16)
     osc = O.OracleScene(mrt.flatten_scene(scene), scene.lights)
     r = O.OracleRenderer(osc, w, h, seed=1, max_bounces=bounces, camera=scene.camera)
     t0 = time.perf_counter()
@@ -92,6 +107,31 @@ def cpu_baseline(mrt, scene, w, h, bounces, threads):
     return {"value": (closest + shadow) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"1 full frame of the same workload ({w}x{h} spp=1, {bounces} bounces, {closest + shadow} rays) in {dt:.2f} s",
             "ms_per_frame": dt * 1e3}, img
+
+
+def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
+    """SURVEY §8(d) ms/frame: hipEvent time of all kernels of ONE frameIndex.  A second renderer on the same context and scene
+    options, one frame per draw call, nothing else in flight; then the reference's own regime (3 frames in flight, one frame
+    per pass, Renderer.swift:33)."""
+    q = mrt.Renderer((w, h), scene, ctx=r.ctx, seed=1, max_bounces=bounces, scene_options=opts)
+    q.set_option("frames_in_flight", 1); q.set_option("frame_batch", 1)
+    q.draw(3, wait=True)
+    per_frame, per_kernel = [], {}
+    for _ in range(frames):
+        q.draw(1, wait=True)
+        per_frame.append(q.stats.ms_gpu_last)
+        for k, (ms, n) in q.kernel_times.items():
+            if n:
+                per_kernel.setdefault(k, []).append(ms / n)
+    out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames,
+           "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU",
+           "kernel_ms_serialised": {k: round(statistics.median(v), 4) for k, v in per_kernel.items()}}
+    q.set_option("frames_in_flight", 3)
+    q.draw(6, wait=True)
+    t0 = time.perf_counter(); q.draw(30, wait=True); dt = time.perf_counter() - t0
+    out["reference_like_3_in_flight_ms_per_frame"] = round(dt * 1e3 / 30, 4)
+    q.close()
+    return out
 
 
 def main():
@@ -116,25 +156,20 @@ def main():
         sys.exit("launch with torch.distributed.run for --gpus > 1")
 
     import metal_raytracing_amd as mrt
-    from metal_raytracing_amd.distributed import reduce_accumulation
+    from metal_raytracing_amd.distributed import ShardedRenderer
     w, h = a.width, a.height
     scene = mrt.SCENES[a.scene]((w, h))
     opts = {} if a.builder is None else {"builder": a.builder}
     for kv in a.sopt:
         k, v = kv.split("="); opts[k] = float(v)
-    r = mrt.Renderer((w, h), scene, device=local_rank, seed=1, max_bounces=a.bounces, scene_options=opts)
+    sr = ShardedRenderer((w, h), scene, rank, world, mode=a.shard, device=local_rank, frames_total=a.warmup + a.steps,
+                         backend=a.dist_backend if world > 1 else None, seed=1, max_bounces=a.bounces, scene_options=opts)
+    r = sr.renderer
     sst = r.device_scene.stats
     for kv in a.opt:
         k, v = kv.split("="); r.set_option(k, float(v))
     if a.frames_in_flight is not None:
         r.set_option("frames_in_flight", a.frames_in_flight)
-    if world > 1:
-        if a.shard == "tile":
-            r.set_shard(rank, world)
-            if a.frames_in_flight is None:
-                r.set_option("frames_in_flight", 8)     # 1/N of the pixels per frame: more frames in flight to cover the per-kernel tails
-        else:
-            r.set_option("sample_offset", rank * (a.warmup + a.steps))
 
     def sync():
         r.wait()
@@ -142,36 +177,22 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    npix = w * h
-    accum_t = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
-
-    # ---- warmup
-    r.draw(a.warmup, wait=True)
-    def reduce_image():
-        r.copy_accum_to(accum_t.data_ptr(), npix * 16); r.wait()
-        if a.dist_backend == "nccl":
-            reduce_accumulation(accum_t, a.shard, dst=0)      # the ONE collective per output image (RCCL over xGMI)
-        else:
-            host = accum_t.cpu(); reduce_accumulation(host, a.shard, dst=0); accum_t.copy_(host)
+    # ---- warmup (W untimed steps, and one reduce so that the collective's set-up is not timed either)
+    sr.draw(a.warmup); r.wait()
     if world > 1:
-        reduce_image()
+        sr.gather()
     r.reset_stats()
     sync()
     # ---- timed region: exactly K steps (+ the one reduce of the output image for N > 1)
     t0 = time.perf_counter()
-    done = 0
-    ext_ms, ext_launches = 0.0, 0
-    # all K steps are enqueued at once: the renderer carries them in batches of `frame_batch` frames on `frames_in_flight` streams;
-    # its first 512 traversal launches carry start/stop events (the live roofline measurement)
-    r.draw(a.steps)
+    sr.draw(a.steps)                 # all K steps are enqueued at once; the first 512 launches carry their own start/stop events
     r.wait()
-    st = r.stats
-    ext_ms += st.ms_extend_last; ext_launches += st.extend_launches_last
     if world > 1:
-        reduce_image()
+        sr.gather()
     sync()
     dt = time.perf_counter() - t0
     st = r.stats
+    kt = r.kernel_times
     rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
     tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
@@ -185,55 +206,70 @@ def main():
 
     if rank == 0:
         value = (closest + shadow) / dt / 1e6
-        # dominant kernels: the traversal launches (k_trace_primary + k_trace_mixed; k_extend in the unfused pipeline).
-        # Algorithmic bytes per launch = (96 B x closest-hit rays + 72 B x shadow rays) / traversal launches;
-        # the fused launches carry both kinds, the unfused k_extend only the 96-B rays.
         fused = r.get_option("fused") != 0 and r.get_option("wide") == 0
         frame_batch = int(r.get_option("frame_batch")) if fused else 1
         passes = (a.steps + frame_batch - 1) // frame_batch              # one pass of the pipeline = frame_batch frames
-        launches_per_frame = (a.bounces + 1 if fused else a.bounces) * passes / a.steps
-        traced_bytes = BYTES_PER_CLOSEST_RAY * st.closest_rays + (BYTES_PER_SHADOW_RAY * st.shadow_rays if fused else 0)
-        bytes_per_launch = traced_bytes / (a.steps * launches_per_frame)
-        rays_per_launch = (st.closest_rays + (st.shadow_rays if fused else 0)) / (a.steps * launches_per_frame)
-        avg_ms = ext_ms / max(1, ext_launches)
+        # dominant kernel: the bounce + shadow traversal (k_trace_mixed_wide_persist): max_bounces launches per pass, each over
+        # [bounce rays of that bounce (closest hit, 96 B) | shadow rays of that bounce (any hit, 72 B)]; the primary rays (96 B each)
+        # belong to k_trace_primary.  This rank's rays (st.*), this rank's launches.
+        trace_launches = a.bounces * passes if fused else a.bounces * a.steps
+        traced_bytes = BYTES_PER_CLOSEST_RAY * (st.closest_rays - st.primary_rays) + (BYTES_PER_SHADOW_RAY * st.shadow_rays if fused else 0)
+        bytes_per_launch = traced_bytes / max(1, trace_launches)
+        rays_per_launch = (st.closest_rays - st.primary_rays + (st.shadow_rays if fused else 0)) / max(1, trace_launches)
+        t_ms, t_n = kt["trace"]
+        avg_ms = t_ms / max(1, t_n)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         frame_bytes = st.bytes_alg / max(1, st.frames)
-        traffic, traffic_src, prof_avg_us, valu_insts = measured_traffic()
+        frame_gbs = frame_bytes * st.frames / dt / 1e9
+        prof = committed_profile()
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak" if a.shard == "sample" else "strong",     # per-GPU work fixed as N grows (sample sharding, the default) vs total work fixed (tile sharding)
+            "scaling": "strong" if a.shard == "tile" else "weak",     # total work fixed as N grows (tile sharding, the default) vs per-GPU work fixed (sample sharding)
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene {w}x{h} spp=1, {a.bounces} bounces, closest-hit + shadow rays counted on device",
                        "scene_sources": scene.describe(), "triangles": int(sst.triangles), "bvh_nodes": int(sst.bvh_nodes),
                        "bvh_build_ms": round(sst.build_ms, 3), "sah_cost": round(sst.sah_cost, 3),
                        "rays_per_frame": {"closest": closest / steps_total, "shadow": shadow / steps_total, "primary": primary / steps_total},
                        "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
-                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")),
-                       "frame_bytes_alg": frame_bytes, "frame_alg_GBps": round(frame_bytes * st.frames / dt / 1e9, 2),
+                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")), "persistent_traversal": int(r.get_option("persistent")),
+                       "ms_per_step_is": "wall time of the timed region / steps with passes of frame_batch frames overlapped on frames_in_flight streams (inverse throughput); the per-frame device time is latency.ms_per_frame",
                        "device": r.ctx.device_name},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_primary+k_trace_mixed" if fused else "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                         "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY, "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
-                         # the live figure spans end-of-previous-command .. end-of-kernel on the launching stream, i.e. it includes the dispatch gap,
-                         # which grows with the frames in flight; the committed rocprofv3 kernel time of the same command:
-                         "avg_launch_ms_rocprof": round(prof_avg_us / 1e3, 4) if prof_avg_us else None,
-                         "launches_timed": ext_launches},
+            "roofline": {"bound": "hbm", "kernel": "k_trace_mixed_wide_persist (bounce + shadow traversal)" if fused else "k_extend",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected"), "traffic_source": prof.get("_source"),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
+                         "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY,
+                         "avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n,
+                         "avg_launch_ms_note": "kernel start/stop events of the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is the duration under overlap (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone; the serialised duration is latency.kernel_ms_serialised.trace",
+                         "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
+                         "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                                   "note": "SURVEY §8(d): (36 B/pixel + 96 B/closest ray + 72 B/shadow ray + one read of the scene) / t_frame"}},
         }
-        if valu_insts and world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3):
-            # what actually bounds the frame: VALU issue.  Wave-instructions per frame from the committed SQ_INSTS_VALU pass
-            # (a property of the workload) over the NOMINAL issue capacity of the timed frame: 256 CUs x 4 SIMDs x one wave64 instruction per
-            # 4 cycles at 2.4 GHz.  The counter also counts instructions that retire early with an empty EXEC mask, so frac can read > 1.
-            VALU_PEAK = 256 * 2.4e9
-            out["valu_issue"] = {"wave_insts_per_frame": round(valu_insts), "achieved_Ginst_per_s": round(valu_insts / (dt / a.steps) / 1e9, 1),
-                                 "nominal_peak_Ginst_per_s": VALU_PEAK / 1e9, "frac": round(valu_insts / (dt / a.steps) / VALU_PEAK, 4), "clock_GHz_assumed": 2.4,
-                                 "source": traffic_src}
+        if a.dump_accum:
+            np.save(a.dump_accum, sr.buffer.cpu().numpy() if world > 1 else r.accumulation())
         if a.png:
             if world > 1:
-                r.write_accum_from(accum_t.data_ptr(), npix * 16)      # show the assembled image, not this rank's shard
+                r.write_accum_from(sr.buffer.data_ptr(), w * h * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
+        single_dragon = world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3)
+        if world == 1:
+            # ceilings calibrated on this chip, now: v_fma_f32 issue rate with every SIMD full, divergent-gather rate from a table of the scene's size
+            import ctypes as C
+            cal = (C.c_double * 5)()
+            mrt._ffi.check(mrt.lib.mrt_debug_calibrate(r.ctx.handle, 128 << 20, cal))
+            out["calibration"] = {"v_fma_f32_Ginst_per_s": round(cal[0] / 1e9, 1), "v_pk_fma_f32_Ginst_per_s": round(cal[1] / 1e9, 1), "shader_clock_GHz_under_fma_load": round(cal[4] / 1e9, 3),
+                                  "gather16_GBps_128MiB_table": round(cal[2] / 1e9, 1), "gather80_GBps_128MiB_table": round(cal[3] / 1e9, 1),
+                                  "note": "only fp32 add/mul/fma and and/or/xor/mov/lshr issue at this rate on gfx950; min/max, conversions, compares, shifts left, bit-field and 24-bit integer ops take ~1.8x as long, rcp/sqrt 3.5x (tools/valu_rates.hip, profiles/r02_valu_rates.json)"}
+            valu = prof.get("valu_wave_insts_per_frame")
+            if valu and single_dragon:
+                rate = valu / (dt / a.steps)
+                out["valu_issue"] = {"wave_insts_per_frame": round(valu), "source": prof.get("_source"), "achieved_Ginst_per_s": round(rate / 1e9, 1),
+                                     "peak_Ginst_per_s_calibrated_v_fma_f32": round(cal[0] / 1e9, 1), "frac": round(rate / cal[0], 4),
+                                     "cycle_weighted_frac": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
+        if world == 1 and not a.no_latency:
+            out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
         if world == 1 and a.bounces > 1 and not a.no_strict:
             # the strict "primary + shadow" figure: the same renderer with max_bounces = 1
             r.set_option("max_bounces", 1); r.frameIndex = 0
@@ -256,7 +292,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    r.close()
+    sr.close()
     if dist is not None:
         dist.destroy_process_group()
 

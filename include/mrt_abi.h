@@ -126,6 +126,18 @@ typedef struct {
     uint32_t _pad;
 } MRTRenderStats;
 
+/* Device time per kernel class over the launches of the last mrt_renderer_render call that carried their own start/stop
+ * events (the first 512 launches; hipExtLaunchKernelGGL events, the clock rocprofv3 --kernel-trace reads).               */
+enum { MRT_KERNEL_PRIMARY = 0,   /* primary-ray generation + first closest hit                      */
+       MRT_KERNEL_SHADE = 1,     /* normals, light sampling, NEE / bounce ray emission, compaction   */
+       MRT_KERNEL_TRACE = 2,     /* bounce rays (closest hit) + shadow rays (any hit): the dominant kernel */
+       MRT_KERNEL_ACCUMULATE = 3,
+       MRT_KERNEL_CLASSES = 4 };
+typedef struct {
+    float    ms[MRT_KERNEL_CLASSES];          /* summed duration of the timed launches of the class   */
+    uint32_t launches[MRT_KERNEL_CLASSES];    /* how many launches that sum covers                     */
+} MRTKernelTimes;
+
 typedef struct MRTContext_  *MRTContext;
 typedef struct MRTScene_    *MRTScene;
 typedef struct MRTRenderer_ *MRTRenderer;
@@ -239,6 +251,7 @@ int mrt_renderer_write_accum_from_device(MRTRenderer r, const void *device_ptr, 
 int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbytes);
 int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out);
 int mrt_renderer_reset_stats(MRTRenderer r);
+int mrt_renderer_kernel_times(MRTRenderer r, MRTKernelTimes *out);   /* waits for the last render call */
 
 /* ---------------------------------------------------------------- device-function probes
  * Evaluate the kernel's helper functions on the device for known-answer tests

@@ -105,6 +105,12 @@ class RenderStats(C.Structure):
                 ("extend_launches_last", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4)]
+
+
+KERNEL_CLASSES = ("primary", "shade", "trace", "accumulate")
+
 assert C.sizeof(Camera) == 64 and C.sizeof(Light) == 128 and C.sizeof(Uniforms) == 96 and C.sizeof(Material) == 64
 assert C.sizeof(Ray) == 32 and C.sizeof(Intersection) == 32
 
@@ -158,6 +164,7 @@ SIGNATURES = {
     "mrt_renderer_read_tonemapped_rgba8": (C.c_int, [_P, _P, _SZ]),
     "mrt_renderer_stats": (C.c_int, [_P, C.POINTER(RenderStats)]),
     "mrt_renderer_reset_stats": (C.c_int, [_P]),
+    "mrt_renderer_kernel_times": (C.c_int, [_P, C.POINTER(KernelTimes)]),
     "mrt_debug_halton": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_hemisphere": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_seeds": (C.c_int, [_P, _U32, _I32, _I32, _P]),

@@ -472,6 +472,15 @@ int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out) {
     return r->r.stats(out);
     MRT_CATCH
 }
+int mrt_renderer_kernel_times(MRTRenderer r, MRTKernelTimes *out) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_kernel_times")
+    REQUIRE(out, "mrt_renderer_kernel_times: NULL");
+    int rc = r->r.wait(); if (rc) return rc;
+    *out = r->r.kernel_times;
+    return MRT_OK;
+    MRT_CATCH
+}
 int mrt_renderer_reset_stats(MRTRenderer r) {
     MRT_TRY
     RENDERER_PROLOGUE("mrt_renderer_reset_stats")

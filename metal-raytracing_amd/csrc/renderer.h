@@ -6,7 +6,7 @@
 
 namespace mrt {
 
-struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
+struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; };    // kind: MRT_KERNEL_* (mrt_abi.h)
 
 // One pass in flight (the reference keeps 3 frames in flight, Renderer.maxFramesInFlight, Renderer.swift:33): its
 // own HIP stream, ray / hit / shadow queues, per-pixel sample buffers and per-bounce queue counters, all sized for
@@ -51,7 +51,7 @@ struct Renderer {
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
     bool persistent = true;              // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter
-    int persist_chunk = 512;             // rays per pull
+    int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it
     size_t slots_for_stack = ~(size_t)0;
@@ -66,6 +66,7 @@ struct Renderer {
     int ext_used = 0;
     bool pending_timing = false;
     float ms_last = 0, ms_extend_last = 0; uint32_t extend_launches_last = 0;
+    MRTKernelTimes kernel_times{};       // per kernel class, over the launches of the last render() that carried events
 
     Renderer() = default;
     Renderer(const Renderer &) = delete;

@@ -741,11 +741,11 @@ int Renderer::render(int n_frames) {                                   // Render
             // traversal launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the
             // same clock rocprofv3 reads): plain hipEventRecord pairs on a stream also count the time a launch waits behind the
             // other frames in flight (+12 % at 12 frames)
-            auto timed = [&]() -> EvPair * { return ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr; };
+            auto timed = [&](int kind) -> EvPair * { if (ext_used >= (int)ev_ext.size()) return nullptr; ev_ext[ext_used].kind = kind; return &ev_ext[ext_used++]; };
             fp.bounce = 0;
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
-            if (primary_wide && sv.num_wnodes) launch_timed(timed(), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
-            else launch_timed(timed(), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
+            if (primary_wide && sv.num_wnodes) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
+            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
@@ -758,21 +758,24 @@ int Renderer::render(int n_frames) {                                   // Render
                 }
                 const hipStream_t ss = shade_priority ? L.hi : st;
                 if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, st)); MRT_HIP(hipStreamWaitEvent(ss, L.ev_x, 0)); }
-                hipLaunchKernelGGL(k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
                 if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, ss)); MRT_HIP(hipStreamWaitEvent(st, L.ev_x, 0)); }
                 if (on_wide && wide_stream && persistent) {
+                    // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
+                    // persist_chunk; 128-ray pulls of a one-frame launch are ~78 atomics per microsecond on the one counter word (limit ~88)
                     const size_t slots = 2 * (size_t)capacity * B;
-                    const uint32_t waves = (uint32_t)std::min<size_t>(cdiv(slots, persist_chunk), (size_t)wave_slots);
-                    launch_timed(timed(), k_trace_mixed_wide_persist, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), (uint32_t)persist_chunk);
+                    const uint32_t chunk = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / ((size_t)wave_slots * 4) / 64 * 64));
+                    const uint32_t waves = (uint32_t)std::min<size_t>(cdiv(slots, chunk), (size_t)wave_slots);
+                    launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk);
                 }
                 else if (on_wide && wide_stream) {
-                    launch_timed(timed(), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
+                    launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
-                else if (on_wide) launch_timed(timed(), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
-                else launch_timed(timed(), k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
+                else if (on_wide) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
+                else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 q = 1 - q;
             }
         } else {
@@ -782,7 +785,8 @@ int Renderer::render(int n_frames) {                                   // Render
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
-                EvPair *ev = ext_used < (int)ev_ext.size() ? &ev_ext[ext_used++] : nullptr;
+                EvPair *ev = nullptr;
+                if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
                 if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
@@ -794,7 +798,11 @@ int Renderer::render(int n_frames) {                                   // Render
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
         if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+        {
+            EvPair *ev = nullptr;
+            if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
+            launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+        }
         MRT_HIP(hipEventRecord(L.accumulated, st));
         last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334 (once per batch: the batch's frames are applied in one kernel)
@@ -814,9 +822,15 @@ int Renderer::wait() {
         float ms = 0;
         MRT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
         ms_last = ms;
-        float ext = 0;
-        for (int k = 0; k < ext_used; k++) { float e = 0; MRT_HIP(hipEventElapsedTime(&e, ev_ext[k].a, ev_ext[k].b)); ext += e; }
-        ms_extend_last = ext; extend_launches_last = (uint32_t)ext_used;
+        float ext = 0; uint32_t next = 0;
+        kernel_times = MRTKernelTimes{};
+        for (int k = 0; k < ext_used; k++) {
+            float e = 0; MRT_HIP(hipEventElapsedTime(&e, ev_ext[k].a, ev_ext[k].b));
+            const int kind = ev_ext[k].kind;
+            kernel_times.ms[kind] += e; kernel_times.launches[kind]++;
+            if (kind == MRT_KERNEL_PRIMARY || kind == MRT_KERNEL_TRACE) { ext += e; next++; }
+        }
+        ms_extend_last = ext; extend_launches_last = next;
         pending_timing = false;
     }
     return MRT_OK;

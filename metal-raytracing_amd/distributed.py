@@ -36,32 +36,46 @@ def reduce_accumulation(accum: torch.Tensor, mode="tile", dst=0, group=None):
 
 
 class ShardedRenderer:
-    """A Renderer bound to this rank's GPU and shard.  `gather()` runs the one collective."""
+    """A Renderer bound to this rank's GPU and shard; `gather()` runs the ONE collective per output image.  bench.py's N > 1
+    path and the multi-process tests drive the multi-GPU case through this class (world == 1: a plain renderer, gather is a copy).
 
-    def __init__(self, size, scene, rank, world, mode="tile", device=None, frames_total=None, **kw):
+    backend None / "nccl": the reduce runs on the device buffer (RCCL over xGMI).  "gloo": rehearsal without a GPU per rank —
+    ranks may share one device and the reduce runs on a host copy.
+    """
+
+    def __init__(self, size, scene, rank, world, mode="tile", device=None, frames_total=None, backend=None, **kw):
         from .renderer import Renderer
-        self.rank, self.world, self.mode = rank, world, mode
+        if mode not in ("tile", "sample"):
+            raise ValueError(mode)
+        self.rank, self.world, self.mode, self.backend = rank, world, mode, backend
         self.renderer = Renderer(size, scene, device=rank if device is None else device, **kw)
         if world > 1:
             if mode == "tile":
                 self.renderer.set_shard(rank, world)
-            elif mode == "sample":
+                # 1/world of the pixels per frame: carry proportionally more frames per pass so that the launches stay large
+                self.renderer.set_option("frame_batch", min(32, 4 * world))
+            else:
                 if frames_total is None:
                     raise ValueError("sample sharding needs frames_total (frames per rank)")
                 self.renderer.set_option("sample_offset", rank * int(frames_total))
-            else:
-                raise ValueError(mode)
         w, h = self.renderer.size
-        self.buffer = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{self.renderer.ctx.device}")
+        self.buffer = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{self.renderer.ctx.device}") if world > 1 else None
 
     def draw(self, frames=1):
         self.renderer.draw(frames)
 
     def gather(self, dst=0):
+        """The assembled image on `dst` (the per-rank accumulation buffers reduced); other ranks get their partial buffer."""
         r = self.renderer
+        if self.world == 1:
+            return torch.from_numpy(r.accumulation())
         r.copy_accum_to(self.buffer.data_ptr(), self.buffer.numel() * 4)
         r.wait()
-        if self.world > 1:
+        if self.backend == "gloo":
+            host = self.buffer.cpu()
+            reduce_accumulation(host, self.mode, dst)
+            self.buffer.copy_(host)
+        else:
             reduce_accumulation(self.buffer, self.mode, dst)
         return self.buffer
 

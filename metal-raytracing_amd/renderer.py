@@ -196,6 +196,14 @@ class Renderer:
     def reset_stats(self):
         check(lib.mrt_renderer_reset_stats(self.handle))
 
+    @property
+    def kernel_times(self):
+        """{class: (summed ms, launches)} over the launches of the last draw that carried their own start/stop events."""
+        from ._ffi import KERNEL_CLASSES, KernelTimes
+        k = KernelTimes()
+        check(lib.mrt_renderer_kernel_times(self.handle, C.byref(k)))
+        return {name: (float(k.ms[i]), int(k.launches[i])) for i, name in enumerate(KERNEL_CLASSES)}
+
     def close(self):
         if self.handle:
             lib.mrt_renderer_destroy(self.handle)

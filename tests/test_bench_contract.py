@@ -24,9 +24,36 @@ def test_bench_json_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and "traffic" in r
+    assert r["frame"]["frac"] > 0 and r["launches_timed"] > 0 and r["avg_launch_ms"] > 0
+    lat = d["latency"]
+    assert lat["ms_per_frame"] > 0 and lat["kernel_ms_serialised"]["trace"] > 0 and lat["reference_like_3_in_flight_ms_per_frame"] > 0
+    assert d["calibration"]["v_fma_f32_Ginst_per_s"] > 100
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 4 and c["value"] > 0 and c["unit"] == "Mrays/s" and "sample" in c
     assert d["parity"]["bit_exact_pixels"] == 1.0 and d["parity"]["rmse"] == 0.0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_assemble_the_one_rank_image(tmp_path):
+    """bench.py's own N > 1 path (ShardedRenderer: tile sharding, one reduce per image) rehearsed with 2 ranks that share this
+    box's GPU over gloo: the image rank 0 assembles must equal the 1-rank image bit for bit, and the JSON line must say
+    n_gpus = 2, strong scaling.  So the first real 8-GPU run is not the first time that code executes."""
+    import numpy as np
+    common = ["--steps", "6", "--warmup", "2", "--width", "320", "--height", "180", "--no-cpu-baseline", "--no-strict", "--no-latency"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-accum", one], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", *common, "--dump-accum", two],
+                        capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0
+    d1 = json.loads([l for l in p1.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d1["config"]["rays_per_frame"] == d["config"]["rays_per_frame"]          # ray-count conservation across the shards
+    a, b = np.load(one), np.load(two)
+    assert a.shape == (180, 320, 4) and np.array_equal(a, b)
 
 
 def test_bench_argparse_defaults():

@@ -70,7 +70,48 @@ KERNEL(k_med3, "v_med3_f32 %0, %0, %1, %2")
 KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c")
 KERNEL(k_bpermute, "ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)")
 KERNEL(k_readlane, "v_readfirstlane_b32 s20, %0", : "s20")
+KERNEL(k_fma_mix_lo, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]")
+KERNEL(k_fma_mix_hi, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+KERNEL(k_cndmask_s, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+KERNEL(k_addc, "v_addc_co_u32 %0, vcc, %0, %0, vcc", : "vcc")
+KERNEL(k_or, "v_or_b32 %0, %0, %1")
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL(k_lshr, "v_lshrrev_b32 %0, 3, %0")
+KERNEL(k_min, "v_min_f32 %0, %0, %1")
+KERNEL(k_mul_legacy, "v_mul_legacy_f32 %0, %0, %1")
+KERNEL(k_or_sdwa, "v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+KERNEL(k_add_f32_sdwa, "v_add_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+KERNEL(k_mul_f32_sdwa, "v_mul_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+KERNEL(k_cmp_class, "v_cmp_class_f32 vcc, %0, %1", : "vcc")
+KERNEL(k_subrev, "v_subrev_u32 %0, %0, %1")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
+KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
+KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
 KERNEL(k_sdwa_cvt, "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1")
+
+#define KERNEL64(NAME, ASM, ...)                                                                                        \
+    __global__ void __launch_bounds__(64, 8) NAME(unsigned *out, unsigned long long *clocks, unsigned seed) {           \
+        unsigned long long a[8];                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) a[k] = seed * (k + 3) + threadIdx.x;                              \
+        unsigned b = seed | 0x3f800000u, c = (seed * 7u) | 0x3f000000u;                                                 \
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();              \
+        for (int i = 0; i < ITERS; i++) {                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 2; r++)                                                               \
+            _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile(ASM : "+v"(a[k]) : "v"(b), "v"(c) __VA_ARGS__);  \
+        }                                                                                                               \
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();              \
+        unsigned long long s = 0;                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) s ^= a[k];                                                        \
+        if (s == 0x12345678u) out[blockIdx.x] = (unsigned)s;                                                            \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = r1 - r0; }              \
+    }
+KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0", : "vcc")
+KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 4, %0")
+KERNEL64(k_pk_fma, "v_pk_fma_f32 %0, %0, %0, %0")
+KERNEL64(k_pk_mul, "v_pk_mul_f32 %0, %0, %0")
+KERNEL64(k_pk_add, "v_pk_add_f32 %0, %0, %0")
+KERNEL64(k_cvt_pk_fp8, "v_cvt_pk_f32_fp8 %0, %1")
+KERNEL64(k_mov_b64, "v_mov_b64 %0, %0")
 
 typedef void (*Kern)(unsigned *, unsigned long long *, unsigned);
 struct Entry { const char *name; Kern k; };
@@ -86,7 +127,9 @@ int main() {
         E(k_fma), E(k_fmac), E(k_mul), E(k_add), E(k_sub), E(k_max), E(k_max3), E(k_min3), E(k_med3), E(k_cvt_ub0), E(k_cvt_ub2), E(k_sdwa_cvt), E(k_cvt_u32), E(k_cndmask),
         E(k_cmp), E(k_cmp_sgpr), E(k_and), E(k_xor), E(k_or3), E(k_bitop3), E(k_lshl), E(k_lshl_or), E(k_bfe), E(k_bfe_i), E(k_bfm), E(k_bfi), E(k_perm), E(k_ffbl), E(k_bcnt),
         E(k_mov), E(k_add_u32), E(k_mul_u24), E(k_mad_u24), E(k_mul_lo), E(k_mul_hi), E(k_rcp), E(k_rsq), E(k_sqrt), E(k_ldexp), E(k_div_scale), E(k_div_fmas),
-        E(k_div_fixup), E(k_bpermute), E(k_readlane)};
+        E(k_div_fixup), E(k_bpermute), E(k_readlane), E(k_fma_mix_lo), E(k_fma_mix_hi), E(k_cndmask_s), E(k_addc), E(k_or), E(k_and_or), E(k_lshr), E(k_min), E(k_mul_legacy),
+        E(k_or_sdwa), E(k_add_f32_sdwa), E(k_mul_f32_sdwa), E(k_cmp_class), E(k_subrev), E(k_lshl_add), E(k_add3), E(k_xad),
+        E(k_mad_u64_u32), E(k_lshl_add_u64), E(k_pk_fma), E(k_pk_mul), E(k_pk_add), E(k_cvt_pk_fp8), E(k_mov_b64)};
     const unsigned grid = (unsigned)simds * 8;
     printf("{\"device\": \"%s\", \"simds\": %d, \"rates\": {", prop.gcnArchName, simds);
     bool first = true;
@@ -102,8 +145,7 @@ int main() {
         const double insts = (double)grid * ITERS * 16.0;
         const double rate = insts / (best * 1e-3);
         const double clock = h[1] ? (double)h[0] / (double)h[1] * 1e8 : 0.0;
-        // cycles per instruction per SIMD from the measuring wave's own clocks: 8 waves share the SIMD
-        const double cyc = h[0] ? (double)h[0] / (ITERS * 16.0 * 8.0) : 0.0;
+        const double cyc = rate > 0 ? clock * simds / rate : 0.0;      // SIMD cycles per wave64 instruction at the clock the loop ran at
         printf("%s\"%s\": {\"Ginst_per_s\": %.1f, \"clock_GHz\": %.3f, \"cycles_per_inst_per_simd\": %.2f}", first ? "" : ", ", e.name + 2, rate / 1e9, clock / 1e9, cyc);
         first = false;
     }
