@@ -14,8 +14,6 @@ struct EvPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; };    // kind
 // waves are covered by the next pass's bulk); only the accumulate step is ordered pass to pass, by an event.
 struct FrameLane {
     hipStream_t stream = nullptr;
-    hipStream_t hi = nullptr;            // high-priority companion stream (option shade_priority): k_shade / k_accumulate jump the dispatch queue
-    hipEvent_t ev_x = nullptr;           // hand-over between the two streams
     hipEvent_t accumulated = nullptr;    // recorded after this lane's k_accumulate
     DevBuf<float4> sample;               // [sub-frame][pixel] radiance of the batch's frames
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
@@ -46,11 +44,10 @@ struct Renderer {
     int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
-    bool shade_priority = false;         // experiment: shade + accumulate on a high-priority stream per lane
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
-    bool persistent = true;              // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter
+    int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it

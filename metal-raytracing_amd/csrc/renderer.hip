@@ -592,7 +592,6 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &e : ev_ext) { MRT_HIP(hipEventCreate(&e.a)); MRT_HIP(hipEventCreate(&e.b)); }
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        MRT_HIP(hipEventCreateWithFlags(&L.ev_x, hipEventDisableTiming));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
         MRT_HIP(L.bounce_counts.alloc(64));       // [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
@@ -609,8 +608,6 @@ Renderer::~Renderer() {
     for (auto &e : ev_ext) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
     for (auto &L : lanes) {
         if (L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
-        if (L.hi) { (void)hipStreamSynchronize(L.hi); (void)hipStreamDestroy(L.hi); }
-        if (L.ev_x) (void)hipEventDestroy(L.ev_x);
         if (L.accumulated) (void)hipEventDestroy(L.accumulated);
     }
 }
@@ -731,7 +728,7 @@ int Renderer::render(int n_frames) {                                   // Render
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
-            if (on_wide && persistent && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
+            if (on_wide && persistent != 0 && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
                 int per_cu = 0, dev = 0; hipDeviceProp_t prop;
                 MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
                 MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist, 64, stack_bytes));
@@ -753,15 +750,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                if (shade_priority && !L.hi) {      // created on demand: every extra stream takes a share of the 16 hardware queues away from the lanes (measured: 28 streams halve the frame rate)
-                    int lo = 0, hi = 0; MRT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); MRT_HIP(hipStreamCreateWithPriority(&L.hi, hipStreamNonBlocking, hi));
-                }
-                const hipStream_t ss = shade_priority ? L.hi : st;
-                if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, st)); MRT_HIP(hipStreamWaitEvent(ss, L.ev_x, 0)); }
-                launch_timed(timed(MRT_KERNEL_SHADE), k_shade, gs, dim3(SHADE_THREADS), 0, ss, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), k_shade, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                                    L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
-                if (shade_priority) { MRT_HIP(hipEventRecord(L.ev_x, ss)); MRT_HIP(hipStreamWaitEvent(st, L.ev_x, 0)); }
-                if (on_wide && wide_stream && persistent) {
+                // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
+                // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
+                const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
+                if (on_wide && wide_stream && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
                     // persist_chunk; 128-ray pulls of a one-frame launch are ~78 atomics per microsecond on the one counter word (limit ~88)
                     const size_t slots = 2 * (size_t)capacity * B;
