@@ -171,6 +171,11 @@ int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride
                        const float *transform_colmajor_4x4, int32_t *mesh_id);
 /* One Submesh = one geometry of that mesh's primitive AS (Mesh.swift:39-48).  indices: 3*ntris
  * uint32 into the mesh's vertex arrays.  Returns the geometry id in *geometry_id.              */
+/* A further instance of an existing mesh: shares its vertex arrays, submeshes and materials, has its own transform and its own
+ * mesh id (= instance id).  The reference's counterpart is an MTLAccelerationStructureInstanceDescriptor whose
+ * accelerationStructureIndex names an existing primitive structure (Renderer.swift:193-203).  With scene option instancing = 1
+ * the geometry gets ONE bottom-level BVH shared by all its instances; with instancing = 0 (default) instances are flattened.   */
+int mrt_scene_add_instance(MRTScene scene, int32_t source_mesh_id, const float *transform4x4_colmajor, int32_t *mesh_id);
 int mrt_mesh_add_submesh(MRTScene scene, int32_t mesh_id, const uint32_t *indices, size_t ntris,
                          const MRTMaterial *material, int32_t *geometry_id);
 /* Convenience = Model(name:position:rotation:scale:) (Model.swift:13): read OBJ+MTL with the

@@ -127,6 +127,7 @@ SIGNATURES = {
     "mrt_scene_create": (C.c_int, [_P, C.POINTER(_P)]),
     "mrt_scene_destroy": (C.c_int, [_P]),
     "mrt_scene_add_mesh": (C.c_int, [_P, _P, _SZ, _P, _SZ, _SZ, _P, _PI32]),
+    "mrt_scene_add_instance": (C.c_int, [_P, _I32, _P, _PI32]),
     "mrt_mesh_add_submesh": (C.c_int, [_P, _I32, _P, _SZ, C.POINTER(Material), _PI32]),
     "mrt_scene_add_obj": (C.c_int, [_P, C.c_char_p, _PF, _PF, _F, _PI32]),
     "mrt_scene_set_lights": (C.c_int, [_P, C.POINTER(Light), _I32]),

@@ -21,6 +21,7 @@ struct MRTScene_ {
     mrt::BuildOptions opt;
     mrt::DeviceScene dev;
     bool committed = false;
+    bool only_transforms_changed = false;   // since the last commit of a two-level scene: the next commit rebuilds the TLAS only
 };
 struct MRTRenderer_ {
     MRTContext ctx = nullptr;
@@ -130,7 +131,23 @@ int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride
     memcpy(m.xf, xf, 64);
     m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;              // matrix4x4_drop_last_row (Utilities.swift:92-101)
     scene->meshes.push_back(std::move(m));
-    scene->committed = false;
+    scene->committed = false; scene->only_transforms_changed = false;
+    if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_add_instance(MRTScene scene, int32_t source_mesh_id, const float *xf, int32_t *mesh_id) {
+    MRT_TRY
+    REQUIRE(scene && xf, "mrt_scene_add_instance: bad argument");
+    REQUIRE(source_mesh_id >= 0 && (size_t)source_mesh_id < scene->meshes.size(), "mrt_scene_add_instance: source_mesh_id out of range");
+    REQUIRE(scene->meshes.size() < 65535, "mrt_scene_add_instance: too many meshes");
+    mrt::HostMesh m;
+    const int src = scene->meshes[source_mesh_id].source;
+    m.source = src >= 0 ? src : source_mesh_id;                         // instances of an instance share the original's geometry
+    memcpy(m.xf, xf, 64);
+    m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;
+    scene->meshes.push_back(std::move(m));
+    scene->committed = false; scene->only_transforms_changed = false;
     if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
     return MRT_OK;
     MRT_CATCH
@@ -141,12 +158,13 @@ int mrt_mesh_add_submesh(MRTScene scene, int32_t mesh_id, const uint32_t *indice
     REQUIRE(mesh_id >= 0 && (size_t)mesh_id < scene->meshes.size(), "mrt_mesh_add_submesh: mesh_id out of range");
     REQUIRE(ntris == 0 || indices, "mrt_mesh_add_submesh: NULL indices");
     mrt::HostMesh &m = scene->meshes[mesh_id];
+    REQUIRE(m.source < 0, "mrt_mesh_add_submesh: the mesh is an instance (mrt_scene_add_instance) and shares its source's submeshes");
     REQUIRE(m.sub_indices.size() < 65535, "mrt_mesh_add_submesh: too many submeshes");
     size_t nv = m.positions.size() / 3;
     for (size_t i = 0; i < ntris * 3; i++) REQUIRE(indices[i] < nv, "mrt_mesh_add_submesh: vertex index out of range");
     m.sub_indices.emplace_back(indices, indices + ntris * 3);
     m.sub_materials.push_back(*material);
-    scene->committed = false;
+    scene->committed = false; scene->only_transforms_changed = false;
     if (geometry_id) *geometry_id = (int32_t)m.sub_indices.size() - 1;
     return MRT_OK;
     MRT_CATCH
@@ -183,9 +201,10 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
-    scene->committed = false;
+    scene->committed = false; scene->only_transforms_changed = false;
     return MRT_OK;
     MRT_CATCH
 }
@@ -193,7 +212,11 @@ int mrt_scene_commit(MRTScene scene) {
     MRT_TRY
     REQUIRE(scene, "mrt_scene_commit: scene is NULL");
     int rc = bind_device(scene->ctx); if (rc) return rc;
-    rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev); if (rc) return rc;
+    if (scene->only_transforms_changed && scene->opt.instancing && scene->dev.num_inst == scene->meshes.size())
+        rc = mrt::update_tlas(scene->meshes, scene->ctx->stream, scene->dev);         // instance rows + TLAS; the BLASes stay (the refit of an animated scene)
+    else rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev);
+    if (rc) return rc;
+    scene->only_transforms_changed = false;
     rc = mrt::upload_lights(scene->lights.data(), (int)scene->lights.size(), scene->ctx->stream, scene->dev); if (rc) return rc;
     scene->committed = true;
     return MRT_OK;
@@ -206,7 +229,10 @@ int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const floa
     float *m = scene->meshes[mesh_id].xf;
     memcpy(m, xf, 64);
     m[3] = m[7] = m[11] = 0.0f; m[15] = 1.0f;
-    scene->committed = false;           // the world-space BVH is rebuilt by the next mrt_scene_commit (22 ms for 885 K triangles)
+    // flattened scene: the world-space BVH is rebuilt by the next mrt_scene_commit (22 ms for 885 K triangles);
+    // two-level scene: the next commit rewrites the instance rows and rebuilds the TLAS only
+    if (scene->committed) scene->only_transforms_changed = true;
+    scene->committed = false;
     return MRT_OK;
     MRT_CATCH
 }
@@ -244,6 +270,7 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
     MRT_TRY
     REQUIRE(scene && (n == 0 || (rays && out4)), "mrt_debug_traversal_stats: bad argument");
     if (!scene->committed) { mrt::set_error("mrt_debug_traversal_stats: scene not committed"); return MRT_ERR_STATE; }
+    if (scene->dev.num_inst) { mrt::set_error("mrt_debug_traversal_stats: not available for two-level scenes"); return MRT_ERR_UNSUPPORTED; }
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::query_stats(scene->dev, scene->ctx->stream, rays, n, any_hit, out4);
     MRT_CATCH
@@ -253,6 +280,7 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
     MRT_TRY
     REQUIRE(scene && rays && out8 && per_wave >= 64 && nwaves * (size_t)per_wave >= n, "mrt_debug_stream_stats: bad argument");
     if (!scene->committed) { mrt::set_error("mrt_debug_stream_stats: scene not committed"); return MRT_ERR_STATE; }
+    if (scene->dev.num_inst) { mrt::set_error("mrt_debug_stream_stats: not available for two-level scenes"); return MRT_ERR_UNSUPPORTED; }
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::query_stream_stats(scene->dev, scene->ctx->stream, rays, n, any_hit, per_wave, out8, nwaves);
     MRT_CATCH

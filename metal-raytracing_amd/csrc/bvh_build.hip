@@ -585,6 +585,7 @@ SceneView DeviceScene::view() const {
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
+    v.inst = inst.p; v.tlas_index = tlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
@@ -628,7 +629,20 @@ int layout_limits(uint64_t triangles, uint64_t nodes) {
     return MRT_OK;
 }
 
-int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+    if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
+    out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.bnodes.release(); out.h_inst.clear();
+    // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
+    std::vector<MeshRef> refs;
+    for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
+    return build_flat(refs, opt, stream, out);
+}
+
+// One world-space BVH over the given (geometry, transform) pairs: the whole flattened scene, or one BLAS (a single mesh under the identity).
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+    struct MeshView { const std::vector<float> &positions, &normals; const float *xf; const std::vector<std::vector<uint32_t>> &sub_indices; const std::vector<MRTMaterial> &sub_materials; };
+    std::vector<MeshView> meshes;
+    for (auto &r : refs) meshes.push_back(MeshView{r.g->positions, r.g->normals, r.xf, r.g->sub_indices, r.g->sub_materials});
     // ---- host-side concatenation (one upload per array)
     size_t V = 0, T = 0, NI = 0; int max_sub = 1;
     for (auto &m : meshes) {
@@ -648,7 +662,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
     size_t vb = 0, tb = 0, ib = 0;
     for (size_t mi = 0; mi < I; mi++) {
-        const HostMesh &m = meshes[mi];
+        const MeshView &m = meshes[mi];
         size_t nv = m.positions.size() / 3;
         memcpy(&h_pos[vb * 3], m.positions.data(), nv * 12);
         for (size_t v = 0; v < nv; v++) h_nrm[vb + v] = make_float4(m.normals[v * 3], m.normals[v * 3 + 1], m.normals[v * 3 + 2], 0.0f);
@@ -803,6 +817,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
     if (int rc = layout_limits(T, h_size)) return rc;           // the surviving node count must fit the 24-bit child index
     float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
     float area = 2.0f * (dx * dy + dy * dz + dz * dx);
+    out.root_lo[0] = rlo.x; out.root_lo[1] = rlo.y; out.root_lo[2] = rlo.z; out.root_hi[0] = rhi.x; out.root_hi[1] = rhi.y; out.root_hi[2] = rhi.z;
     out.stats.bvh_nodes = h_size;
     out.stats.bvh_leaves = h_stat[1];
     out.stats.max_depth = (int32_t)h_stat[0];

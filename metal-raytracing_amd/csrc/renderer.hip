@@ -21,6 +21,7 @@
 #include "device_math.h"
 #include "traverse.h"
 #include "traverse_wide.h"
+#include "traverse_instanced.h"
 #include <cstring>
 #include <algorithm>
 
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
 //   k_trace_mixed   : one launch over two queues — the next-bounce rays (closest hit -> hit records) and the
 //                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
 //                     the loop; a shadow lane simply stops at its first hit.
+template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, sub = blockIdx.y;      // grid = (local tiles, sub-frames of the batch)
     float4 *__restrict__ hits_s = hits + (size_t)sub * fp.capacity;
@@ -134,10 +136,11 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
     // instead of repeating two Halton values, two divisions and a normalisation per pixel)
     dirs[(size_t)sub * fp.capacity + slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));
     TravHit h;
-    bool hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
+    bool hit = TWO_LEVEL ? traverse_instanced<false>(s, org, dir, 0.0f, __builtin_inff(), h) : traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
     hits_s[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 
+template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                     const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                     const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *_
     const uint32_t j = shadow ? i - n_next : i;
     const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
     TravHit h;
-    bool hit = traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow);
+    bool hit = TWO_LEVEL ? traverse_instanced<false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, shadow) : traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow);
     if (shadow) {
         if (!hit) {
             uint32_t pix = __float_as_uint(B.w);
@@ -345,12 +348,16 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
         } else { A = rayA[i]; B = rayB[i]; C = thr[i]; }
         pix = __float_as_uint(B.w);
-        uint4 ts = s.tri_shade[gid];
-        uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
+        uint4 ts; uint32_t inst, geom, vb = 0;
+        if (s.num_inst) {           // two-level scene: the shading record belongs to the BLAS, the instance is found from the global triangle id
+            inst = instance_of_gid(s, gid);
+            const InstanceDev &I = s.inst[inst];
+            ts = s.tri_shade[I.ts_base + (gid - I.gid_base)]; vb = I.vbase; geom = ts.w & 0xFFFFu;
+        } else { ts = s.tri_shade[gid]; inst = ts.w >> 16; geom = ts.w & 0xFFFFu; }
         float bu = H.y, bv = H.z;
         P = mk3(A) + mk3(B) * H.x;                                       // :261
         float bw = 1.0f - bu - bv;                                       // :63-64
-        f3 n_obj = (bu * mk3(s.normals[ts.y]) + bv * mk3(s.normals[ts.z])) + bw * mk3(s.normals[ts.x]);   // :66-72
+        f3 n_obj = (bu * mk3(s.normals[vb + ts.y]) + bv * mk3(s.normals[vb + ts.z])) + bw * mk3(s.normals[vb + ts.x]);   // :66-72
         f3 c0 = mk3(s.inst_cols[inst * 4 + 0]), c1 = mk3(s.inst_cols[inst * 4 + 1]), c2 = mk3(s.inst_cols[inst * 4 + 2]);
         f3 n_w = mk3((c0.x * n_obj.x + c1.x * n_obj.y) + c2.x * n_obj.z,
                      (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
@@ -500,12 +507,14 @@ __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay 
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    bool hit = WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
+    bool hit = s.num_inst ? traverse_instanced<false>(s, ro, rd, r.min_distance, r.max_distance, h)
+             : WIDE ? traverse_wide<false>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<false>(s, ro, rd, r.min_distance, r.max_distance, h);
     MRTIntersection o;
     o._pad = 0;
     if (hit) {
-        uint4 ts = s.tri_shade[h.gid];
-        uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
+        uint32_t inst, geom;
+        if (s.num_inst) { inst = instance_of_gid(s, h.gid); const InstanceDev &I = s.inst[inst]; geom = s.tri_shade[I.ts_base + (h.gid - I.gid_base)].w & 0xFFFFu; }
+        else { const uint4 ts = s.tri_shade[h.gid]; inst = ts.w >> 16; geom = ts.w & 0xFFFFu; }
         o.type = 1; o.distance = h.t; o.instance_id = (int32_t)inst; o.geometry_id = (int32_t)geom;
         o.primitive_id = (int32_t)(h.gid - s.geom_base[inst * (uint32_t)s.max_sub + geom]);
         o.u = h.U / h.ad; o.v = h.V / h.ad;
@@ -520,7 +529,8 @@ __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__r
     MRTRay r = rays[i];
     TravHit h;
     const f3 ro = mk3(r.origin[0], r.origin[1], r.origin[2]), rd = mk3(r.direction[0], r.direction[1], r.direction[2]);
-    out[i] = (WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
+    out[i] = (s.num_inst ? traverse_instanced<true>(s, ro, rd, r.min_distance, r.max_distance, h)
+              : WIDE ? traverse_wide<true>(s, ro, rd, r.min_distance, r.max_distance, h, stk) : traverse<true>(s, ro, rd, r.min_distance, r.max_distance, h)) ? 1 : 0;
 }
 
 // per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
@@ -686,7 +696,8 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
-    const bool wide = use_wide && sv.num_wnodes > 0;
+    const bool two_level = sv.num_inst > 0;          // instanced scene: the fused pipeline on the two-level rope kernels
+    const bool wide = use_wide && sv.num_wnodes > 0 && !two_level;
     if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
         const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
@@ -710,7 +721,7 @@ int Renderer::render(int n_frames) {                                   // Render
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
     // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
     // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
-    const int batch_max = (fused && !wide) ? alloc_batch : 1;
+    const int batch_max = ((fused || two_level) && !wide) ? alloc_batch : 1;
     fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
     hipEvent_t last_acc = nullptr;
     int pass = 0;
@@ -723,7 +734,7 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
-        if (fused && !wide) {
+        if ((fused || two_level) && !wide) {
             // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
@@ -742,7 +753,8 @@ int Renderer::render(int n_frames) {                                   // Render
             fp.bounce = 0;
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
             if (primary_wide && sv.num_wnodes) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
-            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
+            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
+            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
@@ -769,7 +781,8 @@ int Renderer::render(int n_frames) {                                   // Render
                     if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
                 else if (on_wide) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
-                else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
+                else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<true>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
+                else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<false>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 q = 1 - q;
             }
         } else {

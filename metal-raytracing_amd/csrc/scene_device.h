@@ -57,6 +57,21 @@ struct LightDev {            // 96 B, derived once per mrt_scene_set_lights from
     float4 dirn;             // spot: normalize(direction), .w = cos(coneAngle); sun: normalize(direction)
 };
 
+// ---- two-level scenes (scene option instancing = 1; two_level.hip): one BLAS per distinct mesh, built in OBJECT space by the same
+// pipeline as the flattened scene, one record per instance, and a TLAS (rope nodes again, built on the host over the instances'
+// world boxes) whose leaves are ranges of `tlas_index`.  Replaces MTLAccelerationStructureInstanceDescriptor + the instance
+// acceleration structure of Renderer.swift:193-213.  A ray is taken into object space at the instance boundary WITHOUT
+// renormalising its direction, so the hit distance t is the world-space t.
+struct InstanceDev {          // 80 B
+    float4 w2o[3];            // rows of the world->object 3x4: p_obj.k = fma(r.z, p.z, fma(r.y, p.y, r.x * p.x)) + r.w (directions: without r.w)
+    uint32_t node_base;       // first rope node of its BLAS in `bnodes`
+    uint32_t packet_base;     // first triangle packet of its BLAS in `bpackets`
+    uint32_t gid_base;        // global id of its first triangle: instance-major, then geometry, then primitive — the numbering of the flattened scene
+    uint32_t ts_base;         // first shading record of its BLAS in `tri_shade`
+    uint32_t vbase;           // first vertex of its mesh in `normals`
+    uint32_t ntri, blas, _pad;
+};
+
 struct SceneView {           // passed by value to kernels
     const float4 *nodes;         // 4 x float4 per node
     const float4 *packets;       // 3 x float4 per triangle, leaf order
@@ -69,6 +84,12 @@ struct SceneView {           // passed by value to kernels
     // 8-wide compressed layout (WideNode below) for the LDS-stack traversal backend; num_wnodes == 0 → not built
     const float4 *wnodes;        // 5 x float4 per wide node
     const float4 *wpackets;      // 3 x float4 per triangle, grouped per wide node
+    // two-level scenes: `nodes` is the TLAS; num_inst == 0 -> flattened scene
+    const InstanceDev *inst;
+    const uint32_t *tlas_index;  // instance ids, TLAS leaf order
+    const float4 *bnodes;        // rope nodes of all BLASes, 4 x float4 each; followed, in the same allocation, by
+    const float4 *bpackets;      // their triangle packets (object space), 3 x float4 each
+    uint32_t num_inst;
     uint32_t num_wnodes;
     uint32_t num_nodes;
     uint32_t num_tris;
@@ -92,7 +113,8 @@ template <class T> struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
-struct HostMesh {                  // what the caller handed over through mrt_scene_add_mesh / _add_submesh
+struct HostMesh {                  // what the caller handed over through mrt_scene_add_mesh / _add_submesh / _add_instance
+    int source = -1;               // >= 0: an instance of that mesh (shares its vertex arrays, submeshes and materials; its own arrays stay empty)
     std::vector<float> positions;  // packed xyz, object space
     std::vector<float> normals;    // packed xyz, object space
     float xf[16];                  // column-major, last row forced to (0,0,0,1)
@@ -107,6 +129,8 @@ struct BuildOptions {
     float cost_isect = 1.0f;
     int ploc_radius = 16;
     int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
+    int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
+                              // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS
 };
 
 struct DeviceScene {
@@ -118,12 +142,24 @@ struct DeviceScene {
     DevBuf<LightDev> lights;
     int light_count = 0;
     MRTSceneStats stats{};
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};     // box of the whole tree (padded leaf boxes)
+    // two-level scenes (two_level.hip)
+    DevBuf<InstanceDev> inst; DevBuf<uint32_t> tlas_index; DevBuf<float4> bnodes;
+    size_t bpackets_offset = 0; uint32_t num_inst = 0;
+    std::vector<InstanceDev> h_inst;                           // host copy: transform updates rewrite the rows and rebuild the TLAS only
+    std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each
+    float tlas_ms = 0;                                         // host + upload time of the last TLAS build
     SceneView view() const;
 };
 
 // bvh_build.hip
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+// two_level.hip
+int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched
 int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out);
 
 }  // namespace mrt

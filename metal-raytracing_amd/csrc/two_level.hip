@@ -1,0 +1,236 @@
+// two_level.hip — instanced scenes: one BLAS per distinct mesh + a TLAS over the instances (scene option instancing = 1).
+//
+// Replaces the reference's instance acceleration structure: MTLAccelerationStructureInstanceDescriptor per mesh (transform,
+// accelerationStructureIndex; Renderer.swift:193-203) over an array of primitive acceleration structures (:184-192, :205-213),
+// and the compaction pass of Utilities.swift:65-84 (here: each BLAS is built into a scratch allocation and only its surviving
+// nodes are copied into the shared arrays).  The reference never points two instances at one primitive structure
+// (DragonScene.swift:19-20 loads the sphere twice), but its API is instance-based; mrt_scene_add_instance makes the sharing
+// explicit, BASELINE.json configs[4] ("dragon.obj at 4x instancing") uses it.
+//
+//   BLAS   the flattened-scene pipeline of bvh_build.hip (Morton sort -> PLOC -> SAH collapse -> rope nodes + packets) run on ONE mesh
+//          under the identity transform, i.e. in object space; triangle ids are local to the mesh.
+//   TLAS   a rope tree over the instances' world boxes (the 8 corners of the BLAS root box through the instance matrix), built on the
+//          host: median split of the box centres along the widest axis, leaves of up to two instances.  Instance counts are small
+//          (<= 65 535 by the ABI) and the build is microseconds; a transform change rebuilds ONLY this tree and the 80-byte
+//          instance rows (update_tlas) — the BLASes are never touched ("refit" of an animated scene).
+#include "scene_device.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace mrt {
+namespace {
+
+// inverse of the affine map p -> A p + t given as a column-major 4x4 (last row 0 0 0 1): rows of [A^-1 | -A^-1 t], evaluated in double with
+// this exact operation order (the CPU oracle restates it: the instance rows must agree bit for bit) and rounded to float once.
+bool invert_affine(const float *xf, float rows[3][4]) {
+    const double a00 = xf[0], a10 = xf[1], a20 = xf[2], a01 = xf[4], a11 = xf[5], a21 = xf[6], a02 = xf[8], a12 = xf[9], a22 = xf[10];
+    const double tx = xf[12], ty = xf[13], tz = xf[14];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double det = a00 * c00 + a01 * c10 + a02 * c20;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double i[3][3] = {{c00 / det, c01 / det, c02 / det}, {c10 / det, c11 / det, c12 / det}, {c20 / det, c21 / det, c22 / det}};
+    for (int r = 0; r < 3; r++) {
+        rows[r][0] = (float)i[r][0]; rows[r][1] = (float)i[r][1]; rows[r][2] = (float)i[r][2];
+        rows[r][3] = (float)(-(i[r][0] * tx + i[r][1] * ty + i[r][2] * tz));
+    }
+    return true;
+}
+
+struct Box { float lo[3], hi[3]; };
+
+// world box of an instance: the corners of its BLAS root box through the object->world matrix; padded like the leaf boxes of
+// bvh_build.hip (1e-5 |coord| + 1e-6) plus the rounding of the ray's trip into object space
+Box instance_box(const float *xf, const float *lo, const float *hi) {
+    Box b; for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; }
+    for (int c = 0; c < 8; c++) {
+        const double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        for (int k = 0; k < 3; k++) {
+            const double w = (double)xf[k] * p[0] + (double)xf[4 + k] * p[1] + (double)xf[8 + k] * p[2] + (double)xf[12 + k];
+            b.lo[k] = std::min(b.lo[k], (float)w); b.hi[k] = std::max(b.hi[k], (float)w);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        const float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])), e = 4e-5f * m + 4e-6f;
+        b.lo[k] -= e; b.hi[k] += e;
+    }
+    return b;
+}
+
+// Host TLAS: preorder rope nodes in the 64-byte layout of scene_device.h.  The left child is entered first for every octant (near
+// mask 0), so all eight escape links of a node are equal; leaves are ranges of `order`.
+struct TlasBuilder {
+    const std::vector<Box> &boxes;
+    std::vector<uint32_t> order;          // instance ids, leaf order
+    std::vector<float4> nodes;            // 4 per node
+    int depth = 0;
+    explicit TlasBuilder(const std::vector<Box> &b) : boxes(b) {}
+    static float4 f4(float x, float y, float z, uint32_t w) { float f; memcpy(&f, &w, 4); return make_float4(x, y, z, f); }
+    // builds the subtree over order[first, first + count) and returns its node index; `esc` = node to continue with afterwards
+    uint32_t build(uint32_t first, uint32_t count, uint32_t esc, int d) {
+        depth = std::max(depth, d);
+        Box b; for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; }
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = first; i < first + count; i++) {
+            const Box &q = boxes[order[i]];
+            for (int k = 0; k < 3; k++) {
+                b.lo[k] = std::min(b.lo[k], q.lo[k]); b.hi[k] = std::max(b.hi[k], q.hi[k]);
+                const float c = 0.5f * (q.lo[k] + q.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c);
+            }
+        }
+        const uint32_t me = (uint32_t)(nodes.size() / 4);
+        nodes.resize(nodes.size() + 4);
+        uint32_t a, bb;
+        if (count <= 2) { a = NODE_LEAF | first; bb = count; }
+        else {
+            int ax = 0; if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1; if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+            const uint32_t half = count / 2;
+            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count, [&](uint32_t x, uint32_t y) {
+                const float cx = boxes[x].lo[ax] + boxes[x].hi[ax], cy = boxes[y].lo[ax] + boxes[y].hi[ax];
+                return cx < cy || (cx == cy && x < y);
+            });
+            // preorder: the left subtree starts at me + 1; the right subtree's index is known once the left one is built
+            const uint32_t left = me + 1;
+            // the left subtree escapes to the right sibling, whose index = me + 1 + size(left subtree): build left with a placeholder, patch after
+            const size_t before = nodes.size();
+            build(first, half, 0xFFFFFFFEu, d + 1);
+            const uint32_t right = (uint32_t)(nodes.size() / 4);
+            for (size_t n = before; n < nodes.size(); n += 4)       // patch the placeholder links of the left subtree
+                for (int q = 2; q < 4; q++) {
+                    uint32_t w[4]; memcpy(w, &nodes[n + q], 16);
+                    for (int k = 0; k < 4; k++) if (w[k] == 0xFFFFFFFEu) w[k] = right;
+                    memcpy(&nodes[n + q], w, 16);
+                }
+            build(first + half, count - half, esc, d + 1);
+            a = left; bb = right;                                      // near mask 0: left first
+        }
+        nodes[4 * (size_t)me + 0] = f4(b.lo[0], b.lo[1], b.lo[2], a);
+        nodes[4 * (size_t)me + 1] = f4(b.hi[0], b.hi[1], b.hi[2], bb);
+        float e; memcpy(&e, &esc, 4);
+        nodes[4 * (size_t)me + 2] = make_float4(e, e, e, e);
+        nodes[4 * (size_t)me + 3] = make_float4(e, e, e, e);
+        return me;
+    }
+};
+
+}  // namespace
+
+// instance rows + TLAS from the current transforms; BLAS data (out.bnodes, tri_shade, normals ...) is left alone
+int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t I = meshes.size();
+    if (out.h_inst.size() != I) { set_error("update_tlas: the scene's instance list changed; commit rebuilds it"); return MRT_ERR_STATE; }
+    std::vector<Box> boxes(I);
+    std::vector<uint32_t> live;
+    std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
+    for (size_t i = 0; i < I; i++) {
+        InstanceDev &d = out.h_inst[i];
+        const float *xf = meshes[i].xf;
+        for (int c = 0; c < 4; c++) h_cols[i * 4 + c] = make_float4(xf[c * 4 + 0], xf[c * 4 + 1], xf[c * 4 + 2], 0.0f);
+        float rows[3][4];
+        const bool ok = invert_affine(xf, rows);
+        for (int r = 0; r < 3; r++) d.w2o[r] = ok ? make_float4(rows[r][0], rows[r][1], rows[r][2], rows[r][3]) : make_float4(0, 0, 0, 0);
+        if (ok && d.ntri > 0) { boxes[i] = instance_box(xf, &out.blas_lo[3 * (size_t)d.blas], &out.blas_hi[3 * (size_t)d.blas]); live.push_back((uint32_t)i); }
+    }
+    TlasBuilder tb(boxes);
+    tb.order = live;
+    if (!live.empty()) tb.build(0, (uint32_t)live.size(), NODE_TERM, 1);
+    MRT_HIP(out.inst.alloc(std::max<size_t>(I, 1)));
+    MRT_HIP(out.tlas_index.alloc(std::max<size_t>(tb.order.size(), 1)));
+    MRT_HIP(out.nodes.alloc(std::max<size_t>(tb.nodes.size(), 8))); out.packets_offset = std::max<size_t>(tb.nodes.size(), 8);
+    MRT_HIP(out.inst_cols.alloc(h_cols.size()));
+    if (I) MRT_HIP(hipMemcpyAsync(out.inst.p, out.h_inst.data(), I * sizeof(InstanceDev), hipMemcpyHostToDevice, stream));
+    if (!tb.order.empty()) MRT_HIP(hipMemcpyAsync(out.tlas_index.p, tb.order.data(), tb.order.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!tb.nodes.empty()) MRT_HIP(hipMemcpyAsync(out.nodes.p, tb.nodes.data(), tb.nodes.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols.data(), h_cols.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    out.num_inst = (uint32_t)I;
+    out.stats.bvh_nodes = tb.nodes.size() / 4;          // TLAS nodes; the BLAS nodes are counted in scene_bytes
+    out.stats.max_depth = tb.depth;
+    out.tlas_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MRT_OK;
+}
+
+int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt_in, hipStream_t stream, DeviceScene &out) {
+    const size_t I = meshes.size();
+    BuildOptions opt = opt_in; opt.instancing = 0; opt.wide = 0;        // BLASes are traversed through the rope layout (traverse_instanced.h)
+    // distinct geometries, in order of first use
+    std::vector<int> blas_of(I, -1); std::vector<size_t> blas_src;
+    std::map<size_t, int> seen;
+    size_t T_total = 0, V_total = 0; int max_sub = 1;
+    for (size_t i = 0; i < I; i++) {
+        const size_t src = meshes[i].source >= 0 ? (size_t)meshes[i].source : i;
+        auto it = seen.find(src);
+        if (it == seen.end()) { it = seen.emplace(src, (int)blas_src.size()).first; blas_src.push_back(src); }
+        blas_of[i] = it->second;
+        const HostMesh &g = meshes[src];
+        max_sub = std::max<int>(max_sub, (int)g.sub_indices.size());
+        for (auto &s : g.sub_indices) T_total += s.size() / 3;
+    }
+    if (I >= 65536 || max_sub >= 65536 || T_total >= (1ull << 32)) { set_error("scene too large (limits: 65535 instances / submeshes, 2^32 instanced triangles)"); return MRT_ERR_UNSUPPORTED; }
+    const size_t B = blas_src.size();
+    static const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    // ---- BLASes: each built into a scratch scene, surviving nodes + packets copied into the shared arrays
+    std::vector<DeviceScene> blas(B);
+    std::vector<uint32_t> node_base(B), packet_base(B), ts_base(B), vbase(B), ntri(B);
+    size_t nodes_total = 0, packets_total = 0, ts_total = 0;
+    float build_ms = 0; double sah = 0; uint64_t leaves = 0;
+    out.blas_lo.assign(3 * B, 0.0f); out.blas_hi.assign(3 * B, 0.0f);
+    for (size_t b = 0; b < B; b++) {
+        const HostMesh &g = meshes[blas_src[b]];
+        std::vector<MeshRef> one{MeshRef{&g, identity}};
+        int rc = build_flat(one, opt, stream, blas[b]); if (rc) return rc;
+        node_base[b] = (uint32_t)nodes_total; packet_base[b] = (uint32_t)packets_total; ts_base[b] = (uint32_t)ts_total; vbase[b] = (uint32_t)V_total;
+        ntri[b] = (uint32_t)blas[b].stats.triangles;
+        nodes_total += blas[b].stats.bvh_nodes; packets_total += blas[b].stats.triangles; ts_total += blas[b].stats.triangles; V_total += g.positions.size() / 3;
+        build_ms += blas[b].stats.build_ms; sah += blas[b].stats.sah_cost; leaves += blas[b].stats.bvh_leaves;
+        for (int k = 0; k < 3; k++) { out.blas_lo[3 * b + k] = blas[b].root_lo[k]; out.blas_hi[3 * b + k] = blas[b].root_hi[k]; }
+    }
+    if (int rc = layout_limits(packets_total, nodes_total)) return rc;      // the shared arrays obey the same 24-bit / 32-bit addressing as one flat tree
+    MRT_HIP(out.bnodes.alloc(std::max<size_t>(4 * nodes_total + 3 * packets_total, 8)));
+    out.bpackets_offset = 4 * nodes_total;
+    MRT_HIP(out.tri_shade.alloc(std::max<size_t>(ts_total, 1)));
+    MRT_HIP(out.normals.alloc(std::max<size_t>(V_total, 1)));
+    for (size_t b = 0; b < B; b++) {
+        const size_t nn = blas[b].stats.bvh_nodes, nt = blas[b].stats.triangles, nv = meshes[blas_src[b]].positions.size() / 3;
+        if (nn) MRT_HIP(hipMemcpyAsync(out.bnodes.p + 4 * (size_t)node_base[b], blas[b].nodes.p, nn * 64, hipMemcpyDeviceToDevice, stream));
+        if (nt) MRT_HIP(hipMemcpyAsync(out.bnodes.p + out.bpackets_offset + 3 * (size_t)packet_base[b], blas[b].nodes.p + blas[b].packets_offset, nt * 48, hipMemcpyDeviceToDevice, stream));
+        if (nt) MRT_HIP(hipMemcpyAsync(out.tri_shade.p + ts_base[b], blas[b].tri_shade.p, nt * 16, hipMemcpyDeviceToDevice, stream));
+        if (nv) MRT_HIP(hipMemcpyAsync(out.normals.p + vbase[b], blas[b].normals.p, nv * 16, hipMemcpyDeviceToDevice, stream));
+    }
+    MRT_HIP(hipStreamSynchronize(stream));
+    blas.clear();
+    // ---- per-instance tables: materials / first global triangle id per resource slot (Renderer.swift:128-151), instance rows
+    std::vector<float4> h_base(std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
+    out.h_inst.assign(I, InstanceDev{});
+    uint32_t gid = 0;
+    for (size_t i = 0; i < I; i++) {
+        const HostMesh &g = meshes[meshes[i].source >= 0 ? (size_t)meshes[i].source : i];
+        InstanceDev &d = out.h_inst[i];
+        const int b = blas_of[i];
+        d.node_base = node_base[b]; d.packet_base = packet_base[b]; d.ts_base = ts_base[b]; d.vbase = vbase[b]; d.ntri = ntri[b]; d.blas = (uint32_t)b; d.gid_base = gid;
+        uint32_t tb = gid;
+        for (size_t s = 0; s < g.sub_indices.size(); s++) {
+            h_base[i * max_sub + s] = make_float4(g.sub_materials[s].baseColor.x, g.sub_materials[s].baseColor.y, g.sub_materials[s].baseColor.z, 0.0f);
+            h_gbase[i * max_sub + s] = tb;
+            tb += (uint32_t)(g.sub_indices[s].size() / 3);
+        }
+        gid += ntri[b];
+    }
+    MRT_HIP(out.base_color.alloc(h_base.size())); MRT_HIP(out.geom_base.alloc(h_gbase.size()));
+    MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base.data(), h_base.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase.data(), h_gbase.size() * 4, hipMemcpyHostToDevice, stream));
+    out.wnodes.release(); out.wpackets.release(); out.num_wnodes = 0; out.wide_depth = 0;
+    out.stats = MRTSceneStats{};
+    out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
+    out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
+    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
+    return update_tlas(meshes, stream, out);
+}
+
+}  // namespace mrt

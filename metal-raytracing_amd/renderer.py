@@ -46,15 +46,18 @@ class DeviceScene:
         check(lib.mrt_scene_create(ctx.handle, C.byref(self.handle)))
         for k, v in (options or {}).items():
             check(lib.mrt_scene_set_option(self.handle, k.encode(), float(v)))
-        for mesh in scene.meshes:
+        from .scene import flatten_scene
+        for pos, nrm, xf, subs, source in flatten_scene(scene, share=True):
             mid = C.c_int32()
-            pos = np.ascontiguousarray(mesh.positions, np.float32)
-            nrm = np.ascontiguousarray(mesh.normals, np.float32)
-            xf = np.ascontiguousarray(mesh.transform.reshape(16), np.float32)
+            if source >= 0:                                   # same geometry as an earlier mesh: an instance of it
+                check(lib.mrt_scene_add_instance(self.handle, source, ptr(xf), C.byref(mid)))
+                continue
+            pos = np.ascontiguousarray(pos, np.float32)
+            nrm = np.ascontiguousarray(nrm, np.float32)
             check(lib.mrt_scene_add_mesh(self.handle, ptr(pos), 12, ptr(nrm), 12, pos.shape[0], ptr(xf), C.byref(mid)))
-            for sub in mesh.submeshes:
-                idx = np.ascontiguousarray(sub.indices, np.uint32)
-                check(lib.mrt_mesh_add_submesh(self.handle, mid.value, ptr(idx), idx.shape[0], C.byref(sub.material), None))
+            for idx, mat in subs:
+                idx = np.ascontiguousarray(idx, np.uint32)
+                check(lib.mrt_mesh_add_submesh(self.handle, mid.value, ptr(idx), idx.shape[0], C.byref(mat), None))
         self.set_lights(scene.lights)
         check(lib.mrt_scene_commit(self.handle))
 

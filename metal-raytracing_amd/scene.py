@@ -277,10 +277,22 @@ class GardenScene(Scene):
 SCENES = {"dragon": DragonScene, "dragon_irregular": IrregularDragonScene, "cornell": CornellScene, "dragon4": InstancedDragonScene, "garden": GardenScene}
 
 
-def flatten_scene(scene):
+def _geometry_key(mesh):
+    return (mesh.positions.__array_interface__["data"][0], mesh.normals.__array_interface__["data"][0], mesh.positions.shape[0], tuple(id(s) for s in mesh.submeshes))
+
+
+def flatten_scene(scene, share=False):
     """(positions, normals, transform16, [(indices, Material)]) per mesh, in instance order — the
-    arrays that cross the C ABI (and that tests hand to the oracle as well)."""
-    out = []
-    for mesh in scene.meshes:
-        out.append((mesh.positions, mesh.normals, np.ascontiguousarray(mesh.transform.reshape(16)), [(s.indices, s.material) for s in mesh.submeshes]))
+    arrays that cross the C ABI (and that tests hand to the oracle as well).
+
+    share=True: 5-tuples (..., source) where source is the index of an earlier mesh with the very same vertex arrays and
+    submeshes (Model caches what it loads, so `Model(name="dragon")` x 4 is one geometry) or -1; such entries become
+    mrt_scene_add_instance calls — the instances of BASELINE.json configs[4]."""
+    out, first = [], {}
+    for i, mesh in enumerate(scene.meshes):
+        entry = (mesh.positions, mesh.normals, np.ascontiguousarray(mesh.transform.reshape(16)), [(s.indices, s.material) for s in mesh.submeshes])
+        if share:
+            src = first.setdefault(_geometry_key(mesh), i)
+            entry = entry + (src if src != i else -1,)
+        out.append(entry)
     return out

@@ -39,6 +39,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <memory>
 #include <thread>
 #include <atomic>
 #include <algorithm>
@@ -196,6 +197,7 @@ struct Mesh {
     std::vector<std::vector<uint32_t>> sub_idx;
     std::vector<MRTMaterial> sub_mat;
     uint32_t vbase = 0;
+    int source = -1;            // >= 0: an instance of that mesh (its own arrays are empty)
 };
 
 struct BNode { float lo[3], hi[3]; uint32_t left, right; uint32_t first, count; };
@@ -212,6 +214,13 @@ struct Scene {
     std::vector<BNode> nodes;
     std::vector<uint32_t> order;    // leaf triangle order -> gid
     bool committed = false;
+    // two-level mode (the reference's instance acceleration structure, Renderer.swift:193-213): one object-space scene per distinct
+    // mesh, a world->object matrix and a first global triangle id per instance; `tris` / `nodes` above stay empty
+    bool instancing = false;
+    std::vector<std::unique_ptr<Scene>> blas;
+    struct Inst { int blas; bool valid; float rows[3][4]; uint32_t gid_base, ntri; };
+    std::vector<Inst> insts;
+    uint64_t total_tris = 0;
 };
 
 static inline bool tri_test(const Tri &tr, V3 o, V3 d, float tmin, float tmax, float *t_out, float *U_out, float *V_out, float *ad_out) {
@@ -340,30 +349,49 @@ struct Builder {
     }
 };
 
+static bool invert_affine(const M4 &m, float rows[3][4]);
 static void scene_commit(Scene &s) {
-    s.tris.clear(); s.refs.clear(); s.normals.clear(); s.mats.clear(); s.nodes.clear(); s.order.clear();
+    s.tris.clear(); s.refs.clear(); s.normals.clear(); s.mats.clear(); s.nodes.clear(); s.order.clear(); s.blas.clear(); s.insts.clear();
     s.maxSub = 0;
-    for (auto &m : s.meshes) s.maxSub = std::max<int>(s.maxSub, (int)m.sub_idx.size());
+    auto geom = [&](size_t mi) -> const Mesh & { return s.meshes[mi].source >= 0 ? s.meshes[(size_t)s.meshes[mi].source] : s.meshes[mi]; };
+    for (size_t mi = 0; mi < s.meshes.size(); mi++) s.maxSub = std::max<int>(s.maxSub, (int)geom(mi).sub_idx.size());
     if (s.maxSub < 1) s.maxSub = 1;
     s.mats.assign(s.meshes.size() * (size_t)s.maxSub, MRTMaterial{});
+    std::vector<int> blas_of_src(s.meshes.size(), -1);
     uint32_t vbase = 0;
     for (size_t mi = 0; mi < s.meshes.size(); mi++) {
         Mesh &m = s.meshes[mi];
+        const Mesh &g = geom(mi);
         m.vbase = vbase;
-        for (auto &n : m.nrm) s.normals.push_back(n);
-        std::vector<V3> wp(m.pos.size());
-        for (size_t i = 0; i < m.pos.size(); i++) wp[i] = xform_point(m.xf, m.pos[i]);
-        for (size_t g = 0; g < m.sub_idx.size(); g++) {
-            s.mats[mi * s.maxSub + g] = m.sub_mat[g];
-            const auto &ix = m.sub_idx[g];
+        for (auto &n : g.nrm) s.normals.push_back(n);                       // the shading tables stay per instance in both modes
+        std::vector<V3> wp;
+        if (!s.instancing) { wp.resize(g.pos.size()); for (size_t i = 0; i < g.pos.size(); i++) wp[i] = xform_point(m.xf, g.pos[i]); }
+        const uint32_t gid_base = (uint32_t)s.refs.size();
+        for (size_t gi = 0; gi < g.sub_idx.size(); gi++) {
+            s.mats[mi * s.maxSub + gi] = g.sub_mat[gi];
+            const auto &ix = g.sub_idx[gi];
             for (size_t p = 0; p + 2 < ix.size(); p += 3) {
-                Tri t; t.v0 = wp[ix[p]]; t.e1 = wp[ix[p + 1]] - t.v0; t.e2 = wp[ix[p + 2]] - t.v0;
-                s.tris.push_back(t);
-                s.refs.push_back(TriRef{vbase + ix[p], vbase + ix[p + 1], vbase + ix[p + 2], (int32_t)mi, (int32_t)g, (int32_t)(p / 3)});
+                if (!s.instancing) { Tri t; t.v0 = wp[ix[p]]; t.e1 = wp[ix[p + 1]] - t.v0; t.e2 = wp[ix[p + 2]] - t.v0; s.tris.push_back(t); }
+                s.refs.push_back(TriRef{vbase + ix[p], vbase + ix[p + 1], vbase + ix[p + 2], (int32_t)mi, (int32_t)gi, (int32_t)(p / 3)});
             }
         }
-        vbase += (uint32_t)m.pos.size();
+        vbase += (uint32_t)g.pos.size();
+        if (s.instancing) {
+            const size_t src = m.source >= 0 ? (size_t)m.source : mi;
+            if (blas_of_src[src] < 0) {                                      // object-space scene of this geometry: one mesh under the identity
+                blas_of_src[src] = (int)s.blas.size();
+                std::unique_ptr<Scene> b(new Scene());
+                Mesh bm; bm.pos = g.pos; bm.nrm = g.nrm; bm.xf = m4_identity(); bm.sub_idx = g.sub_idx; bm.sub_mat = g.sub_mat;
+                b->meshes.push_back(std::move(bm));
+                scene_commit(*b);
+                s.blas.push_back(std::move(b));
+            }
+            Scene::Inst in{}; in.blas = blas_of_src[src]; in.gid_base = gid_base; in.ntri = (uint32_t)s.refs.size() - gid_base;
+            in.valid = invert_affine(m.xf, in.rows);
+            s.insts.push_back(in);
+        }
     }
+    s.total_tris = s.refs.size();
     size_t T = s.tris.size();
     s.order.resize(T);
     for (size_t i = 0; i < T; i++) s.order[i] = (uint32_t)i;
@@ -417,6 +445,69 @@ static bool any_brute(const Scene &s, V3 o, V3 d, float tmin, float tmax) {
     return false;
 }
 
+// ---------------------------------------------------------------- two-level (instanced) scenes
+// The closed-source intersector walks an instance acceleration structure and takes the ray into each instance's object space; its
+// arithmetic is unknown.  Here: rows of [A^-1 | -A^-1 t] evaluated in double in a fixed operation order and rounded to float once, the ray
+// taken into object space with the fused mrt-math form and its direction NOT renormalised (so t stays the world distance), triangles
+// tested in object space, closest hit = global minimum t with ties to the lowest global triangle id (instance-major numbering).
+static bool invert_affine(const M4 &m, float rows[3][4]) {
+    const float *xf = &m.c[0][0];
+    const double a00 = xf[0], a10 = xf[1], a20 = xf[2], a01 = xf[4], a11 = xf[5], a21 = xf[6], a02 = xf[8], a12 = xf[9], a22 = xf[10];
+    const double tx = xf[12], ty = xf[13], tz = xf[14];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double det = a00 * c00 + a01 * c10 + a02 * c20;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double i[3][3] = {{c00 / det, c01 / det, c02 / det}, {c10 / det, c11 / det, c12 / det}, {c20 / det, c21 / det, c22 / det}};
+    for (int r = 0; r < 3; r++) {
+        rows[r][0] = (float)i[r][0]; rows[r][1] = (float)i[r][1]; rows[r][2] = (float)i[r][2];
+        rows[r][3] = (float)(-(i[r][0] * tx + i[r][1] * ty + i[r][2] * tz));
+    }
+    return true;
+}
+static V3 to_object_point(const float r[3][4], V3 p) {
+    return v3(fmaf(r[0][2], p.z, fmaf(r[0][1], p.y, r[0][0] * p.x)) + r[0][3],
+              fmaf(r[1][2], p.z, fmaf(r[1][1], p.y, r[1][0] * p.x)) + r[1][3],
+              fmaf(r[2][2], p.z, fmaf(r[2][1], p.y, r[2][0] * p.x)) + r[2][3]);
+}
+static V3 to_object_dir(const float r[3][4], V3 v) {
+    return v3(fmaf(r[0][2], v.z, fmaf(r[0][1], v.y, r[0][0] * v.x)),
+              fmaf(r[1][2], v.z, fmaf(r[1][1], v.y, r[1][0] * v.x)),
+              fmaf(r[2][2], v.z, fmaf(r[2][1], v.y, r[2][0] * v.x)));
+}
+static Hit closest_instanced(const Scene &s, V3 o, V3 d, float tmin, float tmax, bool brute) {
+    Hit h; h.t = tmax; h.U = h.V = 0; h.ad = 1; h.gid = 0xFFFFFFFFu;
+    for (const auto &in : s.insts) {
+        if (!in.valid || in.ntri == 0) continue;
+        const V3 oo = to_object_point(in.rows, o), dd = to_object_dir(in.rows, d);
+        const float lim = h.gid == 0xFFFFFFFFu ? tmax : h.t;
+        const Scene &b = *s.blas[in.blas];
+        const Hit hb = brute ? closest_brute(b, oo, dd, tmin, lim) : closest_bvh(b, oo, dd, tmin, lim);
+        if (hb.gid == 0xFFFFFFFFu) continue;
+        // instances are visited in ascending order of global id: an equal t further on never wins the tie
+        if (h.gid == 0xFFFFFFFFu || hb.t < h.t) { h = hb; h.gid = in.gid_base + hb.gid; }
+    }
+    return h;
+}
+static bool any_instanced(const Scene &s, V3 o, V3 d, float tmin, float tmax, bool brute) {
+    for (const auto &in : s.insts) {
+        if (!in.valid || in.ntri == 0) continue;
+        const V3 oo = to_object_point(in.rows, o), dd = to_object_dir(in.rows, d);
+        const Scene &b = *s.blas[in.blas];
+        if (brute ? any_brute(b, oo, dd, tmin, tmax) : any_bvh(b, oo, dd, tmin, tmax)) return true;
+    }
+    return false;
+}
+static Hit scene_closest(const Scene &s, V3 o, V3 d, float tmin, float tmax, bool brute) {
+    if (s.instancing) return closest_instanced(s, o, d, tmin, tmax, brute);
+    return brute ? closest_brute(s, o, d, tmin, tmax) : closest_bvh(s, o, d, tmin, tmax);
+}
+static bool scene_any(const Scene &s, V3 o, V3 d, float tmin, float tmax, bool brute) {
+    if (s.instancing) return any_instanced(s, o, d, tmin, tmax, brute);
+    return brute ? any_brute(s, o, d, tmin, tmax) : any_bvh(s, o, d, tmin, tmax);
+}
+
 // ---------------------------------------------------------------- the kernel (Raytracing.metal:156-405)
 struct Counters { uint64_t closest = 0, shadow = 0; };
 
@@ -439,7 +530,7 @@ static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t sample_inde
     V3 color = v3(1, 1, 1), accumulated = v3(0, 0, 0);                     // :226-227
     for (int bounce = 0; bounce < max_bounces; bounce++) {                 // :237
         cnt.closest++;
-        Hit h = brute ? closest_brute(s, org, dir, 0.0f, INF) : closest_bvh(s, org, dir, 0.0f, INF);   // :244
+        Hit h = scene_closest(s, org, dir, 0.0f, INF, brute);   // :244
         if (dump) { float *d = dump + bounce * 16; d[0] = org.x; d[1] = org.y; d[2] = org.z; d[3] = dir.x; d[4] = dir.y; d[5] = dir.z;
                     d[6] = h.gid == 0xFFFFFFFFu ? -1.0f : h.t; uint32_t g = h.gid; memcpy(&d[7], &g, 4); }
         if (h.gid == 0xFFFFFFFFu) break;                                   // :246-247
@@ -493,7 +584,7 @@ static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t sample_inde
             V3 so = P + n * 1e-3f;                                         // :350
             float smax = ldist - 1e-3f;                                    // :356
             cnt.shadow++;
-            bool occ = brute ? any_brute(s, so, ldir, 0.0f, smax) : any_bvh(s, so, ldir, 0.0f, smax);   // :367
+            bool occ = scene_any(s, so, ldir, 0.0f, smax, brute);   // :367
             shadowed = occ ? 1 : 0;
             if (!occ) accumulated = accumulated + lcol * color;            // :371-373
         }
@@ -592,9 +683,23 @@ int orc_mesh_add_submesh(void *sp, int mesh, const uint32_t *idx, size_t ntris, 
     m.sub_idx.emplace_back(idx, idx + ntris * 3); m.sub_mat.push_back(*mat); s->committed = false;
     return (int)m.sub_idx.size() - 1;
 }
+int orc_scene_add_instance(void *sp, int source, const float *xf16) {
+    Scene *s = (Scene *)sp; if (source < 0 || source >= (int)s->meshes.size()) return -1;
+    Mesh m; m.source = s->meshes[source].source >= 0 ? s->meshes[source].source : source;
+    memcpy(&m.xf, xf16, 64);
+    m.xf.c[0][3] = m.xf.c[1][3] = m.xf.c[2][3] = 0; m.xf.c[3][3] = 1;
+    s->meshes.push_back(std::move(m)); s->committed = false;
+    return (int)s->meshes.size() - 1;
+}
+void orc_scene_set_instancing(void *sp, int on) { Scene *s = (Scene *)sp; s->instancing = on != 0; s->committed = false; }
+void orc_scene_set_transform(void *sp, int mesh, const float *xf16) {
+    Scene *s = (Scene *)sp; if (mesh < 0 || mesh >= (int)s->meshes.size()) return;
+    memcpy(&s->meshes[mesh].xf, xf16, 64);
+    M4 &x = s->meshes[mesh].xf; x.c[0][3] = x.c[1][3] = x.c[2][3] = 0; x.c[3][3] = 1; s->committed = false;
+}
 void orc_scene_set_lights(void *sp, const MRTLight *l, int n) { Scene *s = (Scene *)sp; s->lights.assign(l, l + n); }
 void orc_scene_commit(void *sp) { scene_commit(*(Scene *)sp); }
-uint64_t orc_scene_triangles(void *sp) { return ((Scene *)sp)->tris.size(); }
+uint64_t orc_scene_triangles(void *sp) { return ((Scene *)sp)->total_tris; }
 uint64_t orc_scene_nodes(void *sp) { return ((Scene *)sp)->nodes.size(); }
 
 static void fill_isect(const Scene *s, const Hit &h, MRTIntersection *o) {
@@ -608,7 +713,7 @@ void orc_intersect_closest(void *sp, const MRTRay *rays, size_t n, MRTIntersecti
     Scene *s = (Scene *)sp;
     for (size_t i = 0; i < n; i++) {
         V3 o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]), d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
-        Hit h = brute ? closest_brute(*s, o, d, rays[i].min_distance, rays[i].max_distance) : closest_bvh(*s, o, d, rays[i].min_distance, rays[i].max_distance);
+        Hit h = scene_closest(*s, o, d, rays[i].min_distance, rays[i].max_distance, brute != 0);
         fill_isect(s, h, &out[i]);
     }
 }
@@ -616,7 +721,7 @@ void orc_intersect_any(void *sp, const MRTRay *rays, size_t n, int32_t *occ, int
     Scene *s = (Scene *)sp;
     for (size_t i = 0; i < n; i++) {
         V3 o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]), d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
-        occ[i] = (brute ? any_brute(*s, o, d, rays[i].min_distance, rays[i].max_distance) : any_bvh(*s, o, d, rays[i].min_distance, rays[i].max_distance)) ? 1 : 0;
+        occ[i] = scene_any(*s, o, d, rays[i].min_distance, rays[i].max_distance, brute != 0) ? 1 : 0;
     }
 }
 

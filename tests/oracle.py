@@ -36,6 +36,9 @@ def lib():
         l.orc_mesh_add_submesh.argtypes = [P, I, P, C.c_size_t, P]
         l.orc_scene_set_lights.argtypes = [P, P, I]
         l.orc_scene_commit.argtypes = [P]
+        l.orc_scene_add_instance.argtypes = [P, I, P]
+        l.orc_scene_set_instancing.argtypes = [P, I]
+        l.orc_scene_set_transform.argtypes = [P, I, P]
         l.orc_scene_triangles.argtypes = [P]; l.orc_scene_triangles.restype = C.c_uint64
         l.orc_scene_nodes.argtypes = [P]; l.orc_scene_nodes.restype = C.c_uint64
         l.orc_intersect_closest.argtypes = [P, P, C.c_size_t, P, I]
@@ -70,12 +73,20 @@ def _p(a):
 class OracleScene:
     """Built from the same arrays that cross the product's C ABI (metal_raytracing_amd.flatten_scene)."""
 
-    def __init__(self, meshes, lights):
+    def __init__(self, meshes, lights, instancing=False):
+        """meshes: flatten_scene(scene) 4-tuples, or flatten_scene(scene, share=True) 5-tuples whose last field names the mesh an
+        entry is an instance of.  instancing=True: the two-level restatement (object-space intersection per instance)."""
         l = lib()
         self.h = C.c_void_p(l.orc_scene_create())
         self._keep = []
-        for pos, nrm, xf, subs in meshes:
-            pos = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(nrm, np.float32); xf = np.ascontiguousarray(xf, np.float32)
+        l.orc_scene_set_instancing(self.h, 1 if instancing else 0)
+        for entry in meshes:
+            pos, nrm, xf, subs = entry[:4]
+            xf = np.ascontiguousarray(xf, np.float32)
+            if len(entry) > 4 and entry[4] >= 0:
+                l.orc_scene_add_instance(self.h, int(entry[4]), _p(xf))
+                continue
+            pos = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(nrm, np.float32)
             mid = l.orc_scene_add_mesh(self.h, _p(pos), _p(nrm), pos.shape[0], _p(xf))
             for idx, mat in subs:
                 idx = np.ascontiguousarray(idx, np.uint32)
@@ -85,6 +96,11 @@ class OracleScene:
             arr = (type(lights[0]) * n)(*lights)
             l.orc_scene_set_lights(self.h, C.byref(arr), n)
         l.orc_scene_commit(self.h)
+
+    def set_transform(self, mesh_id, xf16):
+        xf = np.ascontiguousarray(np.asarray(xf16, np.float32).reshape(16))
+        lib().orc_scene_set_transform(self.h, int(mesh_id), _p(xf))
+        lib().orc_scene_commit(self.h)
 
     @property
     def triangles(self):

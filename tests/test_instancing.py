@@ -1,0 +1,143 @@
+"""Two-level scenes: one BLAS per distinct mesh shared by its instances + a TLAS (scene option instancing = 1),
+against (a) the oracle's two-level restatement — bit for bit — and (b) the flattened scene — within the stated tolerance, since the
+triangle test then runs in object space with different roundings."""
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_parity, TOL_ABS
+
+
+def _scene(mrt, size):
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            self.models = [
+                mrt.Model(name="plane", position=[0, 0, 0], scale=10),
+                mrt.Model(name="sphere", position=[-1.2, 0.0, 0.4], scale=1),
+                mrt.Model(name="sphere", position=[1.4, 0.0, -0.2], rotation=[0.3, 1.1, -0.4], scale=1.7),
+                mrt.Model(name="teapot", position=[0.1, 0.0, 1.6], rotation=[0, 0.6, 0], scale=0.01),
+                mrt.Model(name="teapot", position=[-0.6, 0.0, -1.0], rotation=[0, -1.3, 0], scale=0.013),
+                mrt.Model(name="sphere", position=[0.2, 1.1, 0.8], scale=0.4),
+            ]
+    return S(size)
+
+
+def _rays(rng, n):
+    o = np.array([0.0, 1.2, 4.5]) + rng.normal(size=(n, 3)) * 0.4
+    t = np.c_[rng.uniform(-2.5, 2.5, n), rng.uniform(0, 1.8, n), rng.uniform(-1.5, 2.0, n)]
+    d = t - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((n, 8), np.float32); r[:, 0:3] = o; r[:, 4:7] = d; r[:, 7] = np.inf
+    return r
+
+
+def test_shared_geometry_is_detected_and_oracle_instancing_matches_flattening(mrt, orc):
+    sc = _scene(mrt, (96, 64))
+    shared = mrt.flatten_scene(sc, share=True)
+    assert [e[4] for e in shared] == [-1, -1, 1, -1, 3, 1]            # spheres are instances of mesh 1, the second teapot of mesh 3
+    flat = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
+    two = orc.OracleScene(shared, sc.lights, instancing=True)
+    assert flat.triangles == two.triangles
+    rays = _rays(np.random.default_rng(5), 4000)
+    a, b = flat.intersect_closest(rays), two.intersect_closest(rays)
+    bb = two.intersect_closest(rays, brute=True)
+    for f in a.dtype.names:
+        assert np.array_equal(b[f], bb[f]), f                        # the per-BLAS BVH is exact
+    same = (a["type"] == b["type"]) & (a["instance_id"] == b["instance_id"]) & (a["geometry_id"] == b["geometry_id"]) & (a["primitive_id"] == b["primitive_id"])
+    assert same.mean() > 0.998                                        # object-space vs world-space rounding may flip a grazing hit
+    hit = same & (a["type"] == 1)
+    assert hit.sum() > 1000
+    assert np.allclose(a["distance"][hit], b["distance"][hit], rtol=2e-5, atol=1e-6)
+    assert np.abs(a["u"][hit] - b["u"][hit]).max() < 1e-3 and np.abs(a["v"][hit] - b["v"][hit]).max() < 1e-3
+    rays[:, 7] = 3.0
+    assert (flat.intersect_any(rays) == two.intersect_any(rays)).mean() > 0.998
+    # images: the formal bar of SURVEY §8(d)
+    w, h = 96, 64
+    fa = orc.OracleRenderer(flat, w, h, camera=sc.camera); fa.render(2)
+    fb = orc.OracleRenderer(two, w, h, camera=sc.camera); fb.render(2)
+    d = np.abs(fa.accumulation()[..., :3].astype(np.float64) - fb.accumulation()[..., :3])
+    assert (d.max(-1) <= TOL_ABS).mean() >= 0.995 and np.sqrt((d ** 2).sum(-1).mean()) <= 2e-3
+    ca, cb = fa.counters(), fb.counters()
+    assert abs(ca[0] - cb[0]) <= 0.002 * ca[0] and abs(ca[1] - cb[1]) <= 0.002 * ca[1]
+
+
+@pytest.mark.gpu
+def test_two_level_gpu_matches_two_level_oracle_bit_for_bit(mrt, orc, gpu_ctx):
+    w, h = 160, 96
+    sc = _scene(mrt, (w, h))
+    two = orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+    st = r.device_scene.stats
+    assert st.instances == 6 and st.triangles == two.triangles
+    rays = _rays(np.random.default_rng(6), 20000)
+    g, o = r.device_scene.intersect_closest(rays), two.intersect_closest(rays)
+    for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
+        assert np.array_equal(g[f], o[f]), f
+    rays[:, 7] = 3.0
+    assert np.array_equal(r.device_scene.intersect_any(rays), two.intersect_any(rays))
+    r.draw(3, wait=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(3)
+    assert_parity(r.accumulation(), ref.accumulation())
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    # against the flattened scene on the GPU: the formal tolerance
+    f = mrt.Renderer((w, h), sc, ctx=gpu_ctx); f.draw(3, wait=True)
+    d = np.abs(f.accumulation()[..., :3].astype(np.float64) - r.accumulation()[..., :3])
+    assert (d.max(-1) <= TOL_ABS).mean() >= 0.995
+    f.close(); r.close()
+
+
+@pytest.mark.gpu
+def test_transform_change_rebuilds_only_the_tlas(mrt, orc, gpu_ctx):
+    """Animated transforms (SURVEY §8 f-3 'refit'): set_instance_transform + commit on a two-level scene leaves the BLASes alone."""
+    w, h = 128, 80
+    sc = _scene(mrt, (w, h))
+    two = orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+    blas_ms = r.device_scene.stats.build_ms
+    xf = mrt.make_transform([1.0, 0.3, 0.5], [0.2, 2.0, 0.1], 1.2)
+    t0 = time.perf_counter()
+    r.device_scene.set_instance_transform(2, xf); r.device_scene.commit()
+    dt = (time.perf_counter() - t0) * 1e3
+    assert r.device_scene.stats.build_ms == blas_ms                   # no BLAS was rebuilt
+    assert dt < 20.0, f"TLAS update took {dt:.2f} ms"
+    two.set_transform(2, xf.reshape(16))
+    r.frameIndex = 0; r.draw(2, wait=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(2)
+    got = r.accumulation()
+    # the renderer kept accumulating into its previous target: frame 0 overwrites it (Raytracing.metal:395), so this is a fresh image
+    assert_parity(got, ref.accumulation())
+    r.close()
+
+
+@pytest.mark.gpu
+def test_c5_as_one_blas_times_four_instances(mrt, orc, gpu_ctx):
+    """BASELINE configs[4] built the instanced way: ONE dragon BLAS shared by four instances (+ the rest of DragonScene)."""
+    w, h = 320, 180
+    sc = mrt.InstancedDragonScene((w, h))
+    shared = mrt.flatten_scene(sc, share=True)
+    assert sum(1 for e in shared if e[4] >= 0) == 4                    # three extra dragons + the second sphere
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+    st = r.device_scene.stats
+    assert st.triangles == 885194 + 3 * 871414 and st.instances == 10
+    flat_bytes = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    assert st.scene_bytes < 0.45 * flat_bytes.device_scene.stats.scene_bytes      # one dragon's worth of BLAS, not four
+    flat_bytes.close()
+    r.draw(2, wait=True)
+    two = orc.OracleScene(shared, sc.lights, instancing=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(2)
+    assert_parity(r.accumulation(), ref.accumulation())
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    r.close()
+
+
+@pytest.mark.gpu
+def test_flattened_instances_equal_separately_added_meshes(mrt, orc, gpu_ctx):
+    """instancing = 0 with mrt_scene_add_instance (shared host arrays) is the same flattened scene bit for bit."""
+    w, h = 96, 64
+    sc = _scene(mrt, (w, h))
+    a = mrt.Renderer((w, h), sc, ctx=gpu_ctx); a.draw(2, wait=True)
+    flat = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
+    ref = orc.OracleRenderer(flat, w, h, camera=sc.camera); ref.render(2)
+    assert_parity(a.accumulation(), ref.accumulation(), exact_frac=1.0)
+    a.close()
