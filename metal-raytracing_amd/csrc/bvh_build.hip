@@ -583,7 +583,7 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
 SceneView DeviceScene::view() const {
     SceneView v{};
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
-    v.base_color = base_color.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
+    v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.inst = inst.p; v.tlas_index = tlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
@@ -629,6 +629,12 @@ int layout_limits(uint64_t triangles, uint64_t nodes) {
     return MRT_OK;
 }
 
+void pack_material(const MRTMaterial &m, float4 *out3) {
+    out3[0] = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, m.dissolve);
+    out3[1] = make_float4(m.specular.x, m.specular.y, m.specular.z, m.specularExponent);
+    out3[2] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.refractionIndex);
+}
+
 int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
     out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.bnodes.release(); out.h_inst.clear();
@@ -659,6 +665,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     std::vector<SubRec> recs;
     std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
     std::vector<float4> h_base(std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
+    std::vector<float4> h_mat(3 * std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
     std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
     size_t vb = 0, tb = 0, ib = 0;
     for (size_t mi = 0; mi < I; mi++) {
@@ -670,6 +677,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         for (size_t g = 0; g < m.sub_indices.size(); g++) {
             const auto &ix = m.sub_indices[g];
             h_base[mi * max_sub + g] = make_float4(m.sub_materials[g].baseColor.x, m.sub_materials[g].baseColor.y, m.sub_materials[g].baseColor.z, 0.0f);
+            pack_material(m.sub_materials[g], &h_mat[3 * (mi * max_sub + g)]);
             h_gbase[mi * max_sub + g] = (uint32_t)tb;
             if (ix.empty()) continue;
             memcpy(&h_idx[ib], ix.data(), ix.size() * 4);
@@ -683,7 +691,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.stats.max_leaf_tris = opt.max_leaf;
 
     MRT_HIP(out.normals.alloc(h_nrm.size()));
-    MRT_HIP(out.base_color.alloc(h_base.size()));
+    MRT_HIP(out.base_color.alloc(h_base.size())); MRT_HIP(out.materials.alloc(h_mat.size()));
+    MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat.data(), h_mat.size() * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(out.geom_base.alloc(h_gbase.size()));
     MRT_HIP(out.inst_cols.alloc(h_cols.size()));
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(T, 1)));

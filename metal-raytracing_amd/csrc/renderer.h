@@ -44,6 +44,7 @@ struct Renderer {
     int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
+    bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
     bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel

@@ -312,14 +312,16 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
+template <bool MATERIALS>
 __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
                                               float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon,
                                               unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */,
-                                              float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */) {
-    __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES];
+                                              float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */,
+                                              float4 *__restrict__ sample /* MATERIALS: emitted radiance is added here */) {
+    __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES];
     __shared__ unsigned long long blk_base;
     // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
     const uint32_t sub = sample_primary ? blockIdx.y : 0u;
@@ -338,8 +340,9 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
     bool want_shadow = false, want_next = false;
-    f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0);
+    f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0), norg = mk3(0, 0, 0);
     float ldist = 0.0f; uint32_t pix = 0;
+    bool special = false;                // next ray comes from a specular / dielectric lobe (materials extension): queued behind the diffuse ones
     if (active) {
         float4 A, B, C;
         if (sample_primary) {
@@ -366,6 +369,63 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
         int idx = (int)(seeds[pix] + fp.sampleIndex);                  // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
+        norg = P + nrm * 1e-3f;                                          // :350, :390
+        color = mk3(C);
+        bool diffuse = true;
+        if (MATERIALS) {
+            // the materials extension (renderer option materials = 1; not in raytracingKernel — README.md:8 lists it as open work; the
+            // fields are ShaderTypes.h:99-107).  Restates oracle/mrt_oracle.cpp trace_pixel `if (materials)` expression by expression.
+            const float4 *__restrict__ mp = s.materials + 3 * (size_t)(inst * (uint32_t)s.max_sub + geom);
+            const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            const f3 em = color * mk3(m2);
+            const float4 acc = sample_primary ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : sample[pix];
+            sample[pix] = make_float4(acc.x + em.x, acc.y + em.y, acc.z + em.z, 0.0f);
+            const float ul = halton_dev(idx, 2 + 5 * fp.max_bounces + fp.bounce);
+            const f3 spec = mk3(m1);
+            const float kd = fmaxf(surf.x, fmaxf(surf.y, surf.z)), ks = fmaxf(spec.x, fmaxf(spec.y, spec.z));
+            const float dis = m0.w, ns = m1.w, ni = m2.w;
+            const float trn = (dis > 0.0f && dis < 1.0f && ni > 0.0f) ? 1.0f - dis : 0.0f;
+            if (ul < trn) {                                              // dielectric interface
+                const float u2 = ul / trn;
+                const f3 dir = mk3(B);
+                const float cd = dot3(dir, nrm);
+                const bool entering = cd < 0.0f;
+                const f3 nn = entering ? nrm : neg3(nrm);
+                const float eta = entering ? 1.0f / ni : ni;
+                const float cosi = entering ? -cd : cd;
+                const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+                float r0 = (1.0f - ni) / (1.0f + ni); r0 = r0 * r0;
+                float F = 1.0f, cost = 0.0f;
+                if (sin2t < 1.0f) { cost = __builtin_sqrtf(1.0f - sin2t); const float c = entering ? cosi : cost; const float x = 1.0f - c; const float x2 = x * x; F = r0 + (1.0f - r0) * ((x2 * x2) * x); }
+                f3 nd;
+                if (u2 < F) { nd = dir + nn * (2.0f * cosi); norg = P + nn * 1e-3f; }
+                else { nd = dir * eta + nn * (eta * cosi - cost); norg = P + nn * -1e-3f; }
+                ndir = normalize3(nd);
+                diffuse = false; special = true;
+                want_next = fp.bounce + 1 < fp.max_bounces;
+            } else {
+                const float ud = trn > 0.0f ? (ul - trn) / (1.0f - trn) : ul;
+                const float ps = (ks > 0.0f && ns > 0.0f) ? ks / (ks + kd) : 0.0f;
+                if (ud < ps) {                                           // specular lobe
+                    const float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);
+                    const float a2 = 2.0f / (ns + 2.0f);
+                    const float ct2 = (1.0f - hy) / (1.0f + (a2 - 1.0f) * hy);
+                    const float ct = __builtin_sqrtf(ct2), st = __builtin_sqrtf(1.0f - ct2);
+                    float sp_, cp_; sincos_2pi_dev(hx, sp_, cp_);
+                    const f3 hw = align_hemisphere_dev(mk3(st * cp_, ct, st * sp_), nrm);
+                    const f3 dir = mk3(B);
+                    const float dh = dot3(dir, hw);
+                    const f3 wi = dir - hw * (2.0f * dh);
+                    diffuse = false; special = true;
+                    if (dot3(wi, nrm) > 0.0f) {
+                        color = color * (spec * (1.0f / ps));
+                        ndir = normalize3(wi);
+                        want_next = fp.bounce + 1 < fp.max_bounces;
+                    }                                                    // else: sampled below the surface, the path is absorbed
+                } else if (ps > 0.0f) surf = surf * (1.0f / (1.0f - ps));
+            }
+        }
+        if (diffuse) {
         float ls = halton_dev(idx, dim0 + 0);                            // :272
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
         const LightDev L = s.lights[li];
@@ -408,15 +468,19 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
             float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
             ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
         }
+        }
     }
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long m_sh = __ballot(want_shadow), m_nx = __ballot(want_next);
-    if (lane == 0) { w_shadow[wv] = (uint32_t)__popcll(m_sh); w_next[wv] = (uint32_t)__popcll(m_nx); }
+    // MATERIALS: the block's next rays are queued by lobe class — diffuse first, specular / refracted behind them — so that the waves of the
+    // next traversal launch see rays of one kind (README.md:9 "sorting ... to reduce divergence"; the reference's stub is Raytracing.metal:178-197)
+    const unsigned long long m_sh = __ballot(want_shadow), m_nx = __ballot(want_next && !(MATERIALS && special)), m_sp = MATERIALS ? __ballot(want_next && special) : 0ull;
+    if (lane == 0) { w_shadow[wv] = (uint32_t)__popcll(m_sh); w_next[wv] = (uint32_t)__popcll(m_nx); if (MATERIALS) w_spec[wv] = (uint32_t)__popcll(m_sp); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tn = 0, ts = 0;
+        uint32_t tn = 0, ts = 0, tp = 0;
         for (int k = 0; k < SHADE_WAVES; k++) { uint32_t a = w_next[k], b = w_shadow[k]; w_next[k] = tn; w_shadow[k] = ts; tn += a; ts += b; }
-        blk_base = (tn | ts) ? atomicAdd(count_out, ((unsigned long long)ts << 32) | tn) : 0ull;
+        if (MATERIALS) for (int k = 0; k < SHADE_WAVES; k++) { uint32_t a = w_spec[k]; w_spec[k] = tn + tp; tp += a; }
+        blk_base = (tn | ts | tp) ? atomicAdd(count_out, ((unsigned long long)ts << 32) | (tn + tp)) : 0ull;
     }
     __syncthreads();
     const unsigned long long base = blk_base;
@@ -430,9 +494,9 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         scon[ss] = make_float4(con.x, con.y, con.z, 0.0f);
     }
     if (want_next) {
-        uint32_t ns = (uint32_t)base + w_next[wv] + (uint32_t)__popcll(m_nx & lt);
-        f3 no = P + nrm * 1e-3f;                                         // :390
-        nrayA[ns] = make_float4(no.x, no.y, no.z, __builtin_inff());
+        const bool sp = MATERIALS && special;
+        uint32_t ns = (uint32_t)base + (sp ? w_spec[wv] + (uint32_t)__popcll(m_sp & lt) : w_next[wv] + (uint32_t)__popcll(m_nx & lt));
+        nrayA[ns] = make_float4(norg.x, norg.y, norg.z, __builtin_inff());      // :390
         nrayB[ns] = make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix));   // :391
         nthr[ns] = make_float4(color.x, color.y, color.z, 0.0f);
     }
@@ -697,7 +761,7 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     const bool two_level = sv.num_inst > 0;          // instanced scene: the fused pipeline on the two-level rope kernels
-    const bool wide = use_wide && sv.num_wnodes > 0 && !two_level;
+    const bool wide = use_wide && sv.num_wnodes > 0 && !two_level && !materials;
     if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
         const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
@@ -721,7 +785,7 @@ int Renderer::render(int n_frames) {                                   // Render
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
     // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
     // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
-    const int batch_max = ((fused || two_level) && !wide) ? alloc_batch : 1;
+    const int batch_max = ((fused || two_level || materials) && !wide) ? alloc_batch : 1;
     fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
     hipEvent_t last_acc = nullptr;
     int pass = 0;
@@ -734,7 +798,7 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
-        if ((fused || two_level) && !wide) {
+        if ((fused || two_level || materials) && !wide) {
             // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
@@ -762,8 +826,10 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                launch_timed(timed(MRT_KERNEL_SHADE), k_shade, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr);
+                if (materials) launch_timed(timed(MRT_KERNEL_SHADE), k_shade<true>, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
+                else launch_timed(timed(MRT_KERNEL_SHADE), k_shade<false>, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
@@ -796,8 +862,8 @@ int Renderer::render(int n_frames) {                                   // Render
                 if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
                 if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
-                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr);
+                hipLaunchKernelGGL(k_shade<false>, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
+                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 q = 1 - q;

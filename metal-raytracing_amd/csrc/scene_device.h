@@ -78,6 +78,7 @@ struct SceneView {           // passed by value to kernels
     const uint4 *tri_shade;      // per gid
     const float4 *normals;       // object space, concatenated over meshes (float3 stride 16, Mesh.swift:27-29)
     const float4 *base_color;    // per resource slot = instance*max_sub + geometry (Renderer.swift:139)
+    const float4 *materials;     // per resource slot, 3 x float4: baseColor | dissolve, specular | specularExponent, emission | refractionIndex (materials extension)
     const float4 *inst_cols;     // 3 x float4 per instance: columns 0..2 of the 4x3 transform
     const uint32_t *geom_base;   // per resource slot: first gid
     const LightDev *lights;
@@ -134,7 +135,7 @@ struct BuildOptions {
 };
 
 struct DeviceScene {
-    DevBuf<float4> nodes, packets, normals, base_color, inst_cols, wnodes, wpackets;
+    DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;
@@ -153,6 +154,7 @@ struct DeviceScene {
 };
 
 // bvh_build.hip
+void pack_material(const MRTMaterial &m, float4 *out3);
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)

@@ -207,6 +207,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     // ---- per-instance tables: materials / first global triangle id per resource slot (Renderer.swift:128-151), instance rows
     std::vector<float4> h_base(std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
     std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
+    std::vector<float4> h_mat(3 * std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
     out.h_inst.assign(I, InstanceDev{});
     uint32_t gid = 0;
     for (size_t i = 0; i < I; i++) {
@@ -217,6 +218,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
         uint32_t tb = gid;
         for (size_t s = 0; s < g.sub_indices.size(); s++) {
             h_base[i * max_sub + s] = make_float4(g.sub_materials[s].baseColor.x, g.sub_materials[s].baseColor.y, g.sub_materials[s].baseColor.z, 0.0f);
+            pack_material(g.sub_materials[s], &h_mat[3 * (i * max_sub + s)]);
             h_gbase[i * max_sub + s] = tb;
             tb += (uint32_t)(g.sub_indices[s].size() / 3);
         }
@@ -225,6 +227,9 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     MRT_HIP(out.base_color.alloc(h_base.size())); MRT_HIP(out.geom_base.alloc(h_gbase.size()));
     MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base.data(), h_base.size() * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase.data(), h_gbase.size() * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(out.materials.alloc(h_mat.size()));
+    MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat.data(), h_mat.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipStreamSynchronize(stream));          // the host tables die at scope exit
     out.wnodes.release(); out.wpackets.release(); out.num_wnodes = 0; out.wide_depth = 0;
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;

@@ -517,7 +517,7 @@ struct StageDump {          // optional per-bounce dump for stage-level parity t
 };
 
 static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t sample_index, uint32_t offset, int px, int py, int max_bounces,
-                      bool brute, Counters &cnt, float *dump) {
+                      bool brute, Counters &cnt, float *dump, bool materials = false) {
     const float INF = std::numeric_limits<float>::infinity();
     int idx = (int)(offset + sample_index);           // == u.frameIndex unless sample-sharded
     float r0 = halton(idx, 0), r1 = halton(idx, 1);                       // :202-203
@@ -542,6 +542,57 @@ static V3 trace_pixel(const Scene &s, const MRTUniforms &u, uint32_t sample_inde
         V3 n_obj = (bu * s.normals[tr.i1] + bv * s.normals[tr.i2]) + bw * s.normals[tr.i0];   // :66-72
         V3 n = normalize3(xform_dir(xf, n_obj));                           // :267-268
         V3 surf = v3(s.mats[(size_t)tr.inst * s.maxSub + tr.geom].baseColor);   // :262-269
+        if (materials) {
+            // ---- materials extension (renderer option materials = 1).  NOT in raytracingKernel: the reference only carries the fields
+            // (ShaderTypes.h:99-107, filled by SubMesh.swift:37-54) and lists "more advanced materials (starting with refraction)" as open
+            // work (README.md:8).  Defined here, restated by k_shade<true>: emission is added along the path; one extra Halton dimension
+            // (2 + 5 * max_bounces + bounce, beyond the reference's) picks dielectric refraction / reflection (dissolve < 1), a specular
+            // lobe (GGX half vector with alpha^2 = 2 / (Ns + 2); only +, *, /, sqrt and the mrt-math sincos, so both sides agree bit for bit)
+            // or the reference's diffuse path with its albedo divided by the probability of having been chosen.
+            const MRTMaterial &m = s.mats[(size_t)tr.inst * s.maxSub + tr.geom];
+            accumulated = accumulated + color * v3(m.emission);
+            const float ul = halton(idx, 2 + 5 * max_bounces + bounce);
+            const V3 spec = v3(m.specular);
+            const float kd = std::max(surf.x, std::max(surf.y, surf.z)), ks = std::max(spec.x, std::max(spec.y, spec.z));
+            const float trn = (m.dissolve > 0.0f && m.dissolve < 1.0f && m.refractionIndex > 0.0f) ? 1.0f - m.dissolve : 0.0f;
+            if (ul < trn) {                                                 // dielectric interface, clear (throughput unchanged), no next-event estimate
+                const float u2 = ul / trn;
+                const float cd = dot3(dir, n);
+                const bool entering = cd < 0.0f;
+                const V3 nn = entering ? n : neg(n);
+                const float ni = m.refractionIndex;
+                const float eta = entering ? 1.0f / ni : ni;
+                const float cosi = entering ? -cd : cd;
+                const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+                float r0 = (1.0f - ni) / (1.0f + ni); r0 = r0 * r0;
+                float F = 1.0f, cost = 0.0f;
+                if (sin2t < 1.0f) { cost = sqrtf(1.0f - sin2t); const float c = entering ? cosi : cost; const float x = 1.0f - c; const float x2 = x * x; F = r0 + (1.0f - r0) * ((x2 * x2) * x); }
+                V3 nd;
+                if (u2 < F) { nd = dir + nn * (2.0f * cosi); org = P + nn * 1e-3f; }
+                else { nd = dir * eta + nn * (eta * cosi - cost); org = P + nn * -1e-3f; }
+                dir = normalize3(nd);
+                if (dump) { float *d = dump + bounce * 16; d[8] = n.x; d[9] = n.y; d[10] = n.z; d[11] = d[12] = d[13] = 0.0f; d[14] = -2.0f; d[15] = -1.0f; }
+                continue;
+            }
+            const float ud = trn > 0.0f ? (ul - trn) / (1.0f - trn) : ul;
+            const float ps = (ks > 0.0f && m.specularExponent > 0.0f) ? ks / (ks + kd) : 0.0f;
+            if (ud < ps) {                                                  // specular lobe: reflect about a GGX-distributed half vector, no next-event estimate
+                const float hx = halton(idx, 2 + bounce * 5 + 3), hy = halton(idx, 2 + bounce * 5 + 4);
+                const float a2 = 2.0f / (m.specularExponent + 2.0f);
+                const float ct2 = (1.0f - hy) / (1.0f + (a2 - 1.0f) * hy);
+                const float ct = sqrtf(ct2), st = sqrtf(1.0f - ct2);
+                float sp_, cp_; sincos_2pi(hx, &sp_, &cp_);
+                const V3 hw = align_hemisphere(v3(st * cp_, ct, st * sp_), n);
+                const float dh = dot3(dir, hw);
+                const V3 wi = dir - hw * (2.0f * dh);
+                if (dump) { float *d = dump + bounce * 16; d[8] = n.x; d[9] = n.y; d[10] = n.z; d[11] = d[12] = d[13] = 0.0f; d[14] = -3.0f; d[15] = -1.0f; }
+                if (!(dot3(wi, n) > 0.0f)) break;                           // sampled below the surface: the path is absorbed
+                color = color * (spec * (1.0f / ps));
+                org = P + n * 1e-3f; dir = normalize3(wi);
+                continue;
+            }
+            if (ps > 0.0f) surf = surf * (1.0f / (1.0f - ps));             // diffuse lobe chosen with probability 1 - ps
+        }
         float ls = halton(idx, 2 + bounce * 5 + 0);                        // :272
         int li = std::min((int)(ls * (float)u.lightCount), u.lightCount - 1);   // :273
         const MRTLight &L = s.lights[li];
@@ -607,6 +658,7 @@ struct Renderer {
     Counters total;
     int shard_rank = 0, shard_world = 1;
     uint32_t sample_offset = 0;
+    bool materials = false;        // the materials extension (see trace_pixel)
 };
 
 static void default_camera(int w, int h, MRTCamera *c) {       // Scene.swift:40-57
@@ -639,7 +691,7 @@ static void render_frames(Renderer &r, int nframes, int nthreads, bool brute, fl
                     }
                     size_t p = (size_t)y * r.w + x;
                     float *dp = dump ? dump + p * (size_t)r.max_bounces * 16 : nullptr;
-                    V3 c = trace_pixel(s, u, u.frameIndex + r.sample_offset, r.seeds[p], x, y, r.max_bounces, brute, cnts[tid], dp);
+                    V3 c = trace_pixel(s, u, u.frameIndex + r.sample_offset, r.seeds[p], x, y, r.max_bounces, brute, cnts[tid], dp, r.materials);
                     float *a = &r.accum[p * 4];
                     if (u.frameIndex > 0) {                                        // :395-401
                         float fi = (float)u.frameIndex;
@@ -739,6 +791,7 @@ void orc_renderer_set_camera(void *rp, const MRTCamera *c) { ((Renderer *)rp)->c
 void orc_renderer_set_shard(void *rp, int rank, int world) { Renderer *r = (Renderer *)rp; r->shard_rank = rank; r->shard_world = world; }
 void orc_renderer_set_frame_index(void *rp, uint32_t fi) { ((Renderer *)rp)->frameIndex = fi; }
 void orc_renderer_set_sample_offset(void *rp, uint32_t so) { ((Renderer *)rp)->sample_offset = so; }
+void orc_renderer_set_materials(void *rp, int on) { ((Renderer *)rp)->materials = on != 0; }
 void orc_renderer_set_accum(void *rp, const float *rgba) { Renderer *r = (Renderer *)rp; memcpy(r->accum.data(), rgba, r->accum.size() * 4); }
 // dump: NULL or w*h*max_bounces*16 floats (per-bounce stage records; only the last frame's survive)
 void orc_renderer_render(void *rp, int nframes, int nthreads, int brute, float *dump) {

@@ -49,6 +49,7 @@ def lib():
         l.orc_renderer_set_shard.argtypes = [P, I, I]
         l.orc_renderer_set_frame_index.argtypes = [P, U]
         l.orc_renderer_set_sample_offset.argtypes = [P, U]
+        l.orc_renderer_set_materials.argtypes = [P, I]
         l.orc_renderer_set_accum.argtypes = [P, P]
         l.orc_renderer_render.argtypes = [P, I, I, I, P]
         l.orc_renderer_read_accum.argtypes = [P, P]
@@ -139,6 +140,9 @@ class OracleRenderer:
 
     def set_sample_offset(self, so):
         lib().orc_renderer_set_sample_offset(self.h, so)
+
+    def set_materials(self, on=True):
+        lib().orc_renderer_set_materials(self.h, 1 if on else 0)
 
     def render(self, frames=1, threads=0, brute=False, dump=False):
         d = None
