@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         bool diffuse = true;
         if (MATERIALS) {
             // the materials extension (renderer option materials = 1; not in raytracingKernel — README.md:8 lists it as open work; the
-            // fields are ShaderTypes.h:99-107).  Restates oracle/mrt_oracle.cpp trace_pixel `if (materials)` expression by expression.
+            // fields are ShaderTypes.h:99-107).  Semantics: DESIGN.md "Materials extension"; the CPU checker restates this block expression by expression.
             const float4 *__restrict__ mp = s.materials + 3 * (size_t)(inst * (uint32_t)s.max_sub + geom);
             const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
             const f3 em = color * mk3(m2);
