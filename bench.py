@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 12; the reference keeps 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra max_bounces=1 (primary + shadow only) measurement")
-    ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg and the on-chip calibration")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
@@ -242,6 +242,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
                          "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY,
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n,
+                         # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 12 streams x 4-frame passes) and of the serialised frame
+                         "avg_launch_ms_rocprof_driver_command": round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None,
+                         "avg_launch_ms_rocprof_serialised_one_frame": round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None,
                          "avg_launch_ms_note": "kernel start/stop events of the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is the duration under overlap (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone; the serialised duration is latency.kernel_ms_serialised.trace",
                          "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
                          "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
@@ -254,7 +257,7 @@ def main():
                 r.write_accum_from(sr.buffer.data_ptr(), w * h * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
         single_dragon = world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3)
-        if world == 1:
+        if world == 1 and not a.no_latency:
             # ceilings calibrated on this chip, now: v_fma_f32 issue rate with every SIMD full, divergent-gather rate from a table of the scene's size
             import ctypes as C
             cal = (C.c_double * 5)()
@@ -267,7 +270,12 @@ def main():
                 rate = valu / (dt / a.steps)
                 out["valu_issue"] = {"wave_insts_per_frame": round(valu), "source": prof.get("_source"), "achieved_Ginst_per_s": round(rate / 1e9, 1),
                                      "peak_Ginst_per_s_calibrated_v_fma_f32": round(cal[0] / 1e9, 1), "frac": round(rate / cal[0], 4),
-                                     "cycle_weighted_frac": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
+                                     # the instruction mix weighted with the measured issue cost of each class (profiles/r02_summary.json valu_cycles_per_frame):
+                                     # SIMD cycles of VALU issue per frame / (1024 SIMDs x clock x frame time); the chip holds 1.9 GHz under pure v_fma_f32 load
+                                     # and up to 2.4 GHz on lighter mixes, so the two clocks bracket the truth
+                                     "valu_issue_cycles_per_frame": round(prof["valu_cycles_per_frame"]) if prof.get("valu_cycles_per_frame") else None,
+                                     "cycle_weighted_frac_at_2.4GHz": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (2.4e9 * 1024), 4) if prof.get("valu_cycles_per_frame") else None,
+                                     "cycle_weighted_frac_at_fma_load_clock": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
         if world == 1 and not a.no_latency:
             out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
         if world == 1 and a.bounces > 1 and not a.no_strict:

@@ -1,58 +1,79 @@
-"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the small summaries kept under profiles/."""
-import csv, glob, json, os, sys, collections
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the small summaries kept under profiles/ (copied there by hand from
+gpurun_out/profiles_<tag>/ after the GPU call)."""
+import collections, csv, glob, json, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)      # merged back by gpurun; copy into profiles/ afterwards
+P = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 os.makedirs(P, exist_ok=True)
-res = {}
-ks = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
-if ks:
+KERNELS = ("k_trace_primary", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_shade", "k_accumulate")
+
+
+def kname(n):
+    m = re.search(r"(k_[a-z0-9_]+)", n)
+    return m.group(1) if m else n.split("(")[0]
+
+
+res = {"tag": tag}
+for mode in ("driver", "serial"):
+    ks = glob.glob(out + f"/trace_{mode}/**/*kernel_stats.csv", recursive=True)
+    if not ks:
+        continue
     rows = list(csv.DictReader(open(ks[0])))
-    with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(P, f"{tag}_kernel_stats_{mode}.csv"), "w") as f:
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
-            import re
-            mm = re.search(r"(k_[a-z0-9_]+)", r["Name"]); name = mm.group(1) if mm else r["Name"].split("(")[0]
-            f.write(f"\"{name}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
-    for r in rows:
-        for k in ("k_trace_primary", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
-            if k + "(" in r["Name"] or r["Name"].endswith(k):
-                res.setdefault("kernel_avg_us", {})[k] = float(r["AverageNs"]) / 1e3
-                res.setdefault("kernel_calls", {})[k] = int(r["Calls"])
-def pmc(dirname, counter):
-    acc = collections.defaultdict(list)
-    for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
+            f.write(f"\"{kname(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    res[f"kernel_avg_us_{mode}"] = {kname(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows if kname(r["Name"]) in KERNELS}
+    res[f"kernel_calls_{mode}"] = {kname(r["Name"]): int(r["Calls"]) for r in rows if kname(r["Name"]) in KERNELS}
+    try:
+        res[f"bench_{mode}_under_rocprof"] = json.loads(open(out + f"/bench_{mode}_under_rocprof.json").read().strip().splitlines()[-1])
+    except Exception as e:
+        res[f"bench_{mode}_under_rocprof"] = str(e)
+
+
+def pmc_all():
+    """{kernel: {counter: mean per dispatch}} over every pmc_* directory; the runs use 4-frame passes with warm-up = one pass, so every dispatch is full size"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter: continue
-            for k in ("k_trace_primary", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_extend", "k_shadow", "k_shade", "k_raygen", "k_accumulate"):
-                if k + "(" in r["Kernel_Name"]: acc[k].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
-fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-res["valu_busy_pct"] = pmc("pmc_valu", "VALUBusy")                 # % of cycles the VALU is issuing (kernels serialised by the profiler)
-res["valu_lane_utilization_pct"] = pmc("pmc_valu", "VALUUtilization")   # % of lanes active in an average VALU instruction
-# units: KB (1024 B) per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes
-# of wide coalesced reads -> x2; other access widths are uncalibrated, so this is an upper estimate for gathers.
-res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": fetch.get(k), "write_KB": write.get(k),
-                                           "bytes_corrected": (2 * fetch.get(k, 0) + write.get(k, 0)) * 1024 if k in fetch else None} for k in set(fetch) | set(write)}
-# VALU wave-instructions per frame: every dispatch of the render kernels in the 10-frame counter run (8 steps + 2 warm-up)
-insts = 0.0
-for f in glob.glob(out + "/pmc_insts/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == "SQ_INSTS_VALU" and any(k in r["Kernel_Name"] for k in ("k_trace", "k_shade", "k_accumulate")):
-            insts += float(r["Counter_Value"])
-if insts > 0:
-    res["valu_wave_insts_per_frame"] = insts / 10.0
-try:
-    res["bench_under_rocprof"] = json.loads(open(out + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
-except Exception as e:
-    res["bench_under_rocprof"] = str(e)
-# traversal launches together (what bench.py's roofline object times): call-weighted mean over the trace kernels
-tk = [k for k in res.get("kernel_calls", {}) if k.startswith("k_trace") or k == "k_extend"]
-if tk:
-    calls = sum(res["kernel_calls"][k] for k in tk)
-    res["trace_launch_avg_us"] = sum(res["kernel_avg_us"][k] * res["kernel_calls"][k] for k in tk) / calls
-    hb = res["hbm_traffic_bytes_per_launch"]
-    if all(k in hb and hb[k]["bytes_corrected"] is not None for k in tk):
-        res["trace_launch_hbm_bytes"] = sum(hb[k]["bytes_corrected"] * res["kernel_calls"][k] for k in tk) / calls
+            k = kname(r["Kernel_Name"])
+            if k in KERNELS:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}, {k: {c: len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+pm, pn = pmc_all()
+res["pmc_mean_per_dispatch_of_4_frames"] = pm
+res["pmc_dispatches"] = {k: max(v.values()) for k, v in pn.items()}
+# HBM traffic per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2
+# (units: KB = 1024 B); other access widths are uncalibrated, so this is an upper estimate for gathers.
+res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": d.get("FETCH_SIZE"), "write_KB": d.get("WRITE_SIZE"),
+                                           "bytes_corrected": (2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 if "FETCH_SIZE" in d else None} for k, d in pm.items()}
+res["valu_busy_pct"] = {k: d.get("VALUBusy") for k, d in pm.items()}
+res["valu_lane_utilization_pct"] = {k: d.get("VALUUtilization") for k, d in pm.items()}
+# VALU wave-instructions per FRAME: per 4-frame pass there is 1 primary, max_bounces shade, max_bounces trace and 1 accumulate dispatch
+B, BOUNCES = 4, 3
+per_pass = {"k_trace_primary": 1, "k_shade": BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1}
+insts = sum(pm[k].get("SQ_INSTS_VALU", 0.0) * n for k, n in per_pass.items() if k in pm)
+if insts:
+    res["valu_wave_insts_per_frame"] = insts / B
+    # cycle-weighted estimate with the measured issue costs (tools/valu_rates.hip): fp32 add/mul/fma 2.3 cycles, transcendental 8.2, conversions 4.2,
+    # INT32 (and/or/xor/add 2.5, shifts / bit-field / 24-bit multiplies 4.2) taken at 3.3, everything else (min/max, compares, selects ...) 4.2
+    cyc = 0.0
+    for k, n in per_pass.items():
+        if k not in pm:
+            continue
+        d = pm[k]
+        full = d.get("SQ_INSTS_VALU_ADD_F32", 0) + d.get("SQ_INSTS_VALU_MUL_F32", 0) + d.get("SQ_INSTS_VALU_FMA_F32", 0)
+        trans, cvt, i32 = d.get("SQ_INSTS_VALU_TRANS_F32", 0), d.get("SQ_INSTS_VALU_CVT", 0), d.get("SQ_INSTS_VALU_INT32", 0)
+        rest = max(0.0, d.get("SQ_INSTS_VALU", 0) - full - trans - cvt - i32)
+        cyc += n * (2.3 * full + 8.2 * trans + 4.2 * cvt + 3.3 * i32 + 4.2 * rest)
+    res["valu_cycles_per_frame"] = cyc / B
+    res["valu_cycles_per_frame_note"] = "SIMD cycles of VALU issue per frame, estimated from the SQ_INSTS_VALU_* mix and the measured per-instruction costs; divide by 1024 SIMDs x shader clock for the VALU-bound frame time"
+for name in ("valu_rates", "calibrate"):
+    try:
+        res[name] = json.loads(open(out + f"/{name}.json").read().strip().splitlines()[-1])
+    except Exception as e:
+        res[name] = str(e)
 json.dump(res, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k != "bench_under_rocprof"}, indent=1))
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("bench_") and k not in ("valu_rates", "pmc_mean_per_dispatch_of_4_frames")}, indent=1)[:6000])
