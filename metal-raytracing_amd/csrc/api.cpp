@@ -427,6 +427,8 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     if (k == "max_bounces") *value = r->r.max_bounces;
     else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
     else if (k == "frame_batch") *value = r->r.frame_batch;
+    else if (k == "lanes_used") *value = r->r.lanes_used;
+    else if (k == "lane_bytes") *value = (double)r->r.lane_bytes();
     else if (k == "fused") *value = r->r.fused ? 1 : 0;
     else if (k == "materials") *value = r->r.materials ? 1 : 0;
     else if (k == "persistent") *value = r->r.persistent;

@@ -42,6 +42,7 @@ struct Renderer {
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
     int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
+    int lanes_used = 0;                  // lanes the last draw ran on (<= frames_in_flight when device memory is short)
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
     bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
@@ -73,6 +74,8 @@ struct Renderer {
     int resize(int w, int h);
     int alloc_queues();
     int alloc_lane(FrameLane &L);
+    void release_lane(FrameLane &L);
+    size_t lane_bytes() const;           // device bytes of one lane's queues + sample buffer at the current size and batch
     int set_shard(int rank, int world);
     int render(int n_frames);
     int wait();

@@ -711,10 +711,7 @@ int Renderer::alloc_queues() {
     capacity = (uint32_t)tiles_local * 64u;
     // lanes get their buffers when first used (alloc_lane): 16 lanes x 4-frame queues would pin 23 GB at 1080p, 94 GB at 4K
     lanes_ready = 0;
-    for (auto &L : lanes) {
-        for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
-        L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release();
-    }
+    for (auto &L : lanes) release_lane(L);
     // pixels owned by this shard (edge tiles may be partial)
     uint64_t owned = 0;
     for (int lt = 0; lt < tiles_local; lt++) {
@@ -726,6 +723,14 @@ int Renderer::alloc_queues() {
     return MRT_OK;
 }
 
+size_t Renderer::lane_bytes() const {
+    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
+    return (10 * qcap + (size_t)width * height * (size_t)std::max(1, alloc_batch)) * sizeof(float4);
+}
+void Renderer::release_lane(FrameLane &L) {
+    for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
+    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release();
+}
 int Renderer::alloc_lane(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
     for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); MRT_HIP(L.thr[k].alloc(qcap)); }
@@ -759,7 +764,6 @@ int Renderer::render(int n_frames) {                                   // Render
     fp.tiles_x = (width + 7) / 8; fp.tiles_local = tiles_local; fp.max_bounces = max_bounces;
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
-    const int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     const bool two_level = sv.num_inst > 0;          // instanced scene: the fused pipeline on the two-level rope kernels
     const bool wide = use_wide && sv.num_wnodes > 0 && !two_level && !materials;
     if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
@@ -777,7 +781,19 @@ int Renderer::render(int n_frames) {                                   // Render
         frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; camera = keep_cam;
         return render(n_frames);
     }
-    for (; lanes_ready < F; lanes_ready++) { int rc = alloc_lane(lanes[lanes_ready]); if (rc) return rc; }      // the first draw sizes the lanes in use
+    // the first draw sizes the lanes in use.  A lane's queues take ~176 B x pixels x frame_batch (1080p, 4-frame passes: 1.5 GB); when the
+    // device cannot hold all the lanes asked for, the renderer runs on the ones it got (>= 1) instead of failing in the middle of a draw
+    int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
+    for (; lanes_ready < F; lanes_ready++) {
+        const size_t need = lane_bytes();
+        size_t free_b = 0, total_b = 0;
+        const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b > need + (size_t(1) << 30);      // keep 1 GiB of slack for the caller
+        int rc = fits ? alloc_lane(lanes[lanes_ready]) : MRT_ERR_OUT_OF_MEMORY;
+        if (rc == MRT_ERR_OUT_OF_MEMORY && lanes_ready >= 1) { (void)hipGetLastError(); release_lane(lanes[lanes_ready]); break; }
+        if (rc == MRT_ERR_OUT_OF_MEMORY) { set_error("not enough device memory for one pass in flight: " + std::to_string(need >> 20) + " MiB of ray queues needed (" + std::to_string(width) + "x" + std::to_string(height) + ", frame_batch " + std::to_string(alloc_batch) + "); lower frame_batch"); return rc; }
+        if (rc) return rc;
+    }
+    F = std::min(F, lanes_ready); lanes_used = F;
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
@@ -790,7 +806,7 @@ int Renderer::render(int n_frames) {                                   // Render
     hipEvent_t last_acc = nullptr;
     int pass = 0;
     for (int f = 0; f < n_frames; pass++) {
-        const int B = std::min(batch_max, n_frames - f);
+        int B = std::min(batch_max, n_frames - f);
         f += B;
         fp.batch = B;
         FrameLane &L = lanes[pass % F];

@@ -120,7 +120,11 @@ INTERSECTION_DTYPE = np.dtype([("type", np.int32), ("distance", np.float32), ("i
 class Renderer:
     """Renderer.swift:12-357."""
 
-    maxFramesInFlight = 3                                     # Renderer.swift:33 (frames are queued on one HIP stream)
+    @property
+    def maxFramesInFlight(self):
+        """Renderer.maxFramesInFlight (Renderer.swift:33 keeps 3).  Here: passes in flight on separate HIP streams, each carrying
+        `frame_batch` frames (library defaults 12 x 4); set with set_option("frames_in_flight", n)."""
+        return int(self.get_option("frames_in_flight"))
 
     def __init__(self, size, scene=None, device=0, seed=1, max_bounces=3, ctx=None, scene_options=None):
         self.size = (int(size[0]), int(size[1]))
