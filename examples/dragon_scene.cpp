@@ -1,7 +1,7 @@
 // dragon_scene.cpp — what GameViewController.viewDidLoad + Renderer.init + N x draw(in:) do in the
 // reference (GameViewController.swift:17-43, Renderer.swift:45-71, :284-351), on the C++ host mirror.
 //   c++ -std=c++17 -Iinclude examples/dragon_scene.cpp -Lmetal-raytracing_amd -lmrt_hip -o dragon_scene
-//   ./dragon_scene [width height frames out.ppm]
+//   ./dragon_scene [width height frames out.ppm [instancing]]     instancing = 1: the two spheres share one BLAS under a TLAS
 #include <cstdio>
 #include <cstdlib>
 #include "mrt.hpp"
@@ -9,11 +9,12 @@
 int main(int argc, char **argv) {
     int w = argc > 1 ? atoi(argv[1]) : 800, h = argc > 2 ? atoi(argv[2]) : 600;      // the storyboard's 800x600 MTKView
     int frames = argc > 3 ? atoi(argv[3]) : 16;
-    const char *out = argc > 4 ? argv[4] : nullptr;
+    const char *out = argc > 4 && argv[4][0] != '-' ? argv[4] : nullptr;
+    const bool instancing = argc > 5 && atoi(argv[5]) != 0;
     if (const char *res = getenv("MRT_RESOURCES")) mrt::resourceDirectory() = res;
     try {
         mrt::DragonScene scene(w, h);
-        mrt::Renderer renderer(w, h, scene);
+        mrt::Renderer renderer(w, h, scene, 0, 1, 3, instancing);
         MRTSceneStats ss = renderer.sceneStats();
         renderer.draw(frames);
         renderer.wait();

@@ -130,16 +130,23 @@ struct DragonScene : Scene {                                         // DragonSc
 
 class Renderer {                                                     // Renderer.swift:12-357
   public:
-    static constexpr int maxFramesInFlight = 3;                      // Renderer.swift:33
-    Renderer(int width, int height, const Scene &scene, int device = 0, uint32_t seed = 1, int max_bounces = 3) : w_(width), h_(height) {
+    static constexpr int maxFramesInFlight = 3;                      // Renderer.swift:33 (here: setOption("frames_in_flight", n); library default 12 passes of 4 frames)
+    // instancing = true: models loaded from the same resource become instances of one mesh (mrt_scene_add_instance) and the scene is committed
+    // two-level — one BLAS per distinct mesh + a TLAS (the reference's instance acceleration structure, Renderer.swift:193-213)
+    Renderer(int width, int height, const Scene &scene, int device = 0, uint32_t seed = 1, int max_bounces = 3, bool instancing = false) : w_(width), h_(height) {
         check(mrt_context_create(device, &ctx_));                    // MTLCreateSystemDefaultDevice + queue (:46-59)
         try {
             check(mrt_scene_create(ctx_, &scene_));
+            if (instancing) check(mrt_scene_set_option(scene_, "instancing", 1));
+            std::vector<std::pair<std::string, int32_t>> loaded;     // resource name -> mesh id of its first use
             for (const Model &model : scene.models)                  // createBuffers / geometry descriptors (:107-182, Mesh.swift:39-48)
                 for (const Mesh &mesh : model.meshes) {
-                    int32_t id = -1;
+                    int32_t id = -1, source = -1;
+                    if (instancing && model.meshes.size() == 1) for (auto &l : loaded) if (l.first == model.name) source = l.second;
+                    if (source >= 0) { check(mrt_scene_add_instance(scene_, source, mesh.transform, &id)); continue; }
                     check(mrt_scene_add_mesh(scene_, mesh.positions.data(), 12, mesh.normals.data(), 12, mesh.positions.size() / 3, mesh.transform, &id));
                     for (const Submesh &sm : mesh.submeshes) check(mrt_mesh_add_submesh(scene_, id, sm.indices.data(), sm.triangleCount(), &sm.material, nullptr));
+                    loaded.emplace_back(model.name, id);
                 }
             check(mrt_scene_set_lights(scene_, scene.lights.data(), (int32_t)scene.lights.size()));
             check(mrt_scene_commit(scene_));                         // createAccelerationStructures (:184-214)
@@ -154,6 +161,10 @@ class Renderer {                                                     // Renderer
     void wait() { check(mrt_renderer_wait(r_)); }
     void drawableSizeWillChange(int width, int height) { w_ = width; h_ = height; check(mrt_renderer_resize(r_, width, height)); }   // :353-356
     uint32_t frameIndex() const { uint32_t f = 0; check(mrt_renderer_frame_index(r_, &f)); return f; }
+    void setFrameIndex(uint32_t f) { check(mrt_renderer_set_frame_index(r_, f)); }
+    // animated transforms: new object->world matrix (column-major 4x4) for one mesh / instance, then commit(); a two-level scene rebuilds only its TLAS
+    void setInstanceTransform(int32_t meshId, const float transform[16]) { check(mrt_scene_set_instance_transform(scene_, meshId, transform)); }
+    void commit() { check(mrt_scene_commit(scene_)); }
     // implementation knobs (mrt_abi.h): "frames_in_flight" (HIP streams, default 12), "frame_batch" (frames per pass, default 4), ...
     void setOption(const char *key, double value) { check(mrt_renderer_set_option(r_, key, value)); }
     double option(const char *key) const { double v = 0; check(mrt_renderer_get_option(r_, key, &v)); return v; }

@@ -43,3 +43,21 @@ def test_cpp_mirror_matches_python_mirror(mrt, gpu_ctx):
     # the C++ side sums in the same element order in double: identical up to printing precision
     assert abs(float(m.group(6)) - checksum) <= 1e-6 * max(1.0, abs(checksum))
     r.close()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_two_level_matches_python_two_level(mrt, gpu_ctx):
+    """instancing through the C++ mirror (the two spheres of DragonScene become one BLAS x two instances) == the Python mirror's."""
+    _build()
+    w, h, frames = 128, 72, 2
+    p = subprocess.run([EXE, str(w), str(h), str(frames), "-", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"triangles=(\d+) frames=(\d+) frameIndex=(\d+) closest=(\d+) shadow=(\d+) ms=\S+ checksum=(\S+)", p.stdout)
+    assert m, p.stdout
+    r = mrt.Renderer((w, h), mrt.DragonScene((w, h)), ctx=gpu_ctx, scene_options={"instancing": 1})
+    r.draw(frames, wait=True)
+    acc = r.accumulation(); st = r.stats
+    assert (int(m.group(4)), int(m.group(5))) == (st.closest_rays, st.shadow_rays)
+    checksum = float(np.sum(acc[..., 0].astype(np.float64) + acc[..., 1].astype(np.float64) + acc[..., 2].astype(np.float64)))
+    assert abs(float(m.group(6)) - checksum) <= 1e-6 * max(1.0, abs(checksum))
+    r.close()
