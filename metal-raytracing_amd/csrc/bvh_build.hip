@@ -466,7 +466,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n_in;
     uint32_t ch[8]; bool isleaf[8]; int nch = 0;
-    uint32_t ninner = 0, ntris = 0, nreal = 0;     // next-level nodes, packet slots reserved (4 per leaf child), triangles
+    uint32_t ninner = 0, ntris = 0;
     float4 nlo = make_float4(0, 0, 0, 0), nhi = nlo;
     if (active) {
         const uint32_t f = fin[i];
@@ -496,7 +496,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
             uint32_t c = ch[best];
             ch[best] = t.left[c]; ch[nch] = t.right[c]; isleaf[nch] = true; nch++;
         }
-        for (int k = 0; k < nch; k++) { if (isleaf[k]) { ntris += 4; nreal += t.ntri[ch[k]]; } else ninner++; }      // a leaf child owns a block of 4 packet slots
+        for (int k = 0; k < nch; k++) { if (isleaf[k]) ntris += t.ntri[ch[k]]; else ninner++; }
     }
     // wave-aggregated reservation of next-level node slots and packet slots
     const uint32_t lane = threadIdx.x & 63;
@@ -504,7 +504,6 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     for (int o = 1; o < 64; o <<= 1) { uint32_t a = __shfl_up(xi, o), b = __shfl_up(xt, o); if (lane >= (uint32_t)o) { xi += a; xt += b; } }
     uint32_t tot_i = __shfl(xi, 63), tot_t = __shfl(xt, 63), base_i = 0, base_t = 0;
     if (lane == 63) { if (tot_i) base_i = atomicAdd(&counters[0], tot_i); if (tot_t) base_t = atomicAdd(&counters[1], tot_t); }
-    if (nreal) atomicAdd(&counters[2], nreal);
     base_i = __shfl(base_i, 63); base_t = __shfl(base_t, 63);
     if (!active) return;
     const uint32_t my_i = base_i + xi - ninner, my_t = base_t + xt - ntris;
@@ -535,7 +534,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     }
     const float pl[3] = {nlo.x, nlo.y, nlo.z};
     uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z then qhi x,y,z; 2 dwords (8 bytes) each
-    uint32_t valid = 0, inner32 = 0, leaf8 = 0, imask = 0, rank_i = 0, off_t = 0;
+    uint32_t meta[2] = {0, 0}, imask = 0, rank_i = 0, off_t = 0;
     for (int sl = 0; sl < 8; sl++) {
         int k = child_in_slot[sl];
         uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
@@ -553,15 +552,15 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
                 ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
             }
             if (isleaf[k]) {
-                uint32_t cnt = t.ntri[c];                              // <= 4 (max_leaf)
-                valid |= ((1u << cnt) - 1u) << (4 * sl);              // triangle r of the child in slot sl = bit 4 sl + r
-                leaf8 |= 1u << sl;
+                uint32_t cnt = t.ntri[c];
+                uint32_t m = (cnt << 5) | off_t;
+                meta[sl >> 2] |= m << (8 * (sl & 3));
                 uint32_t src = leaf_offset[c];
                 for (uint32_t r = 0; r < cnt; r++)
                     for (int j = 0; j < 3; j++) wpackets[3 * (size_t)(my_t + off_t + r) + j] = packets[3 * (size_t)(src + r) + j];
-                off_t += 4;                                            // the block of the next leaf child (slot order)
+                off_t += cnt;
             } else {
-                imask |= 1u << sl; inner32 |= 1u << (4 * sl);
+                imask |= 1u << sl;
                 fout[my_i + rank_i] = c;
                 rank_i++;
             }
@@ -571,7 +570,7 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     const size_t w = WNODE_STRIDE * (size_t)(base_in + i);
     // exponents are stored unbiased (int8, e - 127): the traversal scales 1/direction with v_ldexp_f32
     wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24)));
-    wnodes[w + 1] = make_float4(__uint_as_float((next_base + my_i) | (leaf8 << 24)), __uint_as_float(my_t), __uint_as_float(valid), __uint_as_float(inner32));
+    wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
     wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
@@ -840,12 +839,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         // ---- 8-wide compressed layout, level by level (BFS numbering)
         const size_t max_w = (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
-        MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(4));
-        // every leaf child of a wide node owns a block of 4 packet slots (its triangles first): the traversal addresses a triangle as
-        // tri_base + 4 * (rank of the child among the node's leaf children) + r without a per-child offset table.  Leaves <= triangles.
-        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(3 * 4 * (size_t)n));      // worst case: every triangle a leaf child of its own; trimmed below
+        MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
-        MRT_HIP(hipMemsetAsync(wc.p, 0, 16, stream));
+        MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
         MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
         uint32_t n_in = 1, base_in = 0, total = 0; int depth = 0;
         uint32_t *fin = fa.p, *fo = fb.p;
@@ -865,19 +862,12 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(hipStreamSynchronize(stream));
         MRT_HIP(hipGetLastError());
         float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
-        uint32_t h_wc[4]; MRT_HIP(hipMemcpy(h_wc, wc.p, 16, hipMemcpyDeviceToHost));
-        if (h_wc[2] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
-        if ((size_t)h_wc[1] * 3 > out.wpackets.n) { set_error("wide BVH build: packet blocks overflow"); return MRT_ERR_HIP; }
-        if ((size_t)h_wc[1] * 3 < out.wpackets.n) {           // keep only the blocks in use
-            DevBuf<float4> exact; MRT_HIP(exact.alloc(3 * (size_t)std::max<uint32_t>(h_wc[1], 1)));
-            MRT_HIP(hipMemcpyAsync(exact.p, out.wpackets.p, (size_t)h_wc[1] * 48, hipMemcpyDeviceToDevice, stream));
-            MRT_HIP(hipStreamSynchronize(stream));
-            std::swap(exact.p, out.wpackets.p); std::swap(exact.n, out.wpackets.n);
-        }
+        uint32_t h_wc[2]; MRT_HIP(hipMemcpy(h_wc, wc.p, 8, hipMemcpyDeviceToHost));
+        if (h_wc[1] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
         out.stats.build_ms += wms;
         out.wide_depth = depth;
         if (depth <= WIDE_STACK && total < (1u << 24)) out.num_wnodes = total;       // deeper than the LDS stack (or child_base beyond its 24 stack bits): keep the rope backend
-        out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)h_wc[1] * 48;
+        out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;
     }

@@ -23,9 +23,17 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_NODE_MIN
 #define MRT_WIDE_NODE_MIN 0   // > 0: take the node branch only when this many lanes want it (-2 % for every value tried)
 #endif
+#ifndef MRT_WIDE_DUAL_TRI
+#define MRT_WIDE_DUAL_TRI 0   // measured: trace launches 13 % shorter, frame rate -1.5 % — the frame is bound by VALU issue in aggregate, and this adds instructions
+#endif
 #ifndef MRT_WIDE_PK_FMA
 #define MRT_WIDE_PK_FMA 0   // v_pk_fma_f32 plane evaluation: -1.5 ... -2.6 % (no spills at 72 VGPRs either: the packed form is not cheaper to issue here)
 #endif
+#ifndef MRT_WIDE_FLAT_HITS
+#define MRT_WIDE_FLAT_HITS 1   // hit children recorded without an inner node/leaf branch: +0.8 % / +1.8 %
+#endif
+// ((1 << width) - 1) << offset in one instruction (width, offset taken mod 32)
+MRT_DEV uint32_t bfm_b32(uint32_t width, uint32_t offset) { uint32_t r; asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset)); return r; }
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
 
 // LDS stack of one wave: per tree level 64 words {child_base << 8 | remaining hit bits} followed by 64 bytes {imask}
@@ -51,19 +59,15 @@ MRT_DEV float box_inv(float d) {
     return __builtin_fmaf(r, __builtin_fmaf(-a, r, 1.0f), r);
 }
 
-// The eight quantised child boxes of one wide node against a ray.
-//   node_hits = bit (slot ^ octant) per internal child hit (so that ffs walks them front to back),
-//   tri_hits  = bit 4 * slot + r per triangle r of a leaf child hit (packet_of_bit turns a bit into a packet index).
+// The eight quantised child boxes of one wide node against a ray: node_hits = bit (slot ^ octant) per internal child hit
+// (so that ffs walks them front to back), tri_hits = bit k per packet tri_base + k of the leaf children hit.
 // Plane distance t = q * (2^e * idir) + (p - o) * idir, one fma per plane; the decode error of the fused evaluation is far
 // below the build-time padding of the leaf boxes, and the far side is widened by 4 ulp (Ize 2013).
-// Hit recording is branch-free and built from what issues cheaply on gfx950 (tools/valu_rates.hip: select, or, and at 2.3-4.2 cycles;
-// a per-child branch with bit-field extraction and v_bfm cost 24 cycles per child and a scalar branch each): a child that is hit sets its
-// nibble in one word; the node's `valid` word keeps the triangles that exist, its `inner32` word the internal children, whose bits are then
-// permuted by the ray's octant (half / byte / nibble swaps of the nibble-spaced word) and squeezed to eight.
 MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4, const f3 o,
-                            const float ix, const float iy, const float iz, const bool nx, const bool ny, const bool nz,
+                            const float ix, const float iy, const float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
                             const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
     const uint32_t ew = __float_as_uint(n0.w);
+    const uint32_t imask = ew >> 24;
     // 2^e * idir: sign-extended exponent byte (v_bfe_i32) + v_ldexp_f32 — two instructions per axis instead of shift, mask, multiply
     const float ax = __builtin_ldexpf(ix, (int)(int8_t)(ew & 0xFFu)), ay = __builtin_ldexpf(iy, (int)(int8_t)((ew >> 8) & 0xFFu)), az = __builtin_ldexpf(iz, (int)(int8_t)((ew >> 16) & 0xFFu));
     const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
@@ -74,11 +78,12 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
     const uint32_t nrx[2] = {nx ? hx0 : lx0, nx ? hx1 : lx1}, frx[2] = {nx ? lx0 : hx0, nx ? lx1 : hx1};
     const uint32_t nry[2] = {ny ? hy0 : ly0, ny ? hy1 : ly1}, fry[2] = {ny ? ly0 : hy0, ny ? ly1 : hy1};
     const uint32_t nrz[2] = {nz ? hz0 : lz0, nz ? hz1 : lz1}, frz[2] = {nz ? lz0 : hz0, nz ? lz1 : hz1};
-    uint32_t th = 0;
+    const uint32_t meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+    uint32_t nh = 0, th = 0;     // locals, not the reference parameters: `if (..) a |= x; else b |= y;` on references becomes a pointer select -> scratch
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int w = i >> 2, k = i & 3;
-#if MRT_WIDE_PK_FMA        // near and far plane of an axis in one v_pk_fma_f32 (4.2 cycles for two FMAs against 2 x 2.3: measured -1.5 ... -2.6 % with the pair set-up)
+#if MRT_WIDE_PK_FMA        // near and far plane of an axis in one v_pk_fma_f32 (packed fp32 runs at twice the scalar rate)
         const float2v px = __builtin_elementwise_fma(float2v{ubyte_f(nrx[w], k), ubyte_f(frx[w], k)}, float2v{ax, ax}, float2v{bx, bx});
         const float2v py = __builtin_elementwise_fma(float2v{ubyte_f(nry[w], k), ubyte_f(fry[w], k)}, float2v{ay, ay}, float2v{by, by});
         const float2v pz = __builtin_elementwise_fma(float2v{ubyte_f(nrz[w], k), ubyte_f(frz[w], k)}, float2v{az, az}, float2v{bz, bz});
@@ -90,24 +95,17 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
         const float tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
                                      __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, tmax);
 #endif
-        th |= (tn <= tf) ? (0xFu << (4 * i)) : 0u;              // v_cndmask + v_or; an empty slot (qlo = 255, qhi = 0) never passes
+        if (tn <= tf) {
+#if MRT_WIDE_FLAT_HITS      // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
+            nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
+            th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
+#else
+            if ((imask >> i) & 1u) nh |= 1u << ((uint32_t)i ^ oct);
+            else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; th |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
+#endif
+        }
     }
-    tri_hits = th & __float_as_uint(n1.z);                      // triangles that exist behind the leaf children hit
-    uint32_t x = th & __float_as_uint(n1.w);                    // bit 4 * slot per internal child hit
-    // slot -> slot ^ octant on the nibble-spaced word: octant bit 2 swaps the halves, bit 1 the bytes of each half, bit 0 the nibbles of each byte
-    x = nz ? __builtin_amdgcn_alignbit(x, x, 16) : x;
-    x = ny ? __builtin_amdgcn_perm(x, x, 0x02030001u) : x;
-    x = nx ? (((x >> 4) & 0x0F0F0F0Fu) | ((x << 4) & 0xF0F0F0F0u)) : x;
-    // bits 0, 4, ..., 28 -> 0 ... 7
-    x = (x | (x >> 3)) & 0x03030303u; x = (x | (x >> 6)) & 0x000F000Fu; x = (x | (x >> 12)) & 0xFFu;
-    node_hits = x;
-}
-
-// packet index of triangle bit b of the node whose block starts at t_base and whose leaf children are leaf8: every leaf child owns four
-// packet slots, in slot order (bvh_build.hip k_wide_level)
-MRT_DEV uint32_t packet_of_bit(uint32_t t_base, uint32_t leaf8, uint32_t b) {
-    const uint32_t slot = b >> 2;
-    return t_base + 4u * (uint32_t)__popc(leaf8 & ((1u << slot) - 1u)) + (b & 3u);
+    node_hits = nh; tri_hits = th;
 }
 
 // stack: depth x WIDE_STACK_LEVEL_BYTES of LDS for the wave (depth = the scene's wide-tree depth, <= WIDE_STACK)
@@ -121,7 +119,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
     const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     uint32_t sp = 0;
     uint32_t g_base = 0, g_mask = 0;      // node group: (permuted hit bits << 8) | imask
-    uint32_t t_base = 0, t_mask = 0, t_leaf = 0;      // triangle group: bit 4 * slot + r still to test; leaf children of that node
+    uint32_t t_base = 0, t_mask = 0;      // triangle group: bit k = packet t_base + k still to test
     uint32_t pending = 0; bool have_pending = true;     // start by entering the root
     for (;;) {
         const bool do_tri = t_mask != 0;
@@ -142,7 +140,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
         if (do_tri) {
             const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
             t_mask &= t_mask - 1u;
-            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)packet_of_bit(t_base, t_leaf, k);
+            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)(t_base + k);
             const float4 r0 = pk[0], r1 = pk[1], r2 = pk[2];
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
@@ -155,11 +153,11 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
             have_pending = false;
             uint32_t node_hits, tri_hits;
-            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, tmin, h.t, node_hits, tri_hits);
+            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, tmin, h.t, node_hits, tri_hits);
             if (STATS && tri_hits) tc->leaves++;
             if ((g_mask >> 8) != 0) { wstack_push(stack, sp, lane, g_base, g_mask); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x) & 0x00FFFFFFu; g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
-            t_base = __float_as_uint(n1.y); t_mask = tri_hits; t_leaf = __float_as_uint(n1.x) >> 24;
+            g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
     return h.gid != 0xFFFFFFFFu;
@@ -223,7 +221,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     uint32_t tagw = 0;                                // tag | any-hit flag << 31
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); float ix = 0, iy = 0, iz = 0; bool nx = false, ny = false, nz = false; uint32_t oct = 0;
     float best_t = 0.0f; uint32_t best_pk = 0xFFFFFFFFu;     // closest hit so far: distance and packet (0xFFFFFFFF = none); id, U, V are re-read at emit time
-    uint32_t g_base = 0, g_mask = 0, t_base = 0, t_mask = 0;   // g_mask: imask | permuted hit bits << 8 | stack depth << 16 | leaf children of the node t_mask belongs to << 21
+    uint32_t g_base = 0, g_mask = 0, t_base = 0, t_mask = 0;   // g_mask: imask | permuted hit bits << 8 | stack depth << 16
     for (;;) {
         const unsigned long long m_idle = __ballot(!live);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
@@ -282,19 +280,21 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         const bool has_tri = live && t_mask != 0;
         const uint32_t t_rest = t_mask & (t_mask - 1u);         // triangles left after this iteration's first one
         bool want_node = live && t_rest == 0u;
-        // this iteration's triangle, addressed before the node group below can be replaced by a stack entry (the leaf bits ride in g_mask)
-        uint32_t tri_pk = 0;
-        if (has_tri) tri_pk = packet_of_bit(t_base, (g_mask >> 21) & 0xFFu, (uint32_t)__ffs((int)t_mask) - 1u);
 #if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
         {
             const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
             if (n_busy != 0u && n_want < (uint32_t)MRT_WIDE_NODE_MIN) want_node = false;
         }
 #endif
-        uint32_t pending = 0;
+#if MRT_WIDE_DUAL_TRI
+        const bool has_tri2 = live && t_rest != 0u;             // two or more pending: test two this iteration (the node registers carry the second packet)
+#else
+        const bool has_tri2 = false;
+#endif
+        uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
         if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
-                const uint32_t sp = (g_mask >> 16) & 0x1Fu;
+                const uint32_t sp = g_mask >> 16;
                 if (sp == 0) { want_node = false; if (!has_tri) { live = false; unreported = true; } }
                 else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
             }
@@ -313,32 +313,40 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
         r1.w = 0.0f; r2.w = 0.0f;
         if (has_tri) {
+            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u;
             t_mask = t_rest;
             const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
+        }
+        if (has_tri2) {
+            tri_pk2 = t_base + (uint32_t)__ffs((int)t_rest) - 1u;
+            t_mask = t_rest & (t_rest - 1u);
+            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk2;
+            n0 = pk[0]; n1 = pk[1]; n2 = pk[2];
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
             n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
-        if (has_tri) {
+        auto consider = [&](const float4 q0, const float4 q1, const float4 q2, const uint32_t pk_index) {
             float t, U, V, ad;
-            if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
-                if ((tagw >> 31) != 0) { best_pk = tri_pk; live = false; unreported = true; }   // any-hit ray: done
+            if (tri_test(q0, q1, q2, o, d, 0.0f, best_t, t, U, V, ad)) {
+                if ((tagw >> 31) != 0) { best_pk = pk_index; live = false; unreported = true; }   // any-hit ray: done
                 else {
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                    if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // t == best_t: ties go to the lowest id (rare)
-                    if (better) { best_t = t; best_pk = tri_pk; }
+                    if (!better) better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // t == best_t: ties go to the lowest id (rare)
+                    if (better) { best_t = t; best_pk = pk_index; }
                 }
             }
-        }
+        };
+        if (has_tri) consider(r0, r1, r2, tri_pk);
+        if (has_tri2 && live) consider(n0, n1, n2, tri_pk2);
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
-            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, 0.0f, best_t, node_hits, tri_hits);
-            uint32_t sp = (g_mask >> 16) & 0x1Fu;
+            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            uint32_t sp = g_mask >> 16;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            const uint32_t cb = __float_as_uint(n1.x);            // child_base | leaf children << 24
-            g_base = cb & 0x00FFFFFFu; g_mask = ((cb >> 24) << 21) | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
