@@ -14,6 +14,16 @@ MRT_DEV float safe_inv(float d) {
     return 1.0f / a;
 }
 
+// 1 / d for the slab tests of the stream and the two-level traversal: v_rcp_f32 (1 ulp) + one Newton step instead of the IEEE division sequence (13 instead of
+// 37 issue cycles, three per refilled ray).  Only box tests see it — they have to be conservative, not exact: the error (< 1 ulp) is two
+// orders of magnitude below the build-time padding of the leaf boxes (1e-5 |coord| + 1e-6) and the far side is widened by 4 ulp.  The
+// triangle test, hence the image, does not depend on it.
+MRT_DEV float box_inv(float d) {
+    const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+    const float r = __builtin_amdgcn_rcpf(a);
+    return __builtin_fmaf(r, __builtin_fmaf(-a, r, 1.0f), r);
+}
+
 // One triangle, Möller–Trumbore in the fused mrt-math form; division only after the barycentric
 // tests pass.  Returns true when 0 <= tmin <= t <= lim.
 MRT_DEV bool tri_test(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float tmin, float lim, float &t, float &U, float &V, float &ad) {

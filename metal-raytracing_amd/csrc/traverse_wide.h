@@ -49,16 +49,6 @@ MRT_DEV void wstack_pop(const uint32_t *stack, uint32_t sp, uint32_t lane, uint3
     g_base = w >> 8; g_mask = ((w & 0xFFu) << 8) | im;
 }
 
-// 1 / d for the slab tests of the stream traversal: v_rcp_f32 (1 ulp) + one Newton step instead of the IEEE division sequence (13 instead of
-// 37 issue cycles, three per refilled ray).  Only box tests see it — they have to be conservative, not exact: the error (< 1 ulp) is two
-// orders of magnitude below the build-time padding of the leaf boxes (1e-5 |coord| + 1e-6) and the far side is widened by 4 ulp.  The
-// triangle test, hence the image, does not depend on it.
-MRT_DEV float box_inv(float d) {
-    const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
-    const float r = __builtin_amdgcn_rcpf(a);
-    return __builtin_fmaf(r, __builtin_fmaf(-a, r, 1.0f), r);
-}
-
 // The eight quantised child boxes of one wide node against a ray: node_hits = bit (slot ^ octant) per internal child hit
 // (so that ffs walks them front to back), tri_hits = bit k per packet tri_base + k of the leaf children hit.
 // Plane distance t = q * (2^e * idir) + (p - o) * idir, one fma per plane; the decode error of the fused evaluation is far
