@@ -270,6 +270,8 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
 /* Diagnostics: lane accounting of the wide stream traversal, per wave of `per_wave` rays:
  * {iterations, sum live lanes, sum node lanes, sum triangle lanes, refills, refilled lanes, hits, rays}.       */
 int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves);
+/* Diagnostics: fill of the 8-wide nodes: out12[c] = nodes with c children (c = 0..8), [9] internal children, [10] leaf children, [11] triangles. */
+int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
 /* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of
  * `triangles` triangles whose BVH keeps `nodes` nodes (0 = unknown) cannot be addressed by the traversal layouts.      */
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes);

@@ -542,6 +542,14 @@ int mrt_debug_seeds(MRTContext ctx, uint32_t seed, int32_t width, int32_t height
     MRT_CATCH
 }
 
+int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12) {
+    MRT_TRY
+    REQUIRE(scene && out12, "mrt_debug_wide_histogram: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_debug_wide_histogram: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::wide_histogram(scene->dev, scene->ctx->stream, out12);
+    MRT_CATCH
+}
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes) {
     MRT_TRY
     return mrt::layout_limits(triangles, nodes);

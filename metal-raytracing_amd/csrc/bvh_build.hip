@@ -578,7 +578,30 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// diagnostics: how full are the 8-wide nodes?  out[c] = nodes with c children (c = 0..8), out[9] = internal children, out[10] = leaf children, out[11] = triangles
+__global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 n0 = wnodes[WNODE_STRIDE * (size_t)i], n1 = wnodes[WNODE_STRIDE * (size_t)i + 1];
+    const uint32_t imask = __float_as_uint(n0.w) >> 24, meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+    uint32_t leaves = 0, tris = 0;
+    for (int k = 0; k < 8; k++) { const uint32_t cnt = ((meta[k >> 2] >> (8 * (k & 3))) & 0xFFu) >> 5; if (cnt) { leaves++; tris += cnt; } }
+    const uint32_t inner = (uint32_t)__popc(imask);
+    atomicAdd(&out[inner + leaves], 1u); atomicAdd(&out[9], inner); atomicAdd(&out[10], leaves); atomicAdd(&out[11], tris);
+}
+
 }  // namespace
+
+int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]) {
+    memset(out12, 0, 48);
+    if (sc.num_wnodes == 0) return MRT_OK;
+    DevBuf<uint32_t> d; MRT_HIP(d.alloc(12));
+    MRT_HIP(hipMemsetAsync(d.p, 0, 48, stream));
+    hipLaunchKernelGGL(k_wide_histogram, dim3(cdiv(sc.num_wnodes, 256)), dim3(256), 0, stream, sc.wnodes.p, sc.num_wnodes, d.p);
+    MRT_HIP(hipMemcpyAsync(out12, d.p, 48, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    return MRT_OK;
+}
 
 SceneView DeviceScene::view() const {
     SceneView v{};

@@ -155,6 +155,7 @@ struct DeviceScene {
 
 // bvh_build.hip
 void pack_material(const MRTMaterial &m, float4 *out3);
+int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
