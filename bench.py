@@ -126,6 +126,13 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames,
            "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU",
            "kernel_ms_serialised": {k: round(statistics.median(v), 4) for k, v in per_kernel.items()}}
+    # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
+    q.set_option("megakernel", 1); q.draw(3, wait=True)
+    mk = []
+    for _ in range(frames):
+        q.draw(1, wait=True); mk.append(q.stats.ms_gpu_last)
+    out["megakernel_ms_per_frame"] = round(statistics.median(mk), 4)
+    q.set_option("megakernel", 0)
     q.set_option("frames_in_flight", 3)
     q.draw(6, wait=True)
     t0 = time.perf_counter(); q.draw(30, wait=True); dt = time.perf_counter() - t0

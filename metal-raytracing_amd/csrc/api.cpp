@@ -405,6 +405,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= (r->r.materials ? 16 : 19), "max_bounces must be in [1,19] ([1,16] with materials = 1)"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
     else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
+    else if (k == "megakernel") r->r.megakernel = value != 0;
     else if (k == "fused") r->r.fused = value != 0;
     else if (k == "materials") { REQUIRE(value == 0 || (value == 1 && r->r.max_bounces <= 16), "materials must be 0 or 1 (and max_bounces <= 16: the lobe choice uses Halton dimension 2 + 5 * max_bounces + bounce < 100)"); r->r.materials = value != 0; }
     else if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
@@ -429,6 +430,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "frame_batch") *value = r->r.frame_batch;
     else if (k == "lanes_used") *value = r->r.lanes_used;
     else if (k == "lane_bytes") *value = (double)r->r.lane_bytes();
+    else if (k == "megakernel") *value = r->r.megakernel ? 1 : 0;
     else if (k == "fused") *value = r->r.fused ? 1 : 0;
     else if (k == "materials") *value = r->r.materials ? 1 : 0;
     else if (k == "persistent") *value = r->r.persistent;

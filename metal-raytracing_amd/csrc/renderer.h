@@ -45,6 +45,8 @@ struct Renderer {
     int lanes_used = 0;                  // lanes the last draw ran on (<= frames_in_flight when device memory is short)
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
+    bool megakernel = false;             // one launch per frame (k_megakernel): lowest latency of a single frame; the wavefront pipeline has the higher throughput
+    int mega_slots = 0; size_t mega_slots_for_stack = ~(size_t)0;
     bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
     bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
     bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel

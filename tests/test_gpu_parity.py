@@ -597,3 +597,34 @@ def test_c5_1080p_spp16_builder_invariance_and_determinism(mrt, gpu_ctx):
     assert st.primary_rays == 16 * 1920 * 1080 and st.primary_rays <= st.closest_rays <= 3 * st.primary_rays and 0 < st.shadow_rays <= st.closest_rays
     assert np.isfinite(ia).all() and (ia[..., 3] == 1).all()
     a.close()
+
+
+# ---------------------------------------------------------------- the one-launch-per-frame megakernel (renderer option megakernel = 1)
+@pytest.mark.parametrize("case", ["cornell", "dragon", "lights", "ragged_shard"])
+def test_megakernel_matches_oracle_and_wavefront_pipeline(mrt, orc, gpu_ctx, case):
+    """k_megakernel carries whole paths per lane (no ray queues, no k_shade, no k_accumulate): same image, same ray counts, bit for bit."""
+    bounces, shard = 3, None
+    if case == "cornell":
+        w, h, frames = 256, 256, 3; sc = mrt.CornellScene((w, h))
+    elif case == "dragon":
+        w, h, frames = 320, 180, 2; sc = mrt.DragonScene((w, h)); bounces = 4
+    elif case == "lights":
+        w, h, frames = 160, 96, 2; sc = mrt.GardenScene((w, h))
+        sc.lights = sc.lights + [mrt.Light.pointLight([0, 2.5, 1], [3, 2, 1]), mrt.Scene.setupLight()]
+    else:
+        w, h, frames = 75, 43, 3; sc = mrt.CornellScene((w, h)); shard = (1, 3)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, max_bounces=bounces)
+    r.set_option("megakernel", 1)
+    if shard: r.set_shard(*shard)
+    r.draw(frames, wait=True)
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, frames, bounces=bounces, shard=shard)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    q = mrt.Renderer((w, h), sc, ctx=gpu_ctx, max_bounces=bounces)
+    if shard: q.set_shard(*shard)
+    q.draw(frames, wait=True)
+    assert np.array_equal(q.accumulation(), r.accumulation()) and q.stats.primary_rays == r.stats.primary_rays
+    # switching the option between draws continues the same accumulation
+    r.set_option("megakernel", 0); r.draw(2, wait=True); q.set_option("megakernel", 1); q.draw(2, wait=True)
+    assert np.array_equal(q.accumulation(), r.accumulation()) and r.frameIndex == frames + 2
+    r.close(); q.close()
