@@ -270,6 +270,10 @@ int mrt_debug_traversal_stats(MRTScene scene, const MRTRay *rays, size_t n, int3
 /* Diagnostics: lane accounting of the wide stream traversal, per wave of `per_wave` rays:
  * {iterations, sum live lanes, sum node lanes, sum triangle lanes, refills, refilled lanes, hits, rays}.       */
 int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, uint32_t per_wave, uint32_t *out8, size_t nwaves);
+/* The render kernels' own traversal (8-wide layout, wave-level stream with lane refill; TLAS + BLASes of an instanced scene in one loop)
+ * on caller rays, for parity tests of that path against mrt_scene_intersect_closest / _any.  min_distance must be 0.  any_hit != 0:
+ * only out[i].type (1 = occluded) is meaningful.                                                                                   */
+int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, MRTIntersection *out);
 /* Diagnostics: fill of the 8-wide nodes: out12[c] = nodes with c children (c = 0..8), [9] internal children, [10] leaf children, [11] triangles. */
 int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
 /* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of

@@ -170,6 +170,7 @@ SIGNATURES = {
     "mrt_debug_hemisphere": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_seeds": (C.c_int, [_P, _U32, _I32, _I32, _P]),
     "mrt_debug_traversal_stats": (C.c_int, [_P, _P, _SZ, _I32, _P]),
+    "mrt_debug_intersect_stream": (C.c_int, [_P, _P, _SZ, _I32, _P]),
     "mrt_debug_stream_stats": (C.c_int, [_P, _P, _SZ, _I32, _U32, _P, _SZ]),
     "mrt_debug_calibrate": (C.c_int, [_P, _SZ, _P]),
     "mrt_debug_wide_histogram": (C.c_int, [_P, _P]),

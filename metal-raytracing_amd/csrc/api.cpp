@@ -286,6 +286,15 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
     MRT_CATCH
 }
 
+int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, MRTIntersection *out) {
+    MRT_TRY
+    REQUIRE(scene && rays && out, "mrt_debug_intersect_stream: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_debug_intersect_stream: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::query_stream(scene->dev, scene->ctx->stream, rays, n, any_hit ? 1 : 0, out);
+    MRT_CATCH
+}
+
 // ---------------------------------------------------------------- host geometry helpers
 int mrt_obj_load(const char *obj_path, MRTMeshData *out) {
     MRT_TRY

@@ -608,7 +608,7 @@ SceneView DeviceScene::view() const {
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
-    v.inst = inst.p; v.tlas_index = tlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
+    v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
@@ -660,7 +660,7 @@ void pack_material(const MRTMaterial &m, float4 *out3) {
 
 int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
-    out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.bnodes.release(); out.h_inst.clear();
+    out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
     // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
@@ -850,7 +850,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
     float area = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.root_lo[0] = rlo.x; out.root_lo[1] = rlo.y; out.root_lo[2] = rlo.z; out.root_hi[0] = rhi.x; out.root_hi[1] = rhi.y; out.root_hi[2] = rhi.z;
-    out.stats.bvh_nodes = h_size;
+    out.stats.bvh_nodes = h_size; out.rope_nodes = h_size;
     out.stats.bvh_leaves = h_stat[1];
     out.stats.max_depth = (int32_t)h_stat[0];
     out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;

@@ -92,6 +92,7 @@ struct Renderer {
 int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out);
 int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out);
 int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4);
+int query_stream(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, MRTIntersection *out);
 int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t per_wave, uint32_t *out8, size_t nwaves);
 int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out);
 int probe_hemisphere(hipStream_t stream, const float *u2, const float *n3, size_t n, float *out3);

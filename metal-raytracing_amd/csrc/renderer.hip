@@ -235,7 +235,8 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
 #ifndef MRT_WIDE_STREAM_WAVES
 #define MRT_WIDE_STREAM_WAVES 7
 #endif
-__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    traverse_wide_stream(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
@@ -259,14 +260,15 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
 
 // Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
 // `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
-__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
-    traverse_wide_stream(s, SharedCounter{work, n, chunk}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, SharedCounter{work, n, chunk}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
@@ -505,12 +507,13 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
 
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
+template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
     hits += (size_t)sub * capacity; dirs += (size_t)sub * capacity;
-    traverse_wide_stream(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
@@ -858,6 +861,32 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     }
 }
 
+// the render kernels' traversal (8-wide stream with lane refill; both levels of an instanced scene) on caller rays — parity tests of that path
+template <bool TWO_LEVEL>
+__global__ void __launch_bounds__(64) k_query_stream(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t per_wave, MRTIntersection *__restrict__ out) {
+    extern __shared__ uint32_t stk_dyn[];
+    const uint32_t begin = blockIdx.x * per_wave;
+    if (begin >= n) return;
+    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(n, begin + per_wave)}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu; is_any = (uint32_t)any;
+            A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f);
+        },
+        [&](uint32_t i, bool is_any, bool hit, const TravHit &h) {
+            MRTIntersection o;
+            o._pad = 0; o.type = hit ? 1 : 0; o.distance = -1.0f; o.instance_id = o.geometry_id = o.primitive_id = -1; o.u = o.v = 0.0f;
+            if (hit && !is_any) {
+                uint32_t inst, geom;
+                if (TWO_LEVEL) { inst = instance_of_gid(s, h.gid); const InstanceDev &I = s.inst[inst]; geom = s.tri_shade[I.ts_base + (h.gid - I.gid_base)].w & 0xFFFFu; }
+                else { const uint4 ts = s.tri_shade[h.gid]; inst = ts.w >> 16; geom = ts.w & 0xFFFFu; }
+                o.distance = h.t; o.instance_id = (int32_t)inst; o.geometry_id = (int32_t)geom;
+                o.primitive_id = (int32_t)(h.gid - s.geom_base[inst * (uint32_t)s.max_sub + geom]);
+                o.u = h.U / h.ad; o.v = h.V / h.ad;
+            }
+            out[i] = o;
+        });
+}
+
 // ------------------------------------------------------------------ device-function probes
 __global__ void k_probe_halton(const int32_t *i, const int32_t *d, uint32_t n, float *out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1067,11 +1096,13 @@ int Renderer::render(int n_frames) {                                   // Render
             // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;
-            const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
+            // two-level scenes walk TLAS and BLASes with the same kernels (traverse_wide_stream<true>); their LDS also parks the lanes' world rays
+            const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (two_level ? WIDE_WORLD_RAY_BYTES : 0);
             if (on_wide && persistent != 0 && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
                 int per_cu = 0, dev = 0; hipDeviceProp_t prop;
                 MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
-                MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist, 64, stack_bytes));
+                if (two_level) MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<true>, 64, stack_bytes));
+                else MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<false>, 64, stack_bytes));
                 if (!wave_slots_user) wave_slots = std::max(1, per_cu) * prop.multiProcessorCount;
                 slots_for_stack = stack_bytes;
             }
@@ -1081,7 +1112,8 @@ int Renderer::render(int n_frames) {                                   // Render
             auto timed = [&](int kind) -> EvPair * { if (ext_used >= (int)ev_ext.size()) return nullptr; ev_ext[ext_used].kind = kind; return &ev_ext[ext_used++]; };
             fp.bounce = 0;
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
-            if (primary_wide && sv.num_wnodes) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
+            if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
+            else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
             else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
             int q = 0;                                                  // shade(b) writes next rays into queue q
@@ -1104,12 +1136,15 @@ int Renderer::render(int n_frames) {                                   // Render
                     const size_t slots = 2 * (size_t)capacity * B;
                     const uint32_t chunk = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / ((size_t)wave_slots * 4) / 64 * 64));
                     const uint32_t waves = (uint32_t)std::min<size_t>(cdiv(slots, chunk), (size_t)wave_slots);
-                    launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
                                  (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk);
                 }
-                else if (on_wide && wide_stream) {
-                    launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
-                    if (shadow_rope) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                else if (on_wide && (wide_stream || two_level)) {
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, dim3(cdiv(2 * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, 0, rpw_m);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
+                    if (shadow_rope && !two_level) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
                 else if (on_wide) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<true>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
@@ -1265,6 +1300,24 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_query_stream_stats, dim3((uint32_t)nwaves), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+
+int query_stream(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, MRTIntersection *out) {
+    if (n == 0) return MRT_OK;
+    if (sc.num_wnodes == 0) { set_error("the scene has no 8-wide layout"); return MRT_ERR_UNSUPPORTED; }
+    for (size_t i = 0; i < n; i++) if (rays[i].min_distance != 0.0f) { set_error("the stream traversal starts every ray at distance 0 (min_distance must be 0)"); return MRT_ERR_INVALID_ARGUMENT; }
+    if (n >= (size_t(1) << 31)) { set_error("too many rays"); return MRT_ERR_INVALID_ARGUMENT; }
+    DevBuf<MRTRay> d_r; DevBuf<MRTIntersection> d_o;
+    MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
+    MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+    const uint32_t per_wave = 256;
+    const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : 0);
+    if (sc.num_inst) hipLaunchKernelGGL(k_query_stream<true>, dim3(cdiv(n, per_wave)), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, d_o.p);
+    else hipLaunchKernelGGL(k_query_stream<false>, dim3(cdiv(n, per_wave)), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, d_o.p);
+    MRT_HIP(hipMemcpyAsync(out, d_o.p, n * sizeof(MRTIntersection), hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     return MRT_OK;

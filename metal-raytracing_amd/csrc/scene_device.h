@@ -46,6 +46,8 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 #endif
 constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wide nodes in HBM (5 = packed 80 B; 8 = one 128-B line each)
 constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
+constexpr int WIDE_STACK_TWO_LEVEL = 30;   // two-level scenes: TLAS levels + 1 (the TLAS group parked at instance entry) + the deepest BLAS; 5-bit depth fields
+constexpr uint32_t WIDE_WORLD_RAY_BYTES = 6 * 64 * 4;   // two-level stream traversal: the world-space ray of every lane (o.xyz, d.xyz) parked in LDS in front of the stack
 constexpr uint32_t WIDE_STACK_LEVEL_BYTES = 320;   // per wave and level: 64 x 4 B {child_base << 8 | hit bits} + 64 x 1 B {imask}
 
 struct LightDev {            // 96 B, derived once per mrt_scene_set_lights from the 128-B MRTLight
@@ -69,7 +71,8 @@ struct InstanceDev {          // 80 B
     uint32_t gid_base;        // global id of its first triangle: instance-major, then geometry, then primitive — the numbering of the flattened scene
     uint32_t ts_base;         // first shading record of its BLAS in `tri_shade`
     uint32_t vbase;           // first vertex of its mesh in `normals`
-    uint32_t ntri, blas, _pad;
+    uint32_t ntri, blas;
+    uint32_t wroot;           // root of its BLAS in the shared 8-wide array `wnodes` (child / packet indices in there are absolute)
 };
 
 struct SceneView {           // passed by value to kernels
@@ -88,6 +91,7 @@ struct SceneView {           // passed by value to kernels
     // two-level scenes: `nodes` is the TLAS; num_inst == 0 -> flattened scene
     const InstanceDev *inst;
     const uint32_t *tlas_index;  // instance ids, TLAS leaf order
+    const uint32_t *wtlas_index; // instance ids in the leaf order of the 8-wide TLAS (wnodes[0 ..]: its leaf children are single instances)
     const float4 *bnodes;        // rope nodes of all BLASes, 4 x float4 each; followed, in the same allocation, by
     const float4 *bpackets;      // their triangle packets (object space), 3 x float4 each
     uint32_t num_inst;
@@ -137,6 +141,7 @@ struct BuildOptions {
 struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
+    uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;
     DevBuf<uint32_t> geom_base;
@@ -145,7 +150,8 @@ struct DeviceScene {
     MRTSceneStats stats{};
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};     // box of the whole tree (padded leaf boxes)
     // two-level scenes (two_level.hip)
-    DevBuf<InstanceDev> inst; DevBuf<uint32_t> tlas_index; DevBuf<float4> bnodes;
+    DevBuf<InstanceDev> inst; DevBuf<uint32_t> tlas_index, wtlas_index; DevBuf<float4> bnodes;
+    uint32_t tlas_wcap = 0; int blas_wdepth = 0;               // 8-wide layout: node slots reserved for the TLAS in front of the BLASes, deepest BLAS (0: rope only)
     size_t bpackets_offset = 0; uint32_t num_inst = 0;
     std::vector<InstanceDev> h_inst;                           // host copy: transform updates rewrite the rows and rebuild the TLAS only
     std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each

@@ -14,6 +14,7 @@
 // with ties to the lowest triangle id, and the quantised boxes only ever grow.
 #pragma once
 #include "traverse.h"
+#include "traverse_instanced.h"
 
 namespace mrt {
 namespace {
@@ -197,9 +198,20 @@ struct SharedCounter {
     }
 };
 
-template <class Chunks, class RayFetch, class Emit>
+//
+// TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
+// (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
+// the same stack: a lane whose pending "triangle" is an instance parks the TLAS group it came from on the stack, takes its ray into object space
+// (direction not renormalised: t stays the world-space distance) and enters the BLAS root; when nothing of the BLAS is left — stack depth back
+// at the entry depth — it restores the world ray from LDS and pops the parked group.  g_mask carries the entry depth in bits 24..28 (0 = at the
+// TLAS level), the stack depth in bits 16..20.  `stack` then starts with WIDE_WORLD_RAY_BYTES of parked world rays.
+template <bool TWO_LEVEL = false, class Chunks, class RayFetch, class Emit>
 MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
+    float *const wray = reinterpret_cast<float *>(stack);      // [6][64]: o.xyz, d.xyz of the lane's ray in world space (TWO_LEVEL)
+    if (TWO_LEVEL) stack += WIDE_WORLD_RAY_BYTES / 4u;
+    uint32_t insts = 0;                                   // TWO_LEVEL: instance being walked | instance of the closest hit << 16
+    uint32_t tl_pack = 0;                                 // TWO_LEVEL: the TLAS leaf's remaining instances while inside a BLAS: tri_base << 8 | mask
     const unsigned long long lt = (1ull << lane) - 1ull;
     // prefetched batch: rays batch_base .. batch_base + batch_n - 1, one per lane; pB.w = tag | any-hit flag << 31
     float4 pA = make_float4(0, 0, 0, 0), pB = pA;
@@ -223,8 +235,15 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)best_pk;
                     const float4 q0 = pk[0];
                     float t_;
-                    (void)tri_test(q0, pk[1], pk[2], o, d, 0.0f, __builtin_inff(), t_, h.U, h.V, h.ad);
-                    h.gid = __float_as_uint(q0.w);
+                    if (TWO_LEVEL) {            // in the object space of the hit's instance, from the parked world ray
+                        const InstanceDev &I = s.inst[insts >> 16];
+                        const f3 wo = mk3(wray[lane], wray[64 + lane], wray[128 + lane]), wd = mk3(wray[192 + lane], wray[256 + lane], wray[320 + lane]);
+                        (void)tri_test(q0, pk[1], pk[2], to_object_point(I, wo), to_object_dir(I, wd), 0.0f, __builtin_inff(), t_, h.U, h.V, h.ad);
+                        h.gid = I.gid_base + __float_as_uint(q0.w);
+                    } else {
+                        (void)tri_test(q0, pk[1], pk[2], o, d, 0.0f, __builtin_inff(), t_, h.U, h.V, h.ad);
+                        h.gid = __float_as_uint(q0.w);
+                    }
                 }
                 emit(tagw & 0x7FFFFFFFu, was_any, was_hit, h); unreported = false;
             }
@@ -255,6 +274,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     // enter the root as the only "hit child" of a pseudo group: base 0, no internal-child bits -> node 0; empty stack
                     g_base = 0; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;
                     live = true;
+                    if (TWO_LEVEL) {
+                        wray[lane] = ax_; wray[64 + lane] = ay_; wray[128 + lane] = az_; wray[192 + lane] = bx_; wray[256 + lane] = by_; wray[320 + lane] = bz_;
+                        insts = 0; tl_pack = 0;
+                    }
                 }
                 batch_used += min(avail, n_idle);
                 if (ss) { ss->refills++; ss->refill_lanes += min(avail, n_idle); }
@@ -267,9 +290,23 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         // with the triangle packet (48 B), tests the triangle, then the node's eight boxes against the possibly shorter ray.
         // (Measured, full frame: node-or-triangle per iteration 6.90, node then triangle with two round trips 7.24,
         // this loop 7.44 Grays/s.)
-        const bool has_tri = live && t_mask != 0;
+        if (TWO_LEVEL) {
+            // a lane inside a BLAS with nothing of it left (no triangle pending, no hit child, stack back at the entry depth) returns to world
+            // space and to the TLAS group parked at entry — in this same iteration it goes on to its next instance or TLAS node
+            const uint32_t sp = (g_mask >> 16) & 0xFFu, isp = g_mask >> 24;
+            if (live && isp != 0u && t_mask == 0u && (g_mask & 0xFF00u) == 0u && sp == isp) {
+                o = mk3(wray[lane], wray[64 + lane], wray[128 + lane]); d = mk3(wray[192 + lane], wray[256 + lane], wray[320 + lane]);
+                ix = box_inv(d.x); iy = box_inv(d.y); iz = box_inv(d.z);
+                nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16;
+                t_base = tl_pack >> 8; t_mask = tl_pack & 0xFFu;
+            }
+        }
+        const bool in_blas = TWO_LEVEL && (g_mask >> 24) != 0u;
+        const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter
+        const bool has_tri = live && t_mask != 0 && !has_inst;
         const uint32_t t_rest = t_mask & (t_mask - 1u);         // triangles left after this iteration's first one
-        bool want_node = live && t_rest == 0u;
+        bool want_node = live && t_rest == 0u && !has_inst;
 #if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
         {
             const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
@@ -282,11 +319,30 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         const bool has_tri2 = false;
 #endif
         uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
-        if (want_node) {
+        if (TWO_LEVEL && has_inst) {
+            // enter the next instance of the TLAS leaf: park the TLAS group (always, also without siblings left: the exit pops it), take the ray
+            // into object space, and fetch the BLAS root in this same iteration
+            const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
+            t_mask &= t_mask - 1u;
+            const uint32_t id = s.wtlas_index[t_base + k];
+            const InstanceDev &I = s.inst[id];
+            tl_pack = (t_base << 8) | t_mask;
+            uint32_t sp = (g_mask >> 16) & 0xFFu;
+            wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++;
+            const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
+            o = oo; d = dd; ix = box_inv(d.x); iy = box_inv(d.y); iz = box_inv(d.z);
+            nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+            g_base = 0; g_mask = (sp << 24) | (sp << 16);          // no group yet: the root's children become the first one
+            t_base = 0; t_mask = 0;
+            insts = (insts & 0xFFFF0000u) | id;
+            pending = I.wroot; want_node = true;
+        }
+        else if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
-                const uint32_t sp = g_mask >> 16;
-                if (sp == 0) { want_node = false; if (!has_tri) { live = false; unreported = true; } }
-                else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
+                const uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16, isp = TWO_LEVEL ? g_mask >> 24 : 0u;
+                if (TWO_LEVEL && isp != 0u && sp == isp) want_node = false;      // the BLAS's last triangle is tested in this iteration; the lane leaves in the next
+                else if (sp == 0) { want_node = false; if (!has_tri) { live = false; unreported = true; } }
+                else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= ((sp - 1u) << 16) | (isp << 24); }
             }
             if (want_node) {
                 const uint32_t hits = (g_mask >> 8) & 0xFFu;
@@ -324,8 +380,11 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 if ((tagw >> 31) != 0) { best_pk = pk_index; live = false; unreported = true; }   // any-hit ray: done
                 else {
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                    if (!better) better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // t == best_t: ties go to the lowest id (rare)
-                    if (better) { best_t = t; best_pk = pk_index; }
+                    if (!better) {                                      // t == best_t: ties go to the lowest (global) id (rare)
+                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + __float_as_uint(q0.w) < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                        else better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                    }
+                    if (better) { best_t = t; best_pk = pk_index; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
                 }
             }
         };
@@ -334,9 +393,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
-            uint32_t sp = g_mask >> 16;
+            uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16;
+            const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }

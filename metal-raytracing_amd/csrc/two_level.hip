@@ -13,6 +13,10 @@
 //          host: median split of the box centres along the widest axis, leaves of up to two instances.  Instance counts are small
 //          (<= 65 535 by the ABI) and the build is microseconds; a transform change rebuilds ONLY this tree and the 80-byte
 //          instance rows (update_tlas) — the BLASes are never touched ("refit" of an animated scene).
+//   8-wide every BLAS also gets the compressed 8-wide layout (bvh_build.hip k_wide_level), all of them in ONE node array with absolute child /
+//          packet indices, behind `tlas_wcap` slots reserved for an 8-wide TLAS whose leaf children are single instances (WideTlasBuilder,
+//          same node format, host-built, rewritten in place by update_tlas).  The stream traversal of traverse_wide.h walks both levels
+//          with one loop and one LDS stack; the rope layout stays for the query kernels and as the A/B path (wide_bounce = 0).
 #include "scene_device.h"
 #include <algorithm>
 #include <chrono>
@@ -117,6 +121,127 @@ struct TlasBuilder {
     }
 };
 
+
+// 8-wide TLAS in the node format of scene_device.h: a median-split binary tree over the instance boxes (leaves = ONE instance), collapsed
+// greedily (largest surface area first) into nodes of up to eight children, BFS-numbered so that a node's internal children are contiguous;
+// child slots by octant of the child centre, boxes quantised outwards to 8 bits on the node's power-of-two grid — the host restatement of
+// k_wide_level.  A leaf child's "packet" tri_base + offset is an entry of `order` (instance ids).
+struct WideTlasBuilder {
+    const std::vector<Box> &boxes;
+    struct BNode { Box b; int left = -1, right = -1, inst = -1; };
+    std::vector<BNode> bn;
+    std::vector<uint32_t> order;          // instance ids, leaf-child order
+    std::vector<float4> nodes;            // 5 per wide node
+    int depth = 0;
+    explicit WideTlasBuilder(const std::vector<Box> &b) : boxes(b) {}
+    static float area(const Box &q) { const float x = q.hi[0] - q.lo[0], y = q.hi[1] - q.lo[1], z = q.hi[2] - q.lo[2]; return x * y + y * z + z * x; }
+    int binary(std::vector<uint32_t> &ids, uint32_t first, uint32_t count) {
+        BNode n; for (int k = 0; k < 3; k++) { n.b.lo[k] = 3.0e38f; n.b.hi[k] = -3.0e38f; }
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = first; i < first + count; i++) {
+            const Box &q = boxes[ids[i]];
+            for (int k = 0; k < 3; k++) {
+                n.b.lo[k] = std::min(n.b.lo[k], q.lo[k]); n.b.hi[k] = std::max(n.b.hi[k], q.hi[k]);
+                const float c = 0.5f * (q.lo[k] + q.hi[k]); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c);
+            }
+        }
+        const int me = (int)bn.size(); bn.push_back(n);
+        if (count == 1) { bn[me].inst = (int)ids[first]; return me; }
+        int ax = 0; if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1; if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        const uint32_t half = count / 2;
+        std::nth_element(ids.begin() + first, ids.begin() + first + half, ids.begin() + first + count, [&](uint32_t x, uint32_t y) {
+            const float cx = boxes[x].lo[ax] + boxes[x].hi[ax], cy = boxes[y].lo[ax] + boxes[y].hi[ax];
+            return cx < cy || (cx == cy && x < y);
+        });
+        const int l = binary(ids, first, half), r = binary(ids, first + half, count - half);
+        bn[me].left = l; bn[me].right = r;
+        return me;
+    }
+    static float4 f4u(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { float f[4]; uint32_t u[4] = {a, b, c, d}; memcpy(f, u, 16); return make_float4(f[0], f[1], f[2], f[3]); }
+    void build(std::vector<uint32_t> ids) {
+        if (ids.empty()) return;
+        const int root = binary(ids, 0, (uint32_t)ids.size());
+        std::vector<int> level{root};                 // binary nodes that become the wide nodes of this level
+        uint32_t base = 0;
+        while (!level.empty()) {
+            depth++;
+            std::vector<int> next;
+            const uint32_t next_base = base + (uint32_t)level.size();
+            nodes.resize(nodes.size() + 5 * level.size());
+            for (size_t i = 0; i < level.size(); i++) {
+                const BNode &f = bn[(size_t)level[i]];
+                int ch[8], nch = 0;
+                if (f.inst >= 0) ch[nch++] = level[i];
+                else {
+                    ch[nch++] = f.left; ch[nch++] = f.right;
+                    while (nch < 8) {
+                        int best = -1; float ba = -1.0f;
+                        for (int k = 0; k < nch; k++) if (bn[(size_t)ch[k]].inst < 0) { const float a = area(bn[(size_t)ch[k]].b); if (a > ba) { ba = a; best = k; } }
+                        if (best < 0) break;
+                        const int c = ch[best];
+                        ch[best] = bn[(size_t)c].left; ch[nch++] = bn[(size_t)c].right;
+                    }
+                }
+                int child_in_slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+                const float cx = f.b.lo[0] + f.b.hi[0], cy = f.b.lo[1] + f.b.hi[1], cz = f.b.lo[2] + f.b.hi[2];
+                for (int k = 0; k < nch; k++) {
+                    const Box &q = bn[(size_t)ch[k]].b;
+                    const int pref = ((q.lo[0] + q.hi[0]) > cx ? 1 : 0) | ((q.lo[1] + q.hi[1]) > cy ? 2 : 0) | ((q.lo[2] + q.hi[2]) > cz ? 4 : 0);
+                    int bs = -1, bd = 99;
+                    for (int sl = 0; sl < 8; sl++) if (child_in_slot[sl] < 0) { const int dd = __builtin_popcount((unsigned)(sl ^ pref)); if (dd < bd) { bd = dd; bs = sl; } }
+                    child_in_slot[bs] = k;
+                }
+                uint32_t eb[3]; float step[3], inv_step[3];
+                for (int a = 0; a < 3; a++) {
+                    const float sdiv = (f.b.hi[a] - f.b.lo[a]) / 255.0f;
+                    uint32_t bits; memcpy(&bits, &sdiv, 4);
+                    uint32_t e = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+                    e = std::min(254u, std::max(1u, e));
+                    eb[a] = e;
+                    const uint32_t sb = e << 23, ib = (254u - e) << 23; memcpy(&step[a], &sb, 4); memcpy(&inv_step[a], &ib, 4);
+                }
+                uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, meta[2] = {0, 0}, imask = 0, off_t = 0;
+                const uint32_t my_i = next_base + (uint32_t)next.size(), my_t = (uint32_t)order.size();
+                for (int sl = 0; sl < 8; sl++) {
+                    const int k = child_in_slot[sl];
+                    uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
+                    if (k >= 0) {
+                        const BNode &c = bn[(size_t)ch[k]];
+                        for (int a = 0; a < 3; a++) {
+                            float fl = std::floor((c.b.lo[a] - f.b.lo[a]) * inv_step[a]), fh = std::ceil((c.b.hi[a] - f.b.lo[a]) * inv_step[a]);
+                            fl = std::min(std::max(fl, 0.0f), 255.0f); fh = std::min(std::max(fh, 0.0f), 255.0f);
+                            if (f.b.lo[a] + fl * step[a] > c.b.lo[a] && fl > 0.0f) fl -= 1.0f;
+                            if (f.b.lo[a] + fh * step[a] < c.b.hi[a] && fh < 255.0f) fh += 1.0f;
+                            ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
+                        }
+                        if (c.inst >= 0) { meta[sl >> 2] |= ((1u << 5) | off_t) << (8 * (sl & 3)); order.push_back((uint32_t)c.inst); off_t++; }
+                        else { imask |= 1u << sl; next.push_back(ch[k]); }
+                    }
+                    for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
+                }
+                const size_t w = 5 * (size_t)(base + i);
+                float ew; const uint32_t ewb = ((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24); memcpy(&ew, &ewb, 4);
+                nodes[w + 0] = make_float4(f.b.lo[0], f.b.lo[1], f.b.lo[2], ew);
+                nodes[w + 1] = f4u(my_i, my_t, meta[0], meta[1]);
+                nodes[w + 2] = f4u(q[0][0], q[0][1], q[1][0], q[1][1]);
+                nodes[w + 3] = f4u(q[2][0], q[2][1], q[3][0], q[3][1]);
+                nodes[w + 4] = f4u(q[4][0], q[4][1], q[5][0], q[5][1]);
+            }
+            base = next_base;
+            level.swap(next);
+        }
+    }
+};
+
+// a BLAS's 8-wide nodes after the copy into the shared array: child / packet bases become absolute
+__global__ void k_relocate_wide(float4 *__restrict__ wnodes, uint32_t n, uint32_t node_off, uint32_t packet_off) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 n1 = wnodes[WNODE_STRIDE * (size_t)i + 1];
+    n1.x = __uint_as_float(__float_as_uint(n1.x) + node_off); n1.y = __uint_as_float(__float_as_uint(n1.y) + packet_off);
+    wnodes[WNODE_STRIDE * (size_t)i + 1] = n1;
+}
+
 }  // namespace
 
 // instance rows + TLAS from the current transforms; BLAS data (out.bnodes, tri_shade, normals ...) is left alone
@@ -147,6 +272,20 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
     if (!tb.order.empty()) MRT_HIP(hipMemcpyAsync(out.tlas_index.p, tb.order.data(), tb.order.size() * 4, hipMemcpyHostToDevice, stream));
     if (!tb.nodes.empty()) MRT_HIP(hipMemcpyAsync(out.nodes.p, tb.nodes.data(), tb.nodes.size() * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols.data(), h_cols.size() * 16, hipMemcpyHostToDevice, stream));
+    // 8-wide TLAS into the slots reserved in front of the BLASes (only when every BLAS has the 8-wide layout)
+    WideTlasBuilder wb(boxes);
+    out.num_wnodes = 0; out.wide_depth = 0;
+    if (out.blas_wdepth > 0 && !live.empty()) {
+        wb.build(live);
+        const size_t wn = wb.nodes.size() / 5;
+        if (wn <= out.tlas_wcap && wb.depth + 1 + out.blas_wdepth <= WIDE_STACK_TWO_LEVEL && WNODE_STRIDE == 5) {
+            MRT_HIP(out.wtlas_index.alloc(std::max<size_t>(wb.order.size(), 1)));
+            MRT_HIP(hipMemcpyAsync(out.wtlas_index.p, wb.order.data(), wb.order.size() * 4, hipMemcpyHostToDevice, stream));
+            MRT_HIP(hipMemcpyAsync(out.wnodes.p, wb.nodes.data(), wb.nodes.size() * 16, hipMemcpyHostToDevice, stream));
+            out.num_wnodes = (uint32_t)(out.wnodes.n / WNODE_STRIDE);
+            out.wide_depth = wb.depth + 1 + out.blas_wdepth;
+        }
+    }
     MRT_HIP(hipStreamSynchronize(stream));
     out.num_inst = (uint32_t)I;
     out.stats.bvh_nodes = tb.nodes.size() / 4;          // TLAS nodes; the BLAS nodes are counted in scene_bytes
@@ -157,7 +296,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
 
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt_in, hipStream_t stream, DeviceScene &out) {
     const size_t I = meshes.size();
-    BuildOptions opt = opt_in; opt.instancing = 0; opt.wide = 0;        // BLASes are traversed through the rope layout (traverse_instanced.h)
+    BuildOptions opt = opt_in; opt.instancing = 0;                      // a BLAS is a flat scene of one mesh: rope layout (queries, A/B path) + 8-wide layout (render kernels)
     // distinct geometries, in order of first use
     std::vector<int> blas_of(I, -1); std::vector<size_t> blas_src;
     std::map<size_t, int> seen;
@@ -176,8 +315,10 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     static const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     // ---- BLASes: each built into a scratch scene, surviving nodes + packets copied into the shared arrays
     std::vector<DeviceScene> blas(B);
-    std::vector<uint32_t> node_base(B), packet_base(B), ts_base(B), vbase(B), ntri(B);
+    std::vector<uint32_t> node_base(B), packet_base(B), ts_base(B), vbase(B), ntri(B), wnode_base(B);
     size_t nodes_total = 0, packets_total = 0, ts_total = 0;
+    const size_t tlas_wcap = std::max<size_t>(I, 1);                      // an 8-wide TLAS over I single-instance leaves has at most max(1, I - 1) nodes
+    size_t wnodes_total = tlas_wcap; bool all_wide = B > 0; int blas_wdepth = 0;
     float build_ms = 0; double sah = 0; uint64_t leaves = 0;
     out.blas_lo.assign(3 * B, 0.0f); out.blas_hi.assign(3 * B, 0.0f);
     for (size_t b = 0; b < B; b++) {
@@ -186,7 +327,9 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
         int rc = build_flat(one, opt, stream, blas[b]); if (rc) return rc;
         node_base[b] = (uint32_t)nodes_total; packet_base[b] = (uint32_t)packets_total; ts_base[b] = (uint32_t)ts_total; vbase[b] = (uint32_t)V_total;
         ntri[b] = (uint32_t)blas[b].stats.triangles;
-        nodes_total += blas[b].stats.bvh_nodes; packets_total += blas[b].stats.triangles; ts_total += blas[b].stats.triangles; V_total += g.positions.size() / 3;
+        wnode_base[b] = (uint32_t)wnodes_total; wnodes_total += blas[b].num_wnodes;
+        if (blas[b].stats.triangles > 0) { all_wide = all_wide && blas[b].num_wnodes > 0; blas_wdepth = std::max(blas_wdepth, blas[b].wide_depth); }
+        nodes_total += blas[b].rope_nodes; packets_total += blas[b].stats.triangles; ts_total += blas[b].stats.triangles; V_total += g.positions.size() / 3;
         build_ms += blas[b].stats.build_ms; sah += blas[b].stats.sah_cost; leaves += blas[b].stats.bvh_leaves;
         for (int k = 0; k < 3; k++) { out.blas_lo[3 * b + k] = blas[b].root_lo[k]; out.blas_hi[3 * b + k] = blas[b].root_hi[k]; }
     }
@@ -196,11 +339,27 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(ts_total, 1)));
     MRT_HIP(out.normals.alloc(std::max<size_t>(V_total, 1)));
     for (size_t b = 0; b < B; b++) {
-        const size_t nn = blas[b].stats.bvh_nodes, nt = blas[b].stats.triangles, nv = meshes[blas_src[b]].positions.size() / 3;
+        const size_t nn = blas[b].rope_nodes, nt = blas[b].stats.triangles, nv = meshes[blas_src[b]].positions.size() / 3;
         if (nn) MRT_HIP(hipMemcpyAsync(out.bnodes.p + 4 * (size_t)node_base[b], blas[b].nodes.p, nn * 64, hipMemcpyDeviceToDevice, stream));
         if (nt) MRT_HIP(hipMemcpyAsync(out.bnodes.p + out.bpackets_offset + 3 * (size_t)packet_base[b], blas[b].nodes.p + blas[b].packets_offset, nt * 48, hipMemcpyDeviceToDevice, stream));
         if (nt) MRT_HIP(hipMemcpyAsync(out.tri_shade.p + ts_base[b], blas[b].tri_shade.p, nt * 16, hipMemcpyDeviceToDevice, stream));
         if (nv) MRT_HIP(hipMemcpyAsync(out.normals.p + vbase[b], blas[b].normals.p, nv * 16, hipMemcpyDeviceToDevice, stream));
+    }
+    // 8-wide layout: [TLAS slots | BLAS 0 | BLAS 1 ...] with absolute indices; its packets are in the wide builder's own order (wpackets)
+    all_wide = all_wide && wnodes_total < (1u << 24) && WNODE_STRIDE == 5;
+    out.wnodes.release(); out.wpackets.release(); out.tlas_wcap = 0; out.blas_wdepth = 0;
+    if (all_wide) {
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * wnodes_total)); MRT_HIP(out.wpackets.alloc(std::max<size_t>(3 * packets_total, 3)));
+        MRT_HIP(hipMemsetAsync(out.wnodes.p, 0, out.wnodes.bytes(), stream));
+        for (size_t b = 0; b < B; b++) {
+            const size_t wn = blas[b].num_wnodes, nt = blas[b].stats.triangles;
+            if (!wn) continue;
+            MRT_HIP(hipMemcpyAsync(out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], blas[b].wnodes.p, wn * WNODE_STRIDE * 16, hipMemcpyDeviceToDevice, stream));
+            MRT_HIP(hipMemcpyAsync(out.wpackets.p + 3 * (size_t)packet_base[b], blas[b].wpackets.p, nt * 48, hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(k_relocate_wide, dim3((uint32_t)((wn + 255) / 256)), dim3(256), 0, stream, out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], (uint32_t)wn, wnode_base[b], packet_base[b]);
+        }
+        MRT_HIP(hipGetLastError());
+        out.tlas_wcap = (uint32_t)tlas_wcap; out.blas_wdepth = blas_wdepth;
     }
     MRT_HIP(hipStreamSynchronize(stream));
     blas.clear();
@@ -214,7 +373,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
         const HostMesh &g = meshes[meshes[i].source >= 0 ? (size_t)meshes[i].source : i];
         InstanceDev &d = out.h_inst[i];
         const int b = blas_of[i];
-        d.node_base = node_base[b]; d.packet_base = packet_base[b]; d.ts_base = ts_base[b]; d.vbase = vbase[b]; d.ntri = ntri[b]; d.blas = (uint32_t)b; d.gid_base = gid;
+        d.node_base = node_base[b]; d.packet_base = packet_base[b]; d.ts_base = ts_base[b]; d.vbase = vbase[b]; d.ntri = ntri[b]; d.blas = (uint32_t)b; d.gid_base = gid; d.wroot = wnode_base[b];
         uint32_t tb = gid;
         for (size_t s = 0; s < g.sub_indices.size(); s++) {
             h_base[i * max_sub + s] = make_float4(g.sub_materials[s].baseColor.x, g.sub_materials[s].baseColor.y, g.sub_materials[s].baseColor.z, 0.0f);
@@ -230,11 +389,11 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     MRT_HIP(out.materials.alloc(h_mat.size()));
     MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat.data(), h_mat.size() * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipStreamSynchronize(stream));          // the host tables die at scope exit
-    out.wnodes.release(); out.wpackets.release(); out.num_wnodes = 0; out.wide_depth = 0;
+    out.num_wnodes = 0; out.wide_depth = 0;
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
-    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
+    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
     return update_tlas(meshes, stream, out);
 }
 

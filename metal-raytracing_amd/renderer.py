@@ -92,6 +92,13 @@ class DeviceScene:
         check(lib.mrt_scene_intersect_any(self.handle, ptr(rays), rays.shape[0], ptr(out)))
         return out
 
+    def intersect_stream(self, rays, any_hit=False):
+        """The render kernels' traversal (8-wide stream, both levels of an instanced scene) on caller rays; min_distance must be 0."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], dtype=INTERSECTION_DTYPE)
+        check(lib.mrt_debug_intersect_stream(self.handle, ptr(rays), rays.shape[0], 1 if any_hit else 0, ptr(out)))
+        return out
+
     def traversal_stats(self, rays, any_hit=False, alu_dup=0, mem_dup=0):
         """Diagnostics: (n, 8) uint32 {node visits, leaf visits, triangle tests, hit gid, t0, t1, 0, 0} per ray."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -74,17 +74,81 @@ def test_two_level_gpu_matches_two_level_oracle_bit_for_bit(mrt, orc, gpu_ctx):
     g, o = r.device_scene.intersect_closest(rays), two.intersect_closest(rays)
     for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
         assert np.array_equal(g[f], o[f]), f
+    # the render kernels' own walk (8-wide TLAS + 8-wide BLASes, one stream loop) answers the same queries with the same bits
+    assert r.device_scene.stats.bvh_nodes > 0
+    gs = r.device_scene.intersect_stream(rays)
+    for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
+        assert np.array_equal(gs[f], o[f]), f
     rays[:, 7] = 3.0
     assert np.array_equal(r.device_scene.intersect_any(rays), two.intersect_any(rays))
+    assert np.array_equal(r.device_scene.intersect_stream(rays, any_hit=True)["type"], two.intersect_any(rays))
     r.draw(3, wait=True)
     ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(3)
     assert_parity(r.accumulation(), ref.accumulation())
     assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    # the rope kernels (wide_bounce = 0: traverse_instanced.h) render the same image
+    rope = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1}); rope.set_option("wide_bounce", 0)
+    rope.draw(3, wait=True)
+    assert np.array_equal(rope.accumulation(), r.accumulation())
+    rope.close()
     # against the flattened scene on the GPU: the formal tolerance
     f = mrt.Renderer((w, h), sc, ctx=gpu_ctx); f.draw(3, wait=True)
     d = np.abs(f.accumulation()[..., :3].astype(np.float64) - r.accumulation()[..., :3])
     assert (d.max(-1) <= TOL_ABS).mean() >= 0.995
     f.close(); r.close()
+
+
+def _swarm(mrt, size, n, seed):
+    rng = np.random.default_rng(seed)
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            self.models = [mrt.Model(name="plane", position=[0, 0, 0], scale=10)]
+            for i in range(n):
+                name = "sphere" if i % 3 else "teapot"
+                sc = float(rng.uniform(0.08, 0.3)) * (1.0 if name == "sphere" else 0.012)
+                self.models.append(mrt.Model(name=name, position=[float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.1, 2.0)), float(rng.uniform(-2.0, 2.0))],
+                                             rotation=[float(x) for x in rng.uniform(-3, 3, 3)], scale=sc))
+    return S(size)
+
+
+@pytest.mark.gpu
+def test_many_instances_deep_tlas(mrt, orc, gpu_ctx):
+    """150 instances of two meshes: a TLAS of several 8-wide levels, overlapping instance boxes, rays that enter and leave many BLASes —
+    the stream traversal (parked TLAS groups, world rays in LDS) against the two-level oracle bit for bit; then every transform changes
+    and only the TLAS is rebuilt."""
+    w, h = 128, 80
+    sc = _swarm(mrt, (w, h), 150, 21)
+    shared = mrt.flatten_scene(sc, share=True)
+    two = orc.OracleScene(shared, sc.lights, instancing=True)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+    assert r.device_scene.stats.instances == 151
+    rays = _rays(np.random.default_rng(8), 30000)
+    o = two.intersect_closest(rays)
+    assert (o["type"] == 1).mean() > 0.5 and len(np.unique(o["instance_id"])) > 60
+    for g in (r.device_scene.intersect_stream(rays), r.device_scene.intersect_closest(rays)):
+        for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
+            assert np.array_equal(g[f], o[f]), f
+    rays[:, 7] = 2.5
+    assert np.array_equal(r.device_scene.intersect_stream(rays, any_hit=True)["type"], two.intersect_any(rays))
+    r.draw(2, wait=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(2)
+    assert_parity(r.accumulation(), ref.accumulation())
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    # move everything
+    rng = np.random.default_rng(22)
+    blas_ms = r.device_scene.stats.build_ms
+    for i in range(1, 151):
+        xf = mrt.make_transform([float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.1, 2.0)), float(rng.uniform(-2.0, 2.0))], [float(x) for x in rng.uniform(-3, 3, 3)],
+                                float(rng.uniform(0.08, 0.3)) * (1.0 if i % 3 != 1 else 0.012))
+        r.device_scene.set_instance_transform(i, xf); two.set_transform(i, xf.reshape(16))
+    r.device_scene.commit()
+    assert r.device_scene.stats.build_ms == blas_ms
+    rays[:, 7] = np.inf
+    o = two.intersect_closest(rays); g = r.device_scene.intersect_stream(rays)
+    for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
+        assert np.array_equal(g[f], o[f]), f
+    r.close()
 
 
 @pytest.mark.gpu
