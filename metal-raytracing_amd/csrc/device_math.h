@@ -30,14 +30,30 @@ MRT_DEV f3 fcross(f3 a, f3 b) {
     return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
 }
 
-// ---- Halton (Raytracing.metal:41-56).  Bases come from the prime table (:27-33), held in
-// constant memory together with fp32 reciprocals used only to form the exact integer quotient.
-static __constant__ short c_primes[100] = {
-    2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,  59,  61,  67,  71,
-    73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173,
-    179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281,
-    283, 293, 307, 311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409,
-    419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541};
+// ---- Halton (Raytracing.metal:41-56).  Bases come from the prime table (:27-33), held in constant memory.
+// Per base: the magic multipliers of the exact digit extraction below and the fp32 reciprocal, evaluated at compile time (the kernels used to
+// derive them per call: three emulated integer divisions and a correctly rounded float division per Halton value, ~10 % of k_shade).
+struct HaltonBase { uint32_t b, M, M2, M1; float invB; };
+struct HaltonTable { HaltonBase e[100]; };
+constexpr HaltonTable make_halton_table() {
+    constexpr int primes[100] = {
+        2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,  59,  61,  67,  71,
+        73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173,
+        179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281,
+        283, 293, 307, 311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397, 401, 409,
+        419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541};
+    HaltonTable t{};
+    for (int k = 0; k < 100; k++) {
+        const uint32_t b = (uint32_t)primes[k];
+        t.e[k].b = b;
+        t.e[k].M = 0xFFFFFFFFu / b + 1u;                       // mulhi(u, M) = u / b for u < 2^22
+        t.e[k].M2 = 0xFFFFFFFFu / (b * b) + 1u;                // mulhi(u, M2) = u / b^2 for u < 2^22 (used for b <= 23)
+        t.e[k].M1 = (1u << 20) / b + 1u;                       // (r2 * M1) >> 20 = r2 / b for r2 < b^2 <= 529
+        t.e[k].invB = 1.0f / (float)primes[k];                 // IEEE division, as the kernels' correctly rounded '/'
+    }
+    return t;
+}
+static __constant__ HaltonTable c_halton = make_halton_table();
 
 // Same float recurrence as the reference: f *= 1/b; r += f * (i % b); i /= b.  gfx950 has no integer divide, and
 // this function is ~20 % of the VALU work of the primary-ray kernel and most of k_shade, so the integer part is
@@ -51,8 +67,9 @@ static __constant__ short c_primes[100] = {
 MRT_DEV float halton_dev(int i, int d) {
     if (i <= 0) return 0.0f;       // the reference's `while (i > 0)` never runs (Raytracing.metal:46): seed offset + frame index wrapped past 2^31
     if (d == 0 && i < (1 << 24)) return (float)__brev((uint32_t)i) * 2.3283064365386963e-10f;   // exact: <= 24 significant bits
-    const int b = c_primes[d];
-    const float invB = 1.0f / (float)b;
+    const HaltonBase hb = c_halton.e[d];
+    const int b = (int)hb.b;
+    const float invB = hb.invB;
     float f = 1.0f, r = 0.0f;
     if (i >= (1 << 22)) {
         while (i > 0) { f = f * invB; r = r + f * (float)(i % b); i = i / b; }
@@ -65,8 +82,7 @@ MRT_DEV float halton_dev(int i, int d) {
         // r2 * (M1*b - 2^20) < 529 * 23 < 2^20.  An odd digit count ends with d1 = 0: r + f*0 == r.
         // (32-bit integer multiplies run at quarter rate on gfx950; per digit this loop costs ~36 cycles of VALU issue instead of ~60.)
         const uint32_t b2 = (uint32_t)(b * b);
-        const uint32_t M2 = 0xFFFFFFFFu / b2 + 1u;
-        const uint32_t M1 = (1u << 20) / (uint32_t)b + 1u;
+        const uint32_t M2 = hb.M2, M1 = hb.M1;
         while (u > 0) {
             const uint32_t q = __umulhi(u, M2);
             const uint32_t r2 = u - __umul24(q, b2);
@@ -78,7 +94,7 @@ MRT_DEV float halton_dev(int i, int d) {
         }
         return r;
     }
-    const uint32_t M = 0xFFFFFFFFu / (uint32_t)b + 1u;     // one emulated divide per call, outside the digit loop
+    const uint32_t M = hb.M;
     while (u > 0) {
         const uint32_t q = __umulhi(u, M);
         const uint32_t rem = u - __umul24(q, (uint32_t)b);  // q < 2^22, b < 2^10: the 24-bit multiply is exact (and full rate)

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                # torch first: its bundled HIP runtime is then the one the whole process shares (a test that imports torch only after
+    import torch    # libmrt_hip.so has loaded /opt/rocm's copy finds "No HIP GPUs"); the full suite always had this order through collection
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
