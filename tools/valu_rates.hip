@@ -87,6 +87,25 @@ KERNEL(k_subrev, "v_subrev_u32 %0, %0, %1")
 KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
 KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
+KERNEL(k_pk_fma_f16, "v_pk_fma_f16 %0, %0, %1, %2")
+KERNEL(k_pk_add_f16, "v_pk_add_f16 %0, %0, %1")
+KERNEL(k_pk_mul_f16, "v_pk_mul_f16 %0, %0, %1")
+KERNEL(k_pk_max_f16, "v_pk_max_f16 %0, %0, %1")
+KERNEL(k_pk_min_f16, "v_pk_min_f16 %0, %0, %1")
+KERNEL(k_fma_f16, "v_fma_f16 %0, %0, %1, %2")
+KERNEL(k_max_f16, "v_max_f16 %0, %0, %1")
+KERNEL(k_cvt_f16_f32, "v_cvt_f16_f32 %0, %0")
+KERNEL(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %0, %1")
+KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1")
+KERNEL(k_pk_max_i16, "v_pk_max_i16 %0, %0, %1")
+KERNEL(k_pk_min_u16, "v_pk_min_u16 %0, %0, %1")
+KERNEL(k_pk_lshl_b16, "v_pk_lshlrev_b16 %0, 1, %0")
+KERNEL(k_pk_mad_u16, "v_pk_mad_u16 %0, %0, %1, %2")
+KERNEL(k_dot2_f16, "v_dot2_f32_f16 %0, %1, %2, %0")
+KERNEL(k_sad_u8, "v_sad_u8 %0, %0, %1, %2")
+KERNEL(k_cvt_pk_u8, "v_cvt_pk_u8_f32 %0, %0, %1, %2")
+KERNEL(k_min3_u32, "v_min3_u32 %0, %0, %1, %2")
+KERNEL(k_max_u32, "v_max_u32 %0, %0, %1")
 KERNEL(k_sdwa_cvt, "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1")
 
 #define KERNEL64(NAME, ASM, ...)                                                                                        \
@@ -128,6 +147,7 @@ int main() {
         E(k_cmp), E(k_cmp_sgpr), E(k_and), E(k_xor), E(k_or3), E(k_bitop3), E(k_lshl), E(k_lshl_or), E(k_bfe), E(k_bfe_i), E(k_bfm), E(k_bfi), E(k_perm), E(k_ffbl), E(k_bcnt),
         E(k_mov), E(k_add_u32), E(k_mul_u24), E(k_mad_u24), E(k_mul_lo), E(k_mul_hi), E(k_rcp), E(k_rsq), E(k_sqrt), E(k_ldexp), E(k_div_scale), E(k_div_fmas),
         E(k_div_fixup), E(k_bpermute), E(k_readlane), E(k_fma_mix_lo), E(k_fma_mix_hi), E(k_cndmask_s), E(k_addc), E(k_or), E(k_and_or), E(k_lshr), E(k_min), E(k_mul_legacy),
+        E(k_pk_fma_f16), E(k_pk_add_f16), E(k_pk_mul_f16), E(k_pk_max_f16), E(k_pk_min_f16), E(k_fma_f16), E(k_max_f16), E(k_cvt_f16_f32), E(k_cvt_pkrtz), E(k_pk_add_u16), E(k_pk_max_i16), E(k_pk_min_u16), E(k_pk_lshl_b16), E(k_pk_mad_u16), E(k_dot2_f16), E(k_sad_u8), E(k_cvt_pk_u8), E(k_min3_u32), E(k_max_u32),
         E(k_or_sdwa), E(k_add_f32_sdwa), E(k_mul_f32_sdwa), E(k_cmp_class), E(k_subrev), E(k_lshl_add), E(k_add3), E(k_xad),
         E(k_mad_u64_u32), E(k_lshl_add_u64), E(k_pk_fma), E(k_pk_mul), E(k_pk_add), E(k_cvt_pk_fp8), E(k_mov_b64)};
     const unsigned grid = (unsigned)simds * 8;
