@@ -919,7 +919,7 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
-        MRT_HIP(L.bounce_counts.alloc(64));       // [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches
+        MRT_HIP(L.bounce_counts.alloc(65));       // [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches; [64]: the megakernel's pixel counter
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -1076,7 +1076,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_megakernel, 64, stack_bytes));
                 mega_slots = std::max(1, per_cu) * prop.multiProcessorCount; mega_slots_for_stack = stack_bytes;
             }
-            uint32_t *work = reinterpret_cast<uint32_t *>(bc + 32);
+            uint32_t *work = reinterpret_cast<uint32_t *>(bc + 64);      // its own word: the pipeline's per-bounce work counters must stay zero between passes
             for (int sub = 0; sub < B; sub++) {
                 fp.frameIndex = frame_index + (uint32_t)sub; fp.sampleIndex = frame_index + (uint32_t)sub + sample_offset; fp.batch = 1;
                 if (last_acc) { MRT_HIP(hipStreamWaitEvent(st, last_acc, 0)); last_acc = nullptr; }
