@@ -295,6 +295,11 @@ int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int
     MRT_CATCH
 }
 
+#ifdef MRT_WAVE_TIMES
+extern "C++" { namespace mrt { int read_wave_times(unsigned long long *out); } }
+extern "C" int mrt_debug_wave_times(unsigned long long *out16384) { return mrt::read_wave_times(out16384); }
+#endif
+
 // ---------------------------------------------------------------- host geometry helpers
 int mrt_obj_load(const char *obj_path, MRTMeshData *out) {
     MRT_TRY

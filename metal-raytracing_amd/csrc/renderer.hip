@@ -258,6 +258,9 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
         });
 }
 
+#ifdef MRT_WAVE_TIMES      // diagnostics build (tools/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
+__device__ unsigned long long g_wave_times[2 * 8192];
+#endif
 // Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
 // `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
 template <bool TWO_LEVEL>
@@ -267,6 +270,11 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+#ifdef MRT_WAVE_TIMES
+    const uint32_t wt_tag = chunk >> 24; chunk &= 0xFFFFFFu;
+    const unsigned long long wt0 = wall_clock64();
+    struct WT { unsigned long long t0; uint32_t tag; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) { g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64(); } } } wt{wt0, wt_tag};
+#endif
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
     traverse_wide_stream<TWO_LEVEL>(s, SharedCounter{work, n, chunk}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
@@ -910,6 +918,10 @@ static inline void launch_timed(EvPair *ev, void (*kernel)(KArgs...), dim3 grid,
 
 }  // namespace
 
+#ifdef MRT_WAVE_TIMES
+int read_wave_times(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(g_wave_times)) == hipSuccess ? MRT_OK : MRT_ERR_HIP; }
+#endif
+
 // ====================================================================== Renderer (host)
 int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed_, int max_bounces_) {
     stream = st; scene = sc; seed = seed_; max_bounces = max_bounces_;
@@ -1141,10 +1153,15 @@ int Renderer::render(int n_frames) {                                   // Render
                     // passes move in lock step, loses 3 % and keeps the full grid)
                     const size_t grid_slots = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? (size_t)std::max(1, wave_slots / 2) : (size_t)wave_slots;
                     const uint32_t waves = (uint32_t)std::min<size_t>(cdiv(slots, chunk), grid_slots);
+#ifdef MRT_WAVE_TIMES
+                    const uint32_t chunk_arg = chunk | ((uint32_t)b << 24);
+#else
+                    const uint32_t chunk_arg = chunk;
+#endif
                     if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg);
                 }
                 else if (on_wide && (wide_stream || two_level)) {
                     if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, dim3(cdiv(2 * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, 0, rpw_m);

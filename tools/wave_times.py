@@ -1,0 +1,26 @@
+"""Occupancy over time of ONE persistent traversal launch (diagnostics build -DMRT_WAVE_TIMES, MRT_LIB_PATH=variants/libmrt_hip_wavetimes.so):
+start and end tick (100 MHz) of every wave of the first bounce + shadow launch of a serialised pass."""
+import ctypes as C, os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import metal_raytracing_amd as mrt
+from metal_raytracing_amd._ffi import lib
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+w, h = 1920, 1080
+r = mrt.Renderer((w, h), mrt.DragonScene((w, h)), seed=1)
+r.set_option("frames_in_flight", 1); r.set_option("frame_batch", batch)
+r.draw(2 * batch, wait=True)
+r.draw(batch, wait=True)
+buf = np.zeros(16384, np.uint64)
+lib.mrt_debug_wave_times.restype = C.c_int
+assert lib.mrt_debug_wave_times(buf.ctypes.data_as(C.c_void_p)) == 0
+t = buf.reshape(-1, 2).astype(np.int64)
+t = t[t[:, 1] > 0]
+t0 = t[:, 0].min(); s = (t[:, 0] - t0) / 100.0; e = (t[:, 1] - t0) / 100.0      # microseconds
+T = e.max()
+print(f"batch {batch}: {len(t)} waves, launch {T:.1f} us; starts: 50% by {np.percentile(s, 50):.1f}, 99% by {np.percentile(s, 99):.1f} us; ends: 1% by {np.percentile(e, 1):.1f}, 50% by {np.percentile(e, 50):.1f}, 90% by {np.percentile(e, 90):.1f}, 99% by {np.percentile(e, 99):.1f} us")
+grid = np.linspace(0, T, 21)
+occ = [(int(((s <= x) & (e > x)).sum())) for x in grid]
+print("resident waves at 5% steps of the launch:", occ)
+print(f"mean residency {np.mean(e - s) / T:.3f} of the launch time (1.0 = every wave alive from start to end)")
