@@ -218,6 +218,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     uint32_t batch_n = 0, batch_used = 0;             // wave-uniform; used == n -> nothing prefetched
     uint32_t cur = 0, end = 0;                        // unfetched part of the current chunk
     bool more = true;                                 // the chunk source may have more
+    bool draining = false;                            // nothing left to hand out: the wave runs until its last rays are done
     // live ray
     bool live = false, unreported = false;            // unreported: the lane's ray is finished, its result not yet emitted
     uint32_t tagw = 0;                                // tag | any-hit flag << 31
@@ -258,7 +259,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 cur += batch_n;
             }
             const uint32_t avail = batch_n - batch_used;
-            if (avail == 0) { if (m_idle == ~0ull) break; }
+            if (avail == 0) { if (m_idle == ~0ull) break; draining = true; }
             else {
                 const uint32_t rank = (uint32_t)__popcll(m_idle & lt);
                 const bool take = !live && rank < avail;
@@ -303,6 +304,33 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
         const bool in_blas = TWO_LEVEL && (g_mask >> 24) != 0u;
+        // Drain phase (rocprofv3 / tools/wave_times.py: the last 30 % of a launch run on < 2 % of the waves, each walking one or two grazing rays
+        // that test 100-200 triangles one per iteration).  The finished lanes help: the pending triangles of ONE such ray are tested by idle
+        // lanes in this same iteration — lane k (or k + 32) takes triangle t_base + k with the owner's ray — and folded back into the owner.
+        bool helping = false; int owner = -1; uint32_t help_pk = 0;
+        if (draining) {
+#ifndef MRT_COOP_MODE
+#define MRT_COOP_MODE 3
+#endif
+            const bool coop_kind = (tagw >> 31) != 0 ? (MRT_COOP_MODE & 1) != 0 : (MRT_COOP_MODE & 2) != 0;
+            const unsigned long long m_many = __ballot(live && coop_kind && (t_mask & (t_mask - 1u)) != 0u && (!TWO_LEVEL || in_blas));
+            const unsigned long long m_free = __ballot(!live && !unreported);
+            if (m_many != 0ull && m_free != 0ull) {
+                owner = __ffsll((long long)m_many) - 1;
+                const uint32_t o_tb = (uint32_t)__builtin_amdgcn_readlane((int)t_base, owner), o_tm = (uint32_t)__builtin_amdgcn_readlane((int)t_mask, owner);
+                const uint32_t f_lo = (uint32_t)m_free, f_hi = (uint32_t)(m_free >> 32), bit = lane & 31u;
+                helping = !live && !unreported && ((o_tm >> bit) & 1u) != 0u && (lane < 32u || ((f_lo >> bit) & 1u) == 0u);
+                if (helping) {
+                    o = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.y), owner)),
+                            __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.z), owner)));
+                    d = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.y), owner)),
+                            __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.z), owner)));
+                    best_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best_t), owner));
+                    help_pk = o_tb + bit;
+                }
+                if ((int)lane == owner) t_mask &= ~((f_lo | f_hi) & o_tm);      // these are being tested now
+            }
+        }
         const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter
         const bool has_tri = live && t_mask != 0 && !has_inst;
         const uint32_t t_rest = t_mask & (t_mask - 1u);         // triangles left after this iteration's first one
@@ -358,9 +386,9 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         asm volatile("" : "=v"(n0.x), "=v"(n0.y), "=v"(n0.z), "=v"(n0.w), "=v"(n1.x), "=v"(n1.y), "=v"(n1.z), "=v"(n1.w), "=v"(n2.x), "=v"(n2.y), "=v"(n2.z), "=v"(n2.w));
         asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
         r1.w = 0.0f; r2.w = 0.0f;
-        if (has_tri) {
-            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u;
-            t_mask = t_rest;
+        if (has_tri || helping) {
+            if (has_tri) { tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u; t_mask = t_rest; }
+            else tri_pk = help_pk;
             const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
         }
@@ -390,6 +418,30 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         };
         if (has_tri) consider(r0, r1, r2, tri_pk);
         if (has_tri2 && live) consider(n0, n1, n2, tri_pk2);
+        if (owner >= 0) {                                        // wave-uniform
+            float h_t = 0.0f; bool h_hit = false;
+            if (helping) { float U_, V_, ad_; h_hit = tri_test(r0, r1, r2, o, d, 0.0f, best_t, h_t, U_, V_, ad_); }
+            // the closest of the helpers' hits (ties: lowest id — all of them are triangles of the owner's current BLAS, so local ids compare)
+            float bt = __builtin_inff(); uint32_t bpk = 0xFFFFFFFFu, bgid = 0xFFFFFFFFu;
+            for (unsigned long long m = __ballot(h_hit); m != 0ull; m &= m - 1ull) {
+                const int l = __ffsll((long long)m) - 1;
+                const float t_ = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(h_t), l));
+                const uint32_t g_ = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r0.w), l), p_ = (uint32_t)__builtin_amdgcn_readlane((int)tri_pk, l);
+                if (t_ < bt || (t_ == bt && g_ < bgid)) { bt = t_; bgid = g_; bpk = p_; }
+            }
+            // (the owner may have run out of nodes in this very iteration — it then waits for its report with these hits folded in)
+            if ((int)lane == owner && bpk != 0xFFFFFFFFu) {
+                if ((tagw >> 31) != 0) { best_pk = bpk; live = false; unreported = true; }
+                else {
+                    bool better = bt < best_t || best_pk == 0xFFFFFFFFu;
+                    if (!better && bt == best_t) {
+                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + bgid < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                        else better = bgid < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                    }
+                    if (better) { best_t = bt; best_pk = bpk; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
+                }
+            }
+        }
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
