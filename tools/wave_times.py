@@ -10,6 +10,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 w, h = 1920, 1080
 r = mrt.Renderer((w, h), mrt.DragonScene((w, h)), seed=1)
 r.set_option("frames_in_flight", 1); r.set_option("frame_batch", batch)
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); r.set_option(k, float(v))
 r.draw(2 * batch, wait=True)
 r.draw(batch, wait=True)
 buf = np.zeros(16384, np.uint64)
