@@ -152,6 +152,22 @@ def test_many_instances_deep_tlas(mrt, orc, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_two_level_with_materials_and_four_bounces(mrt, orc, gpu_ctx):
+    """The two extensions together: instanced scene (8-wide TLAS + BLASes) with the materials path of k_shade (sphere.mtl carries Ks / Ns, so the
+    specular lobe and the lobe-sorted queues are exercised), 4 bounces, against the two-level oracle with its materials switch."""
+    w, h = 128, 80
+    sc = _scene(mrt, (w, h))
+    two = orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, max_bounces=4, scene_options={"instancing": 1})
+    r.set_option("materials", 1)
+    r.draw(3, wait=True)
+    ref = orc.OracleRenderer(two, w, h, max_bounces=4, camera=sc.camera); ref.set_materials(True); ref.render(3)
+    assert_parity(r.accumulation(), ref.accumulation())
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    r.close()
+
+
+@pytest.mark.gpu
 def test_transform_change_rebuilds_only_the_tlas(mrt, orc, gpu_ctx):
     """Animated transforms (SURVEY §8 f-3 'refit'): set_instance_transform + commit on a two-level scene leaves the BLASes alone."""
     w, h = 128, 80
