@@ -33,6 +33,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_FLAT_HITS
 #define MRT_WIDE_FLAT_HITS 1   // hit children recorded without an inner node/leaf branch: +0.8 % / +1.8 %
 #endif
+#ifndef MRT_COOP_MODE
+#define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
+#endif
 // ((1 << width) - 1) << offset in one instruction (width, offset taken mod 32)
 MRT_DEV uint32_t bfm_b32(uint32_t width, uint32_t offset) { uint32_t r; asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset)); return r; }
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
@@ -167,8 +170,8 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 //   emit(tag, is_any, hit, h)     result of a finished ray; called by all idle lanes together at refill time, so that
 //                                 its divisions and stores do not run at one or two lanes in the iteration a ray ends in
 //
-// Register budget: 80 VGPRs = 6 waves per SIMD (MRT_WIDE_STREAM_WAVES); the LDS stack (5 B per lane and level)
-// leaves room for more, but the one-round-trip iteration below holds a node (20) and a packet (10) at once.
+// Register budget: 72 VGPRs = 7 waves per SIMD (MRT_WIDE_STREAM_WAVES; the two-level instantiation: 77-80 VGPRs, 6 waves); the one-round-trip
+// iteration below holds a node (20 registers) and a packet (10) at once.
 #ifndef MRT_WIDE_REFILL_AT
 #define MRT_WIDE_REFILL_AT 16
 #endif
@@ -309,9 +312,6 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         // lanes in this same iteration — lane k (or k + 32) takes triangle t_base + k with the owner's ray — and folded back into the owner.
         bool helping = false; int owner = -1; uint32_t help_pk = 0;
         if (draining) {
-#ifndef MRT_COOP_MODE
-#define MRT_COOP_MODE 3
-#endif
             const bool coop_kind = (tagw >> 31) != 0 ? (MRT_COOP_MODE & 1) != 0 : (MRT_COOP_MODE & 2) != 0;
             const unsigned long long m_many = __ballot(live && coop_kind && (t_mask & (t_mask - 1u)) != 0u && (!TWO_LEVEL || in_blas));
             const unsigned long long m_free = __ballot(!live && !unreported);
