@@ -285,6 +285,13 @@ def main():
                                      "cycle_weighted_frac_at_fma_load_clock": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
         if world == 1 and not a.no_latency:
             out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
+            # the dominant kernel ALONE: one-frame launches on one stream (the latency leg's own start/stop events), algorithmic bytes of one frame's
+            # bounce + shadow rays spread over its max_bounces launches — the kernel-level figure that profiles/r02_kernel_stats_serial.csv reproduces
+            t_ser = out["latency"]["kernel_ms_serialised"].get("trace")
+            if t_ser and fused:
+                b_ser = (BYTES_PER_CLOSEST_RAY * (closest - primary) + BYTES_PER_SHADOW_RAY * shadow) / steps_total / a.bounces
+                out["roofline"]["serialised_one_frame_launch"] = {"avg_launch_ms": t_ser, "algorithmic_bytes_per_launch": round(b_ser), "achieved": round(b_ser / (t_ser * 1e-3) / 1e9, 2),
+                                                                  "frac": round(b_ser / (t_ser * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s"}
         if world == 1 and a.bounces > 1 and not a.no_strict:
             # the strict "primary + shadow" figure: the same renderer with max_bounces = 1
             r.set_option("max_bounces", 1); r.frameIndex = 0

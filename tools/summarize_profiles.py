@@ -18,7 +18,7 @@ for mode in ("driver", "serial"):
     ks = glob.glob(out + f"/trace_{mode}/**/*kernel_stats.csv", recursive=True)
     if not ks:
         continue
-    rows = list(csv.DictReader(open(ks[0])))
+    rows = list(csv.DictReader(open(max(ks, key=os.path.getmtime))))      # gpurun merges into an existing directory: take the newest run
     with open(os.path.join(P, f"{tag}_kernel_stats_{mode}.csv"), "w") as f:
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
@@ -34,7 +34,11 @@ for mode in ("driver", "serial"):
 def pmc_all():
     """{kernel: {counter: mean per dispatch}} over every pmc_* directory; the runs use 4-frame passes with warm-up = one pass, so every dispatch is full size"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    newest = {}
+    for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):      # one (the newest) file per pass directory
+        d = f[len(out):].split(os.sep)[1]
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]): newest[d] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             k = kname(r["Kernel_Name"])
             if k in KERNELS:
