@@ -332,8 +332,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
         const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter
-        const bool has_tri = live && t_mask != 0 && !has_inst;
-        const uint32_t t_rest = t_mask & (t_mask - 1u);         // triangles left after this iteration's first one
+        bool has_tri = live && t_mask != 0 && !has_inst;
+        uint32_t t_rest = t_mask & (t_mask - 1u);               // triangles left after this iteration's first one
         bool want_node = live && t_rest == 0u && !has_inst;
 #if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
         {
@@ -363,7 +363,9 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             g_base = 0; g_mask = (sp << 24) | (sp << 16);          // no group yet: the root's children become the first one
             t_base = 0; t_mask = 0;
             insts = (insts & 0xFFFF0000u) | id;
-            pending = I.wroot; want_node = true;
+            if (I.ntri <= 8u) {          // a BLAS of a few triangles (a wall, a floor): no node to test, its packets are the pending set, the first one is tested now
+                t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true;
+            } else { pending = I.wroot; want_node = true; }
         }
         else if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
