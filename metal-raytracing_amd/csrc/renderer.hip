@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64, 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
+__global__ void __launch_bounds__(64, TWO_LEVEL ? 5 : 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
