@@ -296,8 +296,9 @@ int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int
 }
 
 #ifdef MRT_WAVE_TIMES
-extern "C++" { namespace mrt { int read_wave_times(unsigned long long *out); } }
+extern "C++" { namespace mrt { int read_wave_times(unsigned long long *out); int read_wave_iters(uint32_t *out); } }
 extern "C" int mrt_debug_wave_times(unsigned long long *out16384) { return mrt::read_wave_times(out16384); }
+extern "C" int mrt_debug_wave_iters(uint32_t *out32768) { return mrt::read_wave_iters(out32768); }
 #endif
 
 // ---------------------------------------------------------------- host geometry helpers

@@ -920,6 +920,7 @@ static inline void launch_timed(EvPair *ev, void (*kernel)(KArgs...), dim3 grid,
 
 #ifdef MRT_WAVE_TIMES
 int read_wave_times(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(g_wave_times)) == hipSuccess ? MRT_OK : MRT_ERR_HIP; }
+int read_wave_iters(uint32_t *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_iters), sizeof(g_wave_iters)) == hipSuccess ? MRT_OK : MRT_ERR_HIP; }
 #endif
 
 // ====================================================================== Renderer (host)

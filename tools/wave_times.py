@@ -18,6 +18,10 @@ buf = np.zeros(16384, np.uint64)
 lib.mrt_debug_wave_times.restype = C.c_int
 assert lib.mrt_debug_wave_times(buf.ctypes.data_as(C.c_void_p)) == 0
 t = buf.reshape(-1, 2).astype(np.int64)
+it = np.zeros(32768, np.uint32)
+lib.mrt_debug_wave_iters.restype = C.c_int
+assert lib.mrt_debug_wave_iters(it.ctypes.data_as(C.c_void_p)) == 0
+it = it.reshape(-1, 4).astype(np.int64)[t[:, 1] > 0]
 t = t[t[:, 1] > 0]
 t0 = t[:, 0].min(); s = (t[:, 0] - t0) / 100.0; e = (t[:, 1] - t0) / 100.0      # microseconds
 T = e.max()
@@ -25,4 +29,9 @@ print(f"batch {batch}: {len(t)} waves, launch {T:.1f} us; starts: 50% by {np.per
 grid = np.linspace(0, T, 21)
 occ = [(int(((s <= x) & (e > x)).sum())) for x in grid]
 print("resident waves at 5% steps of the launch:", occ)
+last = np.argsort(-t[:, 1])[:5]
+for k in last:
+    dur = (t[k, 1] - t[k, 0]) / 100.0
+    print(f"   late wave: alive {dur:.0f} us, {it[k, 0]} iterations ({dur / max(it[k, 0], 1):.2f} us each), {it[k, 1]} of them in the drain phase with {it[k, 2] / max(it[k, 1], 1):.1f} live lanes on average")
+print(f"   all waves: {it[:, 0].mean():.0f} iterations on average, {1e0 * ((t[:, 1] - t[:, 0]) / 100.0).mean() / it[:, 0].mean():.2f} us per iteration")
 print(f"mean residency {np.mean(e - s) / T:.3f} of the launch time (1.0 = every wave alive from start to end)")
