@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
 
 #ifdef MRT_WAVE_TIMES      // diagnostics build (tools/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
 __device__ unsigned long long g_wave_times[2 * 8192];
+__device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: iterations | drain iterations + longest iteration << 12 | live lanes summed over the drain iterations | drain start tick
 #endif
 // Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
 // `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
@@ -273,7 +274,10 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
 #ifdef MRT_WAVE_TIMES
     const uint32_t wt_tag = chunk >> 24; chunk &= 0xFFFFFFu;
     const unsigned long long wt0 = wall_clock64();
-    struct WT { unsigned long long t0; uint32_t tag; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) { g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64(); } } } wt{wt0, wt_tag};
+    StreamStats wst{0, 0, 0, 0, 0, 0};
+    struct WT { unsigned long long t0; uint32_t tag; StreamStats &st; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) {
+        g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64();
+        g_wave_iters[4 * blockIdx.x] = st.iters; g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{wt0, wt_tag, wst};
 #endif
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
     traverse_wide_stream<TWO_LEVEL>(s, SharedCounter{work, n, chunk}, stk_dyn,
@@ -287,7 +291,11 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
             } else {
                 hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
             }
-        });
+        }
+#ifdef MRT_WAVE_TIMES
+        , wt_tag == 0 ? &wst : nullptr
+#endif
+        );
 }
 
 // ------------------------------------------------------------------ one launch per frame: the wave-level megakernel (option megakernel = 1)

@@ -18,9 +18,6 @@
 
 namespace mrt {
 namespace {
-#ifdef MRT_WAVE_TIMES
-__device__ uint32_t g_wave_iters[4 * 8192];      // per wave of the last stream launch: iterations, iterations in the drain phase, sum of live lanes over those
-#endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 // Compile-time switches kept for A/B builds (tools/build_variant.sh); the defaults are the measured best.
@@ -180,7 +177,12 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 #endif
 constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
-struct StreamStats { uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes; };
+struct StreamStats {
+    uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes;
+#ifdef MRT_WAVE_TIMES
+    uint32_t drain_iters = 0, drain_live = 0, maxdt = 0; unsigned long long prev = 0ull, drain_t0 = 0ull;
+#endif
+};
 
 // A wave's supply of rays: consecutive chunks [b, e) of the queue.  `next(b, e)` is called by the whole wave (wave-uniform
 // result) when the current chunk is used up and returns false when there is nothing left.
@@ -225,10 +227,6 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     uint32_t cur = 0, end = 0;                        // unfetched part of the current chunk
     bool more = true;                                 // the chunk source may have more
     bool draining = false;                            // nothing left to hand out: the wave runs until its last rays are done
-#ifdef MRT_WAVE_TIMES
-    uint32_t mrt_wt_iters = 0, mrt_wt_drain_iters = 0, mrt_wt_drain_live = 0;
-    struct WTI { uint32_t &a, &b, &c; __device__ ~WTI() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) { g_wave_iters[4 * blockIdx.x] = a; g_wave_iters[4 * blockIdx.x + 1] = b; g_wave_iters[4 * blockIdx.x + 2] = c; } } } wti{mrt_wt_iters, mrt_wt_drain_iters, mrt_wt_drain_live};
-#endif
     // live ray
     bool live = false, unreported = false;            // unreported: the lane's ray is finished, its result not yet emitted
     uint32_t tagw = 0;                                // tag | any-hit flag << 31
@@ -296,7 +294,12 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
 #ifdef MRT_WAVE_TIMES
-        mrt_wt_iters++; if (draining) { mrt_wt_drain_iters++; mrt_wt_drain_live += (uint32_t)__popcll(__ballot(live)); }
+        if (ss) {
+            if (draining) { ss->drain_iters++; ss->drain_live += (uint32_t)__popcll(__ballot(live)); }
+            const unsigned long long now_ = wall_clock64(); const uint32_t dt_ = (uint32_t)(now_ - ss->prev);
+            if (ss->prev != 0ull && dt_ > ss->maxdt) ss->maxdt = dt_;
+            ss->prev = now_; if (draining && ss->drain_t0 == 0ull) ss->drain_t0 = now_;
+        }
 #endif
         if (ss) { ss->iters++; ss->live_sum += (uint32_t)__popcll(__ballot(live)); ss->tri_sum += (uint32_t)__popcll(__ballot(live && t_mask != 0)); ss->node_sum += (uint32_t)__popcll(__ballot(live && t_mask == 0)); }
         // One memory round trip per iteration.  A lane with at most one triangle left to test already knows the next node

@@ -32,6 +32,8 @@ print("resident waves at 5% steps of the launch:", occ)
 last = np.argsort(-t[:, 1])[:5]
 for k in last:
     dur = (t[k, 1] - t[k, 0]) / 100.0
-    print(f"   late wave: alive {dur:.0f} us, {it[k, 0]} iterations ({dur / max(it[k, 0], 1):.2f} us each), {it[k, 1]} of them in the drain phase with {it[k, 2] / max(it[k, 1], 1):.1f} live lanes on average")
+    nd = it[k, 1] & 0xFFF; maxdt = (it[k, 1] >> 12) / 100.0
+    d0 = ((it[k, 3] - (t0 & 0xFFFFFFFF)) & 0xFFFFFFFF) / 100.0 if it[k, 3] else -1
+    print(f"   late wave: alive {dur:.0f} us, {it[k, 0]} iterations ({dur / max(it[k, 0], 1):.2f} us each), longest single iteration {maxdt:.1f} us, drain phase from {d0:.0f} us on: {nd} iterations with {it[k, 2] / max(nd, 1):.1f} live lanes on average")
 print(f"   all waves: {it[:, 0].mean():.0f} iterations on average, {1e0 * ((t[:, 1] - t[:, 0]) / 100.0).mean() / it[:, 0].mean():.2f} us per iteration")
 print(f"mean residency {np.mean(e - s) / T:.3f} of the launch time (1.0 = every wave alive from start to end)")
