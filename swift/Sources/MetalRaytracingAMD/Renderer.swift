@@ -6,16 +6,26 @@ public final class Renderer {
     public private(set) var width: Int, height: Int
     private var ctx: MRTContext?, scene: MRTScene?, renderer: MRTRenderer?
 
-    public init(width: Int, height: Int, scene s: Scene, device: Int32 = 0, seed: UInt32 = 1, maxBounces: Int32 = 3) throws {
+    /// instancing = true: models loaded from the same resource become instances of one mesh (mrt_scene_add_instance) and the scene is committed
+    /// two-level — one BLAS per distinct mesh + a TLAS, the reference's instance acceleration structure (Renderer.swift:193-213).
+    public init(width: Int, height: Int, scene s: Scene, device: Int32 = 0, seed: UInt32 = 1, maxBounces: Int32 = 3, instancing: Bool = false) throws {
         self.width = width; self.height = height
         try check(mrt_context_create(device, &ctx))
         try check(mrt_scene_create(ctx, &scene))
-        for mesh in s.models.flatMap(\.meshes) {
-            var id: Int32 = -1
-            try check(mrt_scene_add_mesh(scene, mesh.positions, 12, mesh.normals, 12, mesh.positions.count / 3, mesh.transform, &id))
-            for sub in mesh.submeshes {
-                var mat = sub.material
-                try check(mrt_mesh_add_submesh(scene, id, sub.indices, sub.indices.count / 3, &mat, nil))
+        if instancing { try check(mrt_scene_set_option(scene, "instancing", 1)) }
+        var loaded: [String: Int32] = [:]                 // resource name -> mesh id of its first use
+        for model in s.models {
+            for mesh in model.meshes {
+                var id: Int32 = -1
+                if instancing, model.meshes.count == 1, let source = loaded[model.name] {
+                    try check(mrt_scene_add_instance(scene, source, mesh.transform, &id)); continue
+                }
+                try check(mrt_scene_add_mesh(scene, mesh.positions, 12, mesh.normals, 12, mesh.positions.count / 3, mesh.transform, &id))
+                for sub in mesh.submeshes {
+                    var mat = sub.material
+                    try check(mrt_mesh_add_submesh(scene, id, sub.indices, sub.indices.count / 3, &mat, nil))
+                }
+                if loaded[model.name] == nil { loaded[model.name] = id }
             }
         }
         try check(mrt_scene_set_lights(scene, s.lights, Int32(s.lights.count)))
@@ -29,6 +39,11 @@ public final class Renderer {
     public var frameIndex: UInt32 { var f: UInt32 = 0; mrt_renderer_frame_index(renderer, &f); return f }
     public func draw(frames: Int32 = 1) throws { try check(mrt_renderer_render(renderer, frames)) }
     public func wait() throws { try check(mrt_renderer_wait(renderer)) }
+    /// animated transforms: a new object->world matrix (column-major 4x4) for one mesh / instance, then commit(); a two-level scene rebuilds only its TLAS
+    public func setInstanceTransform(meshId: Int32, transform: [Float]) throws { try check(mrt_scene_set_instance_transform(scene, meshId, transform)) }
+    public func commit() throws { try check(mrt_scene_commit(scene)) }
+    /// implementation knobs of include/mrt_abi.h: "frames_in_flight", "frame_batch", "materials", "megakernel", ...
+    public func setOption(_ key: String, _ value: Double) throws { try check(mrt_renderer_set_option(renderer, key, value)) }
     public func drawableSizeWillChange(width: Int, height: Int) throws {
         self.width = width; self.height = height
         try check(mrt_renderer_resize(renderer, Int32(width), Int32(height)))
