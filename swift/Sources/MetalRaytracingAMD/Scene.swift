@@ -42,7 +42,9 @@ public struct Mesh {
 public final class Model {
     public static var resourceDirectory = "assets/Resources"
     public var meshes: [Mesh] = []
+    public let name: String                                // the resource it was loaded from (Renderer(instancing:) shares meshes by it)
     public init(name: String, position: SIMD3<Float>, rotation: SIMD3<Float> = [0, 0, 0], scale: Float) throws {
+        self.name = name
         var md: MRTMeshData?
         let rc = mrt_obj_load("\(Model.resourceDirectory)/\(name).obj", &md)
         if rc == MRT_ERR_IO.rawValue && name == "dragon" { try check(mrt_dragon_proxy(&md)) }
