@@ -38,6 +38,8 @@ struct Renderer {
     uint64_t frames_rendered = 0;
 
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
+    DevBuf<uint32_t> hint;               // per pixel: the packet its primary ray hit last (k_trace_primary tests it first); 0xFFFFFFFF = none
+    bool primary_hint = true;
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__rest
 //                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
 //                     the loop; a shadow lane simply stops at its first hit.
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs) {
+__global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t *__restrict__ hint) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, sub = blockIdx.y;      // grid = (local tiles, sub-frames of the batch)
     float4 *__restrict__ hits_s = hits + (size_t)sub * fp.capacity;
     int x, y;
@@ -136,7 +136,23 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
     // instead of repeating two Halton values, two divisions and a normalisation per pixel)
     dirs[(size_t)sub * fp.capacity + slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));
     TravHit h;
-    bool hit = TWO_LEVEL ? traverse_instanced<false>(s, org, dir, 0.0f, __builtin_inff(), h) : traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
+    bool hit;
+    if (!TWO_LEVEL && hint != nullptr) {
+        // the triangle this pixel hit in an earlier frame is tested first: the jittered ray most often hits it again, and the walk then starts with
+        // the right distance bound instead of discovering it.  Any packet is a legal guess (a wrong one is one wasted test); the result is unchanged.
+        const uint32_t pixel = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+        const uint32_t guess = hint[pixel];
+        h.t = __builtin_inff(); h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = 0xFFFFFFFFu;
+        if (guess < s.num_tris) {
+            const float4 *__restrict__ pk = s.packets + 3 * (size_t)guess;
+            const float4 q0 = pk[0];
+            float t, U, V, ad;
+            if (tri_test(q0, pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = __float_as_uint(q0.w); h.pk = guess; }
+        }
+        hit = traverse<false, false, false, true>(s, org, dir, 0.0f, h.t, h);
+        if (h.pk != guess) hint[pixel] = h.pk;
+    }
+    else hit = TWO_LEVEL ? traverse_instanced<false>(s, org, dir, 0.0f, __builtin_inff(), h) : traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
     hits_s[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
 }
 
@@ -965,6 +981,8 @@ int Renderer::resize(int w, int h) {                                   // Render
     const int B = std::max(1, std::min(frame_batch, MAX_FRAME_BATCH));
     alloc_batch = B;
     MRT_HIP(seeds.alloc(npix * B));
+    MRT_HIP(hint.alloc(npix));
+    MRT_HIP(hipMemsetAsync(hint.p, 0xFF, hint.bytes(), stream));
     MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix));
     MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
     MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
@@ -1135,8 +1153,8 @@ int Renderer::render(int n_frames) {                                   // Render
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
             if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
             else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
-            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
-            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p);
+            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, (uint32_t *)nullptr);
+            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, primary_hint ? hint.p : (uint32_t *)nullptr);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;

@@ -7,7 +7,7 @@
 namespace mrt {
 namespace {
 
-struct TravHit { float t, U, V, ad; uint32_t gid; };
+struct TravHit { float t, U, V, ad; uint32_t gid; uint32_t pk = 0xFFFFFFFFu; };      // pk: packet of the hit (rope traversal with SEED only)
 
 MRT_DEV float safe_inv(float d) {
     float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
@@ -56,9 +56,11 @@ struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0,
 // advances (a box test or a triangle test).  Measured on MI355X the wave time is (iterations of its
 // slowest lane) x (round-trip latency); a split inner-node / leaf loop made the slowest wave iterate
 // 4x more often than any of its lanes needed.
-template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
+// SEED: `h` already holds a candidate hit (or t = tmax, gid = none) that the walk has to beat — a correct guess makes every box behind it a miss
+// from the first step on; the result is the same minimum over (t, id) either way.  h.pk then tracks the packet of the winner.
+template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false, bool SEED = false>
 MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, TravCounters *tc = nullptr, bool any_rt = false) {
-    h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
+    if (!SEED) { h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; }
     if (s.num_nodes == 0) return false;
     const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
     // slab planes as one fma each: t = plane * inv - o * inv.  The extra rounding (<= 1 ulp of o*inv, i.e.
@@ -85,7 +87,7 @@ MRT_DEV bool traverse(const SceneView &s, f3 o, f3 d, float tmin, float tmax, Tr
             if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
                 if (ANY || (RUNTIME_ANY && any_rt)) return true;
                 const uint32_t gid = __float_as_uint(r0.w);
-                if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; }   // t <= h.t here
+                if (t < h.t || gid < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = gid; if (SEED) h.pk = tri - 1u; }   // t <= h.t here
             }
         } else {
             // conservative slab test: far side widened by ~4 ulp (Ize 2013), boxes padded at build time
