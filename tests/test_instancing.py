@@ -152,6 +152,38 @@ def test_many_instances_deep_tlas(mrt, orc, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_many_tiny_instances(mrt, orc, gpu_ctx):
+    """600 instances of the two-triangle plane (entered without a root-node test: their packets are the pending set at once) among 40 spheres: a TLAS
+    of four 8-wide levels whose leaves are mostly such tiny BLASes; queries and an image against the two-level oracle, bit for bit."""
+    rng = np.random.default_rng(31)
+    w, h = 96, 64
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            self.models = [mrt.Model(name="plane", position=[0, 0, 0], scale=10)]
+            for i in range(640):
+                name = "sphere" if i % 16 == 0 else "plane"
+                self.models.append(mrt.Model(name=name, position=[float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.05, 2.2)), float(rng.uniform(-2.0, 2.5))],
+                                             rotation=[float(x) for x in rng.uniform(-3, 3, 3)], scale=float(rng.uniform(0.05, 0.25))))
+    sc = S((w, h))
+    two = orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True)
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+    assert r.device_scene.stats.instances == 641
+    rays = _rays(np.random.default_rng(9), 20000)
+    o = two.intersect_closest(rays); g = r.device_scene.intersect_stream(rays)
+    assert (o["type"] == 1).mean() > 0.5 and len(np.unique(o["instance_id"])) > 200
+    for f in ("type", "distance", "instance_id", "geometry_id", "primitive_id", "u", "v"):
+        assert np.array_equal(g[f], o[f]), f
+    rays[:, 7] = 2.0
+    assert np.array_equal(r.device_scene.intersect_stream(rays, any_hit=True)["type"], two.intersect_any(rays))
+    r.draw(2, wait=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(2)
+    assert_parity(r.accumulation(), ref.accumulation())
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == ref.counters()
+    r.close()
+
+
+@pytest.mark.gpu
 def test_two_level_with_materials_and_four_bounces(mrt, orc, gpu_ctx):
     """The two extensions together: instanced scene (8-wide TLAS + BLASes) with the materials path of k_shade (sphere.mtl carries Ks / Ns, so the
     specular lobe and the lobe-sorted queues are exercised), 4 bounces, against the two-level oracle with its materials switch."""
