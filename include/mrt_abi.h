@@ -233,7 +233,12 @@ int mrt_renderer_resize(MRTRenderer r, int32_t width, int32_t height);
 int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
 /* Tuning knobs of this implementation (no counterpart in the reference beyond maxFramesInFlight, Renderer.swift:33):
  * "max_bounces", "frames_in_flight" (HIP streams carrying frame batches concurrently), "frame_batch" (frames carried through
- * the pipeline per pass), "fused", "wide_bounce", "wide_stream", "primary_wide", "shadow_rope", "wide", "sample_offset".      */
+ * the pipeline per pass, <= 32), "persistent" (bounce / shadow traversal as persistent waves pulling chunks: 0 never, 1 always, 2 by launch
+ * size), "persist_chunk", "wave_slots", "primary_hint" (primary rays test the triangle their pixel hit last first), "materials" (the
+ * materials extension: emission, specular lobe, refraction; max_bounces <= 16), "megakernel" (one launch per frame: lowest latency of a
+ * single frame), "sample_offset", and the A/B switches "fused", "wide_bounce", "wide_stream", "primary_wide", "shadow_rope", "wide";
+ * read-only through mrt_renderer_get_option: "lanes_used", "lane_bytes".  Every setting renders the same image bit for bit
+ * (except "materials", which changes the shading model).                                                                          */
 int mrt_renderer_set_option(MRTRenderer r, const char *key, double value);
 int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value);
 /* Screen-tile shard for multi-GPU: this renderer owns 8x8 tiles with (tile_id % world) == rank;
