@@ -352,7 +352,8 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_no_refill", "rope_only", "rope_unfused", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass"])
+@pytest.mark.parametrize("backend", ["hybrid_default", "hybrid_no_refill", "rope_only", "rope_unfused", "wide_all", "wide_primary_stream", "shadow_on_rope", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
+                                     "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every traversal backend / scheduling option must give the oracle's image: the default hybrid (stackless
     rope walk for primary rays, 8-wide compressed layout + LDS stack for bounce and shadow rays), rope only,
@@ -367,6 +368,10 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "wide_all": r.set_option("wide", 1)
     if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
     if backend == "shadow_on_rope": r.set_option("shadow_rope", 1)
+    if backend == "no_primary_hint": r.set_option("primary_hint", 0)
+    if backend == "persistent_always": r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
+    if backend == "persistent_never": r.set_option("persistent", 0)
+    if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 4: 5 frames = 4 + 1
