@@ -128,6 +128,23 @@ struct DragonScene : Scene {                                         // DragonSc
     }
 };
 
+// createBuffers / geometry descriptors (Renderer.swift:107-182, Mesh.swift:39-48): hand a Scene's models and lights to an MRTScene.
+// instancing: models loaded from the same resource become instances of one mesh (mrt_scene_add_instance), committed two-level.
+inline void uploadScene(MRTScene dst, const Scene &scene, bool instancing = false) {
+    if (instancing) check(mrt_scene_set_option(dst, "instancing", 1));
+    std::vector<std::pair<std::string, int32_t>> loaded;             // resource name -> mesh id of its first use
+    for (const Model &model : scene.models)
+        for (const Mesh &mesh : model.meshes) {
+            int32_t id = -1, source = -1;
+            if (instancing && model.meshes.size() == 1) for (auto &l : loaded) if (l.first == model.name) source = l.second;
+            if (source >= 0) { check(mrt_scene_add_instance(dst, source, mesh.transform, &id)); continue; }
+            check(mrt_scene_add_mesh(dst, mesh.positions.data(), 12, mesh.normals.data(), 12, mesh.positions.size() / 3, mesh.transform, &id));
+            for (const Submesh &sm : mesh.submeshes) check(mrt_mesh_add_submesh(dst, id, sm.indices.data(), sm.triangleCount(), &sm.material, nullptr));
+            loaded.emplace_back(model.name, id);
+        }
+    check(mrt_scene_set_lights(dst, scene.lights.data(), (int32_t)scene.lights.size()));
+}
+
 class Renderer {                                                     // Renderer.swift:12-357
   public:
     static constexpr int maxFramesInFlight = 3;                      // Renderer.swift:33 (here: setOption("frames_in_flight", n); library default 12 passes of 4 frames)
@@ -137,18 +154,7 @@ class Renderer {                                                     // Renderer
         check(mrt_context_create(device, &ctx_));                    // MTLCreateSystemDefaultDevice + queue (:46-59)
         try {
             check(mrt_scene_create(ctx_, &scene_));
-            if (instancing) check(mrt_scene_set_option(scene_, "instancing", 1));
-            std::vector<std::pair<std::string, int32_t>> loaded;     // resource name -> mesh id of its first use
-            for (const Model &model : scene.models)                  // createBuffers / geometry descriptors (:107-182, Mesh.swift:39-48)
-                for (const Mesh &mesh : model.meshes) {
-                    int32_t id = -1, source = -1;
-                    if (instancing && model.meshes.size() == 1) for (auto &l : loaded) if (l.first == model.name) source = l.second;
-                    if (source >= 0) { check(mrt_scene_add_instance(scene_, source, mesh.transform, &id)); continue; }
-                    check(mrt_scene_add_mesh(scene_, mesh.positions.data(), 12, mesh.normals.data(), 12, mesh.positions.size() / 3, mesh.transform, &id));
-                    for (const Submesh &sm : mesh.submeshes) check(mrt_mesh_add_submesh(scene_, id, sm.indices.data(), sm.triangleCount(), &sm.material, nullptr));
-                    loaded.emplace_back(model.name, id);
-                }
-            check(mrt_scene_set_lights(scene_, scene.lights.data(), (int32_t)scene.lights.size()));
+            uploadScene(scene_, scene, instancing);                  // createBuffers / geometry descriptors (:107-182, Mesh.swift:39-48)
             check(mrt_scene_commit(scene_));                         // createAccelerationStructures (:184-214)
             check(mrt_renderer_create(ctx_, scene_, width, height, seed, max_bounces, &r_));
             check(mrt_renderer_set_camera(r_, &scene.camera));
@@ -159,6 +165,10 @@ class Renderer {                                                     // Renderer
     ~Renderer() { destroy(); }
     void draw(int frames = 1) { check(mrt_renderer_render(r_, frames)); }                   // draw(in:) (:284-351)
     void wait() { check(mrt_renderer_wait(r_)); }
+    uint64_t framesCompleted() const { uint64_t f = 0; check(mrt_renderer_frames_completed(r_, &f)); return f; }   // the completion handler of :285-287 as a poll; never blocks
+    // updateUniforms (:216-229): size, frameIndex, lightCount and camera as the one 96-byte block the reference binds at buffer index 0
+    MRTUniforms uniforms() const { MRTUniforms u; check(mrt_renderer_get_uniforms(r_, &u)); return u; }
+    void setUniforms(const MRTUniforms &u) { check(mrt_renderer_set_uniforms(r_, &u)); w_ = u.width; h_ = u.height; }
     void drawableSizeWillChange(int width, int height) { w_ = width; h_ = height; check(mrt_renderer_resize(r_, width, height)); }   // :353-356
     uint32_t frameIndex() const { uint32_t f = 0; check(mrt_renderer_frame_index(r_, &f)); return f; }
     void setFrameIndex(uint32_t f) { check(mrt_renderer_set_frame_index(r_, f)); }
@@ -186,6 +196,46 @@ class Renderer {                                                     // Renderer
     MRTContext ctx_ = nullptr;
     MRTScene scene_ = nullptr;
     MRTRenderer r_ = nullptr;
+};
+
+// The same Renderer over the n GPUs of one node (one process): the scene is replicated, the image sharded by 8x8 screen tile
+// (tile_id % n == rank), and gather() runs the ONE reduce(sum) per output image (RCCL over xGMI).  The reference creates a single
+// MTLDevice (Renderer.swift:46-59); this widens that seam.  The assembled image is bit-identical to Renderer's.
+class GroupRenderer {
+  public:
+    GroupRenderer(int width, int height, const Scene &scene, const std::vector<int> &devices, uint32_t seed = 1, int max_bounces = 3, bool instancing = false) : w_(width), h_(height) {
+        check(mrt_group_create(devices.data(), (int32_t)devices.size(), &g_));
+        try {
+            MRTContext c0 = nullptr; check(mrt_group_context(g_, 0, &c0));
+            check(mrt_scene_create(c0, &template_));
+            uploadScene(template_, scene, instancing);               // the template is replicated and committed on every device
+            check(mrt_group_renderer_create(g_, template_, width, height, seed, max_bounces, &gr_));
+            check(mrt_group_set_camera(gr_, &scene.camera));
+        } catch (...) { destroy(); throw; }
+    }
+    GroupRenderer(const GroupRenderer &) = delete;
+    GroupRenderer &operator=(const GroupRenderer &) = delete;
+    ~GroupRenderer() { destroy(); }
+    int size() const { int32_t n = 0; check(mrt_group_size(g_, &n)); return n; }
+    void draw(int frames = 1) { check(mrt_group_render(gr_, frames)); }                      // every device; returns at once
+    void wait() { check(mrt_group_wait(gr_)); }
+    uint64_t framesCompleted() const { uint64_t f = 0; check(mrt_group_frames_completed(gr_, &f)); return f; }
+    void setOption(const char *key, double value) { check(mrt_group_set_option(gr_, key, value)); }
+    std::vector<float> gather() { std::vector<float> a((size_t)w_ * h_ * 4); check(mrt_group_gather(gr_, a.data(), a.size() * 4)); return a; }   // the assembled image
+    MRTRenderStats stats() { MRTRenderStats s; check(mrt_group_stats(gr_, &s)); return s; }
+    std::string reduceMode() const { int32_t m = 0; char note[256]; check(mrt_group_reduce_mode(g_, &m, note, sizeof note)); return note; }
+
+  private:
+    void destroy() {
+        if (gr_) mrt_group_renderer_destroy(gr_);
+        if (template_) mrt_scene_destroy(template_);
+        if (g_) mrt_group_destroy(g_);
+        gr_ = nullptr; template_ = nullptr; g_ = nullptr;
+    }
+    int w_, h_;
+    MRTGroup g_ = nullptr;
+    MRTScene template_ = nullptr;
+    MRTGroupRenderer gr_ = nullptr;
 };
 
 }  // namespace mrt

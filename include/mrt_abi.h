@@ -141,6 +141,8 @@ typedef struct {
 typedef struct MRTContext_  *MRTContext;
 typedef struct MRTScene_    *MRTScene;
 typedef struct MRTRenderer_ *MRTRenderer;
+typedef struct MRTGroup_         *MRTGroup;            /* n devices of one node driven by one process               */
+typedef struct MRTGroupRenderer_ *MRTGroupRenderer;    /* one renderer per device of a group, image sharded by tile  */
 
 /* ---------------------------------------------------------------- errors */
 /* Message of the last failing call on this thread ("" if none).                               */
@@ -231,6 +233,14 @@ int mrt_renderer_destroy(MRTRenderer r);
 int mrt_renderer_resize(MRTRenderer r, int32_t width, int32_t height);
 /* Default camera = Scene.setupCamera(size) recomputed from the size (Scene.swift:36-57).       */
 int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
+/* updateUniforms (Renderer.swift:216-229) in one call: the 96-byte Uniforms block the reference binds at buffer index 0
+ * (ShaderTypes.h:89-97, Renderer.swift:304).  A new width / height resizes (new targets and seeds, Renderer.swift:353-356, and
+ * the given frameIndex is applied after that); frameIndex is the accumulation weight and Halton index of the next frame;
+ * lightCount in [1, lights of the scene] makes the kernels sample only the first lightCount lights (Raytracing.metal:273, :335);
+ * blocksWide is ignored (derived from the size; the reference's kernel never reads it).  get_uniforms returns what the next
+ * frame will be drawn with.                                                                                                 */
+int mrt_renderer_set_uniforms(MRTRenderer r, const MRTUniforms *uniforms);
+int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
 /* Tuning knobs of this implementation (no counterpart in the reference beyond maxFramesInFlight, Renderer.swift:33):
  * "max_bounces", "frames_in_flight" (HIP streams carrying frame batches concurrently), "frame_batch" (frames carried through
  * the pipeline per pass, <= 32), "persistent" (bounce / shadow traversal as persistent waves pulling chunks: 0 never, 1 always, 2 by launch
@@ -251,6 +261,10 @@ int mrt_renderer_frame_index(MRTRenderer r, uint32_t *frame_index);
 int mrt_renderer_render(MRTRenderer r, int32_t n_frames);
 /* commandBuffer completion (Renderer.swift:285-287).                                           */
 int mrt_renderer_wait(MRTRenderer r);
+/* The same completion as a poll (the reference's handler is told per command buffer, Renderer.swift:285-287): frames, counted
+ * as MRTRenderStats.frames is, whose accumulation has finished on the device.  Never blocks; completion is reported per pass
+ * of `frame_batch` frames.                                                                                                   */
+int mrt_renderer_frames_completed(MRTRenderer r, uint64_t *frames);
 /* accumulationTargets[0] after the swap (Renderer.swift:332-334): w*h RGBA32F, row 0 = bottom of
  * the image as the kernel writes it (Raytracing.metal:206-207; the blit flips, Shaders.metal:35). */
 int mrt_renderer_read_accum(MRTRenderer r, float *rgba, size_t nbytes);
@@ -262,6 +276,36 @@ int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbyt
 int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out);
 int mrt_renderer_reset_stats(MRTRenderer r);
 int mrt_renderer_kernel_times(MRTRenderer r, MRTKernelTimes *out);   /* waits for the last render call */
+
+/* ---------------------------------------------------------------- device group (multi-GPU, one process)
+ * The reference creates ONE device and ONE queue (MTLCreateSystemDefaultDevice + makeCommandQueue, Renderer.swift:46-59); this is that
+ * seam widened to the n GPUs of a node.  The scene and its BVH are replicated on every device; the image is sharded by 8x8 screen tile
+ * (tile_id % n == rank); each device accumulates its frames locally; mrt_group_gather assembles the image with ONE reduce(sum) of the
+ * RGBA32F buffer — ncclReduce over xGMI (RCCL is opened when a group of several distinct devices is created), or peer copies + add.
+ * The assembled image is bit-identical to the single-device image.                                                                  */
+int mrt_group_create(const int *device_ids, int32_t n, MRTGroup *out);
+int mrt_group_destroy(MRTGroup g);
+int mrt_group_size(MRTGroup g, int32_t *n);
+int mrt_group_context(MRTGroup g, int32_t rank, MRTContext *ctx);                  /* borrowed: the group owns its contexts            */
+/* mode: 0 = ncclReduce(sum, float32, root 0), 1 = peer copies into the root device + add; note: why (may be NULL).                  */
+int mrt_group_reduce_mode(MRTGroup g, int32_t *mode, char *note, size_t note_len);
+int mrt_group_set_reduce_mode(MRTGroup g, int32_t mode);
+/* Renderer.init for the whole group: `scene` (any context; committed or not) is the template — its meshes, lights and build options are
+ * replicated and committed on every device; rank r renders the tiles with tile_id % n == r.  The template scene stays the caller's.  */
+int mrt_group_renderer_create(MRTGroup g, MRTScene scene, int32_t width, int32_t height, uint32_t seed, int32_t max_bounces, MRTGroupRenderer *out);
+int mrt_group_renderer_destroy(MRTGroupRenderer gr);
+int mrt_group_renderer_rank(MRTGroupRenderer gr, int32_t rank, MRTRenderer *r);     /* borrowed: one device's renderer (options, stats)  */
+int mrt_group_set_option(MRTGroupRenderer gr, const char *key, double value);      /* mrt_renderer_set_option on every device           */
+int mrt_group_set_camera(MRTGroupRenderer gr, const MRTCamera *camera);
+/* draw(in:) (Renderer.swift:284-351) n_frames times on every device: enqueues and returns; the devices run concurrently.              */
+int mrt_group_render(MRTGroupRenderer gr, int32_t n_frames);
+int mrt_group_wait(MRTGroupRenderer gr);
+int mrt_group_frames_completed(MRTGroupRenderer gr, uint64_t *frames);             /* minimum over the devices; never blocks            */
+/* The one collective per output image: reduce(sum) of every device's accumulation buffer into rank 0, then (rgba != NULL) a copy of
+ * the assembled w*h RGBA32F image to the host (row 0 = bottom, as mrt_renderer_read_accum).  Blocks until the image is assembled.   */
+int mrt_group_gather(MRTGroupRenderer gr, float *rgba, size_t nbytes);
+int mrt_group_gathered_device_ptr(MRTGroupRenderer gr, void **device_ptr);         /* the assembled image on the root device            */
+int mrt_group_stats(MRTGroupRenderer gr, MRTRenderStats *out);                     /* ray counters summed over the devices              */
 
 /* ---------------------------------------------------------------- device-function probes
  * Evaluate the kernel's helper functions on the device for known-answer tests

@@ -152,6 +152,9 @@ SIGNATURES = {
     "mrt_renderer_destroy": (C.c_int, [_P]),
     "mrt_renderer_resize": (C.c_int, [_P, _I32, _I32]),
     "mrt_renderer_set_camera": (C.c_int, [_P, C.POINTER(Camera)]),
+    "mrt_renderer_set_uniforms": (C.c_int, [_P, C.POINTER(Uniforms)]),
+    "mrt_renderer_get_uniforms": (C.c_int, [_P, C.POINTER(Uniforms)]),
+    "mrt_renderer_frames_completed": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "mrt_renderer_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "mrt_renderer_get_option": (C.c_int, [_P, C.c_char_p, _P]),
     "mrt_renderer_set_shard": (C.c_int, [_P, _I32, _I32]),
@@ -166,6 +169,23 @@ SIGNATURES = {
     "mrt_renderer_stats": (C.c_int, [_P, C.POINTER(RenderStats)]),
     "mrt_renderer_reset_stats": (C.c_int, [_P]),
     "mrt_renderer_kernel_times": (C.c_int, [_P, C.POINTER(KernelTimes)]),
+    "mrt_group_create": (C.c_int, [_PI32, _I32, C.POINTER(_P)]),
+    "mrt_group_destroy": (C.c_int, [_P]),
+    "mrt_group_size": (C.c_int, [_P, _PI32]),
+    "mrt_group_context": (C.c_int, [_P, _I32, C.POINTER(_P)]),
+    "mrt_group_reduce_mode": (C.c_int, [_P, _PI32, C.c_char_p, _SZ]),
+    "mrt_group_set_reduce_mode": (C.c_int, [_P, _I32]),
+    "mrt_group_renderer_create": (C.c_int, [_P, _P, _I32, _I32, _U32, _I32, C.POINTER(_P)]),
+    "mrt_group_renderer_destroy": (C.c_int, [_P]),
+    "mrt_group_renderer_rank": (C.c_int, [_P, _I32, C.POINTER(_P)]),
+    "mrt_group_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "mrt_group_set_camera": (C.c_int, [_P, C.POINTER(Camera)]),
+    "mrt_group_render": (C.c_int, [_P, _I32]),
+    "mrt_group_wait": (C.c_int, [_P]),
+    "mrt_group_frames_completed": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "mrt_group_gather": (C.c_int, [_P, _P, _SZ]),
+    "mrt_group_gathered_device_ptr": (C.c_int, [_P, C.POINTER(_P)]),
+    "mrt_group_stats": (C.c_int, [_P, C.POINTER(RenderStats)]),
     "mrt_debug_halton": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_hemisphere": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "mrt_debug_seeds": (C.c_int, [_P, _U32, _I32, _I32, _P]),
@@ -186,6 +206,39 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C metal-raytracing_amd/csrc`. There is no CPU fallback for the render path.")
 
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process, whatever the import order.  PyTorch ships its own libamdhip64 / libhsa-runtime64 under
+    torch/lib with the SAME sonames as /opt/rocm's: whichever copy is loaded first serves both.  libmrt_hip.so works on either; torch
+    only works on its own (import torch after /opt/rocm's runtime is resident: "No HIP GPUs are available").  So when torch is
+    installed and not yet imported, its copies are loaded here, before libmrt_hip.so pulls in the system ones.  A C / C++ / Swift
+    host never sees this: it has one runtime.  MRT_HIP_RUNTIME=system skips it."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MRT_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    loaded = []
+    # (not librccl: the library opens RCCL only when a device group is created, and then takes the copy already in the process)
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path)
+                loaded.append(path)
+            except OSError:
+                return loaded
+    return loaded
+
+
+HIP_RUNTIME_PRELOADED = _share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch: fail loudly

@@ -1,34 +1,13 @@
 // api.cpp — implementation of include/mrt_abi.h.  Every entry point validates its arguments,
 // catches C++ exceptions and returns a status code; nothing throws or aborts across the ABI.
 // There is no CPU fallback: without a HIP device mrt_context_create fails (MRT_ERR_NO_DEVICE).
-#include "renderer.h"
+#include "api_types.h"
 #include "abi_check.h"
+#include <algorithm>
 #include <cstring>
 #include <cstdio>
 #include <memory>
 #include <new>
-
-struct MRTContext_ {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    char name[256] = {0};
-};
-struct MRTScene_ {
-    MRTContext ctx = nullptr;
-    std::vector<mrt::HostMesh> meshes;
-    std::vector<MRTLight> lights;
-    mrt::BuildOptions opt;
-    mrt::DeviceScene dev;
-    bool committed = false;
-    bool only_transforms_changed = false;   // since the last commit of a two-level scene: the next commit rebuilds the TLAS only
-};
-struct MRTRenderer_ {
-    MRTContext ctx = nullptr;
-    MRTScene scene = nullptr;
-    mrt::Renderer r;
-};
-struct MRTMeshData_ { mrt::MeshData m; };
 
 namespace mrt {
 static thread_local std::string g_err;
@@ -40,13 +19,6 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return e == hipErrorOutOfMemory ? MRT_ERR_OUT_OF_MEMORY : MRT_ERR_HIP;
 }
 }  // namespace mrt
-
-#define MRT_TRY try {
-#define MRT_CATCH                                                                      \
-    } catch (const std::bad_alloc &) { mrt::set_error("out of host memory"); return MRT_ERR_OUT_OF_MEMORY; } \
-    catch (const std::exception &e) { mrt::set_error(std::string("exception: ") + e.what()); return MRT_ERR_INVALID_ARGUMENT; } \
-    catch (...) { mrt::set_error("unknown exception"); return MRT_ERR_INVALID_ARGUMENT; }
-#define REQUIRE(cond, msg) do { if (!(cond)) { mrt::set_error(msg); return MRT_ERR_INVALID_ARGUMENT; } } while (0)
 
 static int bind_device(MRTContext ctx) { MRT_HIP(hipSetDevice(ctx->device)); return MRT_OK; }
 
@@ -201,6 +173,9 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
+    else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
+    else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
     else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
@@ -412,6 +387,42 @@ int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera) {
     REQUIRE(r && camera, "mrt_renderer_set_camera: bad argument");
     r->r.camera = *camera;
     return MRT_OK;
+}
+// updateUniforms (Renderer.swift:216-229) as ONE call: size, frame index, light count and camera.  blocksWide is derived (the reference
+// computes it from the size, :222, and its kernel never reads it).
+int mrt_renderer_set_uniforms(MRTRenderer r, const MRTUniforms *u) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_set_uniforms")
+    REQUIRE(u, "mrt_renderer_set_uniforms: uniforms is NULL");
+    REQUIRE(u->width > 0 && u->height > 0 && (int64_t)u->width * u->height < (1ll << 30), "mrt_renderer_set_uniforms: bad size");
+    REQUIRE(u->lightCount >= 1 && u->lightCount <= r->scene->dev.light_count, "mrt_renderer_set_uniforms: lightCount must be in [1, lights of the scene]");
+    if (u->width != r->r.width || u->height != r->r.height) {          // mtkView(_:drawableSizeWillChange:): new targets, new seeds (Renderer.swift:353-356)
+        MRT_HIP(hipStreamSynchronize(r->r.stream));
+        int rc = r->r.resize(u->width, u->height); if (rc) return rc;
+    }
+    r->r.frame_index = u->frameIndex;
+    r->r.light_count_limit = u->lightCount == r->scene->dev.light_count ? 0 : u->lightCount;
+    r->r.camera = u->camera;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *u) {
+    REQUIRE(r && u, "mrt_renderer_get_uniforms: bad argument");
+    memset(u, 0, sizeof *u);
+    u->width = r->r.width; u->height = r->r.height; u->blocksWide = (r->r.width + 7) / 8;
+    u->frameIndex = r->r.frame_index;
+    u->lightCount = r->r.light_count_limit > 0 ? std::min(r->r.light_count_limit, r->scene->dev.light_count) : r->scene->dev.light_count;
+    u->camera = r->r.camera;
+    return MRT_OK;
+}
+// commandBuffer.addCompletedHandler (Renderer.swift:285-287) as a poll: frames (since create / resize / reset_stats) whose accumulation
+// has finished on the device.  Never blocks; mrt_renderer_wait is the blocking form.
+int mrt_renderer_frames_completed(MRTRenderer r, uint64_t *frames) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_frames_completed")
+    REQUIRE(frames, "mrt_renderer_frames_completed: NULL");
+    return r->r.poll_completed(frames);
+    MRT_CATCH
 }
 int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     MRT_TRY

@@ -456,11 +456,59 @@ __global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restric
 }
 __global__ void k_set_root_parent(const uint32_t *__restrict__ cid, uint32_t *__restrict__ parent) { parent[cid[0]] = NONE; }
 
+// ------------------------------------------------------------------ optimal 8-wide collapse (wide_collapse = 1)
+// After Ylitie, Karras, Laine 2017 ("Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", §3.1): for every node n of the
+// binary tree, C(n, i) = the least SAH cost of representing n's subtree as a forest of at most i wide-BVH roots, i = 1..7:
+//   C(n, 1)  = min(C_leaf(n), C_node(n)),   C_leaf = area * triangles * c_tri  (subtrees of <= max_leaf triangles),
+//                                           C_node = area * c_node + min_k C(left, k) + C(right, 8 - k)
+//   C(n, i)  = min(C(n, i - 1), min_k C(left, k) + C(right, i - k))
+// computed bottom-up (same arrival protocol as k_refit), with the arg-min of every entry kept: dec[0] = k of C_node, dec[1] = 1 when the
+// leaf is cheaper, dec[i] = k of the split or 0 for "no better than i - 1 roots".  k_wide_level<true> then unfolds the decisions of a
+// wide node's root into its (at most eight) children.  The greedy collapse it replaces opens the largest child first and fills 6.0 of 8
+// slots on DragonScene; this one trades nodes against triangle tests with the constants the traversal kernel was measured at.
+struct WideDP { float *C; uint8_t *dec; };      // 8 entries per node
+__global__ void k_wide_dp(TreeArrays t, WideDP dp, uint32_t *__restrict__ flags2, uint32_t n, uint32_t leaf_base, int max_leaf, float c_node, float c_tri) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t node = leaf_base + j;
+    {
+        const float c = c_tri * box_area(t.lo[node], t.hi[node]);
+        for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)node + i] = c; dp.dec[8 * (size_t)node + i] = i == 1 ? 1 : 0; }
+    }
+    __threadfence();
+    uint32_t p = t.parent[node];
+    while (p != NONE) {
+        uint32_t old = atomicAdd(&flags2[p], 1u);
+        if (old == 0) return;
+        __threadfence();
+        const uint32_t l = t.left[p], r = t.right[p];
+        float cl[8], cr[8];
+        for (int i = 1; i < 8; i++) { cl[i] = dp.C[8 * (size_t)l + i]; cr[i] = dp.C[8 * (size_t)r + i]; }
+        const float area = box_area(t.lo[p], t.hi[p]);
+        const uint32_t nt = t.ntri[p];
+        float C[8]; uint8_t D[8];
+        float best = 3.0e38f; int bk = 1;
+        for (int k = 1; k <= 7; k++) { const float c = cl[k] + cr[8 - k]; if (c < best) { best = c; bk = k; } }
+        const float c_int = area * c_node + best;
+        const float c_leaf = nt <= (uint32_t)max_leaf ? area * (float)nt * c_tri : 3.0e38f;
+        D[0] = (uint8_t)bk; D[1] = c_leaf <= c_int ? 1 : 0; C[1] = fminf(c_leaf, c_int); C[0] = c_int;
+        for (int i = 2; i <= 7; i++) {
+            float b = 3.0e38f; int k_ = 1;
+            for (int k = 1; k < i; k++) { const float c = cl[k] + cr[i - k]; if (c < b) { b = c; k_ = k; } }
+            if (b < C[i - 1]) { C[i] = b; D[i] = (uint8_t)k_; } else { C[i] = C[i - 1]; D[i] = 0; }
+        }
+        for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)p + i] = C[i]; dp.dec[8 * (size_t)p + i] = D[i]; }
+        __threadfence();
+        p = t.parent[p];
+    }
+}
+
 // ------------------------------------------------------------------ 8-wide collapse + quantisation
 // One thread per wide node of the current level.  Greedy collapse (largest surface area first) of the
 // refitted binary tree; children that are binary inner nodes form the next level (BFS numbering, so a
 // node's children are contiguous and the top of the tree sits at the lowest indices).
-__global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_offset, const uint32_t *__restrict__ fin, uint32_t n_in,
+template <bool DP>
+__global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict__ leaf_offset, const uint32_t *__restrict__ fin, uint32_t n_in,
                              uint32_t base_in, uint32_t next_base, uint32_t *__restrict__ fout, uint32_t *__restrict__ counters /* [0] next-level nodes, [1] packets */,
                              float4 *__restrict__ wnodes, const float4 *__restrict__ packets, float4 *__restrict__ wpackets) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +516,24 @@ __global__ void k_wide_level(TreeArrays t, const uint32_t *__restrict__ leaf_off
     uint32_t ch[8]; bool isleaf[8]; int nch = 0;
     uint32_t ninner = 0, ntris = 0;
     float4 nlo = make_float4(0, 0, 0, 0), nhi = nlo;
-    if (active) {
+    if (active && DP) {
+        const uint32_t f = fin[i];
+        nlo = t.lo[f]; nhi = t.hi[f];
+        if (base_in == 0 && dp.dec[8 * (size_t)f + 1]) { ch[0] = f; isleaf[0] = true; nch = 1; }     // the whole scene is one leaf
+        else {
+            // unfold the decisions: (node, roots allowed) pairs, depth first; at most eight children come out
+            uint32_t st_n[8]; uint8_t st_i[8]; int sp = 0;
+            { const uint32_t k = dp.dec[8 * (size_t)f + 0]; st_n[sp] = t.right[f]; st_i[sp++] = (uint8_t)(8u - k); st_n[sp] = t.left[f]; st_i[sp++] = (uint8_t)k; }
+            while (sp > 0) {
+                const uint32_t c = st_n[--sp]; uint32_t b = st_i[sp];
+                while (b > 1u && dp.dec[8 * (size_t)c + b] == 0) b--;
+                if (b == 1u) { ch[nch] = c; isleaf[nch] = dp.dec[8 * (size_t)c + 1] != 0; nch++; }
+                else { const uint32_t k = dp.dec[8 * (size_t)c + b]; st_n[sp] = t.right[c]; st_i[sp++] = (uint8_t)(b - k); st_n[sp] = t.left[c]; st_i[sp++] = (uint8_t)k; }
+            }
+        }
+        for (int k = 0; k < nch; k++) { if (isleaf[k]) ntris += t.ntri[ch[k]]; else ninner++; }
+    }
+    if (active && !DP) {
         const uint32_t f = fin[i];
         nlo = t.lo[f]; nhi = t.hi[f];
         if (t.collapsed[f]) { ch[0] = f; isleaf[0] = true; nch = 1; }
@@ -860,11 +925,21 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     // a wide node addresses its leaf triangles with a 32-bit mask: 8 leaf children x max_leaf triangles must fit
     if (opt.wide && opt.max_leaf <= 4) {
         // ---- 8-wide compressed layout, level by level (BFS numbering)
-        const size_t max_w = (size_t)h_size / 2 + 2;
+        // greedy: every wide node is an inner node of the collapsed binary tree and swallows at least one more; optimal: every wide node has
+        // at least two children and every leaf child at least one triangle, so there are fewer wide nodes than triangles.  The array is trimmed below.
+        const size_t max_w = opt.wide_collapse ? (size_t)n + 2 : (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
         MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
         MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
+        DevBuf<float> dpC; DevBuf<uint8_t> dpD;
+        WideDP dp{nullptr, nullptr};
+        if (opt.wide_collapse) {
+            MRT_HIP(dpC.alloc(8 * (size_t)nnodes)); MRT_HIP(dpD.alloc(8 * (size_t)nnodes));
+            dp.C = dpC.p; dp.dec = dpD.p;
+            MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
+            hipLaunchKernelGGL(k_wide_dp, dim3(cdiv(n, B)), dim3(B), 0, stream, t, dp, flags.p, n, leaf_base, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
+        }
         MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
         MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
         uint32_t n_in = 1, base_in = 0, total = 0; int depth = 0;
@@ -873,8 +948,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
             depth++;
             if (total + n_in > max_w) { set_error("wide BVH build overflow"); return MRT_ERR_HIP; }
             MRT_HIP(hipMemsetAsync(wc.p, 0, 4, stream));
-            hipLaunchKernelGGL(k_wide_level, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
-                               out.wnodes.p, packets_p, out.wpackets.p);
+            if (opt.wide_collapse) hipLaunchKernelGGL(k_wide_level<true>, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
+                                                      out.wnodes.p, packets_p, out.wpackets.p);
+            else hipLaunchKernelGGL(k_wide_level<false>, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
+                                    out.wnodes.p, packets_p, out.wpackets.p);
             uint32_t n_out = 0;
             MRT_HIP(hipMemcpyAsync(&n_out, wc.p, 4, hipMemcpyDeviceToHost, stream));
             MRT_HIP(hipStreamSynchronize(stream));
@@ -889,6 +966,12 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         if (h_wc[1] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
         out.stats.build_ms += wms;
         out.wide_depth = depth;
+        if ((size_t)total + 1 < max_w) {            // keep what the tree uses
+            DevBuf<float4> trimmed; MRT_HIP(trimmed.alloc(WNODE_STRIDE * (size_t)std::max(total, 1u)));
+            MRT_HIP(hipMemcpyAsync(trimmed.p, out.wnodes.p, WNODE_STRIDE * (size_t)total * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            MRT_HIP(hipStreamSynchronize(stream));
+            std::swap(out.wnodes.p, trimmed.p); std::swap(out.wnodes.n, trimmed.n);
+        }
         if (depth <= WIDE_STACK && total < (1u << 24)) out.num_wnodes = total;       // deeper than the LDS stack (or child_base beyond its 24 stack bits): keep the rope backend
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;

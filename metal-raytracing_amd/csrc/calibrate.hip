@@ -81,11 +81,15 @@ int calibrate(hipStream_t stream, size_t table_bytes, double *out3) {
     int dev = 0; MRT_HIP(hipGetDevice(&dev));
     hipDeviceProp_t prop; MRT_HIP(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount;
+    // the gather index has 28 usable bits ((idx >> 4) & mask): 2^28 16-byte records = 4 GiB is the largest table the R = 1 pass can cover
+    if (table_bytes > (size_t(4) << 30)) table_bytes = size_t(4) << 30;
     DevBuf<float> sink; MRT_HIP(sink.alloc(1 << 16));
-    hipEvent_t e0, e1; MRT_HIP(hipEventCreate(&e0)); MRT_HIP(hipEventCreate(&e1));
+    DevBuf<unsigned long long> clocks; MRT_HIP(clocks.alloc(2));       // before the events: nothing below may return without finish()
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return MRT_ERR_HIP;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MRT_ERR_HIP; }
     auto finish = [&](int rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; };
     const int iters = 4096;
-    DevBuf<unsigned long long> clocks; MRT_HIP(clocks.alloc(2));
     for (int pass = 0; pass < 2; pass++) {
         const uint32_t grid = (uint32_t)(cus * 4 * 8);
         float best = 1e30f;

@@ -3,6 +3,8 @@
 #include "scene_device.h"
 #include "host_geometry.h"
 #include <array>
+#include <deque>
+#include <vector>
 
 namespace mrt {
 
@@ -63,6 +65,16 @@ struct Renderer {
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
+
+    int light_count_limit = 0;           // > 0: the kernels see only the first n lights (Uniforms.lightCount, ShaderTypes.h:93; 0 = all the scene's lights)
+    // completion without blocking (the reference is told per frame, Renderer.swift:285-287): one pooled event per pass, recorded after its
+    // k_accumulate; passes complete in order (each accumulate waits for the previous one)
+    struct PassDone { hipEvent_t ev; uint64_t frames_through; };
+    std::deque<PassDone> passes_pending;
+    std::vector<hipEvent_t> pass_events_free;
+    uint64_t frames_completed_known = 0; // frames (since create / resize) whose accumulate is known to have finished
+    int note_pass(hipStream_t st);       // render(): after a pass's accumulate
+    int poll_completed(uint64_t *out);   // hipEventQuery only; never waits
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::array<EvPair, 512> ev_ext;

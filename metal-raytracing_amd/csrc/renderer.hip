@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
         }
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
-            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);      // (the scaled form needs one more register: 128 -> spills)
             uint32_t sp = g_mask >> 16;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
             g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
@@ -636,8 +636,10 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
             const float4 *__restrict__ mp = s.materials + 3 * (size_t)(inst * (uint32_t)s.max_sub + geom);
             const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
             const f3 em = color * mk3(m2);
-            const float4 acc = sample_primary ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : sample[pix];
-            sample[pix] = make_float4(acc.x + em.x, acc.y + em.y, acc.z + em.z, 0.0f);
+            // bounce 0: pix == spix and the zero above went through `sample_primary`; the emission follows through the SAME pointer (both are
+            // __restrict__: two names for one address would leave the order of the two stores to the compiler)
+            if (sample_primary) sample_primary[pix] = make_float4(0.0f + em.x, 0.0f + em.y, 0.0f + em.z, 0.0f);
+            else { const float4 acc = sample[pix]; sample[pix] = make_float4(acc.x + em.x, acc.y + em.y, acc.z + em.z, 0.0f); }
             const float ul = halton_dev(idx, 2 + 5 * fp.max_bounces + fp.bounce);
             const f3 spec = mk3(m1);
             const float kd = fmaxf(surf.x, fmaxf(surf.y, surf.z)), ks = fmaxf(spec.x, fmaxf(spec.y, spec.z));
@@ -870,7 +872,8 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
     else { if (any) traverse<true, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); else traverse<false, true>(s, o, d, r.min_distance, r.max_distance, h, &tc); }
     unsigned long long t1 = wall_clock64();
     out[8 * i + 0] = tc.steps; out[8 * i + 1] = tc.leaves; out[8 * i + 2] = tc.tris; out[8 * i + 3] = h.gid;
-    out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters; out[8 * i + 7] = __float_as_uint(tc.sink);   // 100 MHz ticks
+    out[8 * i + 4] = (uint32_t)t0; out[8 * i + 5] = (uint32_t)t1; out[8 * i + 6] = tc.wave_iters;   // 100 MHz ticks
+    out[8 * i + 7] = (tc.alu_dup | tc.mem_dup) ? __float_as_uint(tc.sink) : (tc.empty & 0xFFFFu) | (tc.stale << 16);    // 8-wide layout: empty visits | stale visits << 16
 }
 
 // stream-traversal lane accounting (diagnostics): per wave {iterations, sum of live lanes, node lanes, tri lanes, refills, refilled lanes}
@@ -969,6 +972,8 @@ Renderer::~Renderer() {
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto &e : ev_ext) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+    for (auto &pd : passes_pending) (void)hipEventDestroy(pd.ev);
+    for (auto e : pass_events_free) (void)hipEventDestroy(e);
     for (auto &L : lanes) {
         if (L.stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
         if (L.accumulated) (void)hipEventDestroy(L.accumulated);
@@ -991,7 +996,33 @@ int Renderer::resize(int w, int h) {                                   // Render
     frame_index = 0; cur = 0;
     MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
     frames_rendered = 0;
+    for (auto &pd : passes_pending) pass_events_free.push_back(pd.ev);      // the caller synchronised (mrt_renderer_resize)
+    passes_pending.clear(); frames_completed_known = 0;
     return alloc_queues();
+}
+
+int Renderer::note_pass(hipStream_t st) {
+    // more than 1024 passes queued ahead of the GPU: the newest entry absorbs further passes (its event is re-recorded)
+    if (passes_pending.size() < 1024 || passes_pending.empty()) {
+        hipEvent_t e = nullptr;
+        if (!pass_events_free.empty()) { e = pass_events_free.back(); pass_events_free.pop_back(); }
+        else MRT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        passes_pending.push_back(PassDone{e, frames_rendered});
+    } else passes_pending.back().frames_through = frames_rendered;
+    MRT_HIP(hipEventRecord(passes_pending.back().ev, st));
+    return MRT_OK;
+}
+int Renderer::poll_completed(uint64_t *out) {
+    while (!passes_pending.empty()) {
+        const hipError_t q = hipEventQuery(passes_pending.front().ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery", __FILE__, __LINE__);
+        frames_completed_known = passes_pending.front().frames_through;
+        pass_events_free.push_back(passes_pending.front().ev);
+        passes_pending.pop_front();
+    }
+    *out = frames_completed_known;
+    return MRT_OK;
 }
 
 int Renderer::alloc_queues() {
@@ -1046,7 +1077,7 @@ int Renderer::render(int n_frames) {                                   // Render
     SceneView sv = scene->view();
     if (sv.light_count < 1) { set_error("scene has no lights (lightCount must be >= 1, Raytracing.metal:273)"); return MRT_ERR_STATE; }
     FrameParams fp{};
-    fp.width = width; fp.height = height; fp.lightCount = sv.light_count;
+    fp.width = width; fp.height = height; fp.lightCount = light_count_limit > 0 ? std::min(light_count_limit, sv.light_count) : sv.light_count;
     fp.cam_pos = make_float4(camera.position.x, camera.position.y, camera.position.z, 0);
     fp.cam_right = make_float4(camera.right.x, camera.right.y, camera.right.z, 0);
     fp.cam_up = make_float4(camera.up.x, camera.up.y, camera.up.z, 0);
@@ -1069,7 +1100,7 @@ int Renderer::render(int n_frames) {                                   // Render
         MRT_HIP(hipMemcpyAsync(totals.p, keep_totals, sizeof keep_totals, hipMemcpyHostToDevice, stream));
         MRT_HIP(hipMemcpyAsync(accum[keep_cur].p, keep.p, keep.bytes(), hipMemcpyDeviceToDevice, stream));
         MRT_HIP(hipStreamSynchronize(stream));
-        frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; camera = keep_cam;
+        frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; frames_completed_known = keep_rendered; camera = keep_cam;
         return render(n_frames);
     }
     // the first draw sizes the lanes in use.  A lane's queues take ~176 B x pixels x frame_batch (1080p, 4-frame passes: 1.5 GB); when the
@@ -1129,6 +1160,7 @@ int Renderer::render(int n_frames) {                                   // Render
             MRT_HIP(hipEventRecord(L.accumulated, st));
             last_acc = L.accumulated;
             frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
+            if (int rc = note_pass(st)) return rc;
             continue;
         }
         if ((fused || two_level || materials) && !wide) {
@@ -1229,6 +1261,7 @@ int Renderer::render(int n_frames) {                                   // Render
         last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334 (once per batch: the batch's frames are applied in one kernel)
         frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
+        if (int rc = note_pass(st)) return rc;
     }
     // join: the main stream continues after every lane has drained
     for (int k = 0; k < std::min(F, pass); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
@@ -1240,6 +1273,7 @@ int Renderer::render(int n_frames) {                                   // Render
 
 int Renderer::wait() {
     MRT_HIP(hipStreamSynchronize(stream));
+    { uint64_t done = 0; if (int rc = poll_completed(&done)) return rc; }
     if (pending_timing) {
         float ms = 0;
         MRT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -1298,6 +1332,9 @@ int Renderer::stats(MRTRenderStats *out) {
 }
 int Renderer::reset_stats() {
     MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
+    MRT_HIP(hipStreamSynchronize(stream));       // frames_completed counts from here: nothing of the old count may still be in flight
+    for (auto &pd : passes_pending) pass_events_free.push_back(pd.ev);
+    passes_pending.clear(); frames_completed_known = 0;
     frames_rendered = 0;
     return MRT_OK;
 }

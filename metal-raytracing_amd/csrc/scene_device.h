@@ -134,6 +134,8 @@ struct BuildOptions {
     float cost_isect = 1.0f;
     int ploc_radius = 16;
     int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
+    int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
+    float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
                               // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS
 };

@@ -44,7 +44,8 @@ MRT_DEV bool tri_test(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float tmin, f
     return t >= tmin && t <= lim;
 }
 
-struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0, mem_dup = 0; float sink = 0.0f; };
+struct TravCounters { uint32_t steps, leaves, tris, wave_iters; int alu_dup = 0, mem_dup = 0; float sink = 0.0f;
+                      uint32_t empty = 0, stale = 0; };     // 8-wide layout: node visits in which no child was hit / whose own grid box already lay beyond the best hit
 
 // Stackless traversal of the rope layout (scene_device.h).  State per ray: the next node, the pending
 // triangle range of the current leaf and the best hit — no stack, no parent walk.  Closest hit =

@@ -33,6 +33,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_FLAT_HITS
 #define MRT_WIDE_FLAT_HITS 1   // hit children recorded without an inner node/leaf branch: +0.8 % / +1.8 %
 #endif
+#ifndef MRT_WIDE_SCALED
+#define MRT_WIDE_SCALED 1   // stream kernels: box distances in units of the ray's limit, interval ends from the clamp modifier (wide_node_test<true>)
+#endif
 #ifndef MRT_COOP_MODE
 #define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
 #endif
@@ -57,11 +60,24 @@ MRT_DEV void wstack_pop(const uint32_t *stack, uint32_t sp, uint32_t lane, uint3
 // (so that ffs walks them front to back), tri_hits = bit k per packet tri_base + k of the leaf children hit.
 // Plane distance t = q * (2^e * idir) + (p - o) * idir, one fma per plane; the decode error of the fused evaluation is far
 // below the build-time padding of the leaf boxes, and the far side is widened by 4 ulp (Ize 2013).
+//
+// SCALED (the stream kernels; tmin = 0): the distances are computed in units of the ray's current limit — 1/d is multiplied by S = 1 / (tmax * (1 + 4 ulp)),
+// limits clamped to [1e-6, 1e30] so that S stays finite for tmax = 0 and for tmax = inf — and the two ends of the ray's interval come from the
+// free `clamp` output modifier ([0, 1]) instead of a v_max with 0 and a v_min with tmax per child (half-rate instructions):
+//   near = max3(nx, ny, clamp(nz)) >= 0,   far = clamp(min3(fx, fy, fz) * (1 + 4 ulp)) <= 1,   hit <=> near < far.
+// The comparison is strict because both ends clamp to the same value when the box lies behind the origin (far = 0 = near) or beyond the
+// limit (near >= 1 = far); for a box that the exact test accepts the widened far side is strictly beyond the near side.  Per node this costs
+// v_med3 + v_mul + v_rcp + 3 v_mul and saves 8 x (v_max + v_min).
+template <bool SCALED = false>
 MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4, const f3 o,
-                            const float ix, const float iy, const float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
+                            float ix, float iy, float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
                             const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
     const uint32_t ew = __float_as_uint(n0.w);
     const uint32_t imask = ew >> 24;
+    if (SCALED) {
+        const float S = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(tmax, 1e-6f, 1e30f) * 1.0000005f);
+        ix *= S; iy *= S; iz *= S;
+    }
     // 2^e * idir: sign-extended exponent byte (v_bfe_i32) + v_ldexp_f32 — two instructions per axis instead of shift, mask, multiply
     const float ax = __builtin_ldexpf(ix, (int)(int8_t)(ew & 0xFFu)), ay = __builtin_ldexpf(iy, (int)(int8_t)((ew >> 8) & 0xFFu)), az = __builtin_ldexpf(iz, (int)(int8_t)((ew >> 16) & 0xFFu));
     const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
@@ -84,12 +100,20 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
         const float tn = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, tmin));
         const float tf = fminf(fminf(fminf(px.y, py.y), pz.y) * 1.0000005f, tmax);
 #else
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
-                               fmaxf(__builtin_fmaf(ubyte_f(nrz[w], k), az, bz), tmin));
-        const float tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
-                                     __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, tmax);
+        float tn, tf;
+        if (SCALED) {
+            tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
+                       __builtin_amdgcn_fmed3f(__builtin_fmaf(ubyte_f(nrz[w], k), az, bz), 0.0f, 1.0f));
+            tf = __builtin_amdgcn_fmed3f(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
+                                               __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, 0.0f, 1.0f);
+        } else {
+            tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
+                       fmaxf(__builtin_fmaf(ubyte_f(nrz[w], k), az, bz), tmin));
+            tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
+                             __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, tmax);
+        }
 #endif
-        if (tn <= tf) {
+        if (SCALED ? tn < tf : tn <= tf) {
 #if MRT_WIDE_FLAT_HITS      // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
             nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
             th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
@@ -149,6 +173,16 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, tmin, h.t, node_hits, tri_hits);
             if (STATS && tri_hits) tc->leaves++;
+            if (STATS) {
+                if ((node_hits | tri_hits) == 0u) tc->empty++;
+                // the node's own box (its quantisation grid, p .. p + 255 * 2^e, which encloses every child) against the ray's current limit: a visit that a
+                // distance kept with the stack entry would have skipped
+                const uint32_t ew = __float_as_uint(n0.w);
+                const float gx = __builtin_ldexpf(255.0f, (int)(int8_t)(ew & 0xFFu)), gy = __builtin_ldexpf(255.0f, (int)(int8_t)((ew >> 8) & 0xFFu)), gz = __builtin_ldexpf(255.0f, (int)(int8_t)((ew >> 16) & 0xFFu));
+                const float x0 = (n0.x - o.x) * ix, x1 = (n0.x + gx - o.x) * ix, y0 = (n0.y - o.y) * iy, y1 = (n0.y + gy - o.y) * iy, z0 = (n0.z - o.z) * iz, z1 = (n0.z + gz - o.z) * iz;
+                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+                if (tn > h.t) tc->stale++;
+            }
             if ((g_mask >> 8) != 0) { wstack_push(stack, sp, lane, g_base, g_mask); sp++; }     // siblings still to visit
             g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
@@ -459,7 +493,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
-            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
             uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16;
             const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit

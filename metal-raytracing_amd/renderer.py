@@ -158,6 +158,27 @@ class Renderer:
     def set_camera(self, camera: Camera):
         check(lib.mrt_renderer_set_camera(self.handle, C.byref(camera)))
 
+    # -- Renderer.uniforms / updateUniforms (Renderer.swift:216-229): size, frameIndex, lightCount and camera in one 96-byte block
+    @property
+    def uniforms(self):
+        from ._ffi import Uniforms
+        u = Uniforms()
+        check(lib.mrt_renderer_get_uniforms(self.handle, C.byref(u)))
+        return u
+
+    @uniforms.setter
+    def uniforms(self, u):
+        check(lib.mrt_renderer_set_uniforms(self.handle, C.byref(u)))
+        self.size = (int(u.width), int(u.height))
+
+    @property
+    def framesCompleted(self):
+        """Frames whose accumulation has finished on the device (never blocks) — the poll form of the completion handler of
+        Renderer.swift:285-287."""
+        v = C.c_uint64()
+        check(lib.mrt_renderer_frames_completed(self.handle, C.byref(v)))
+        return v.value
+
     def set_option(self, key, value):
         check(lib.mrt_renderer_set_option(self.handle, key.encode(), float(value)))
 
@@ -225,6 +246,124 @@ class Renderer:
         self.device_scene.close()
         if self._own_ctx:
             self.ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class _TemplateScene(DeviceScene):
+    """A scene that is filled (meshes, lights, options) but not committed: the template a device group replicates."""
+
+    def __init__(self, ctx_handle, scene, options=None):
+        self.ctx = None
+        self.handle = C.c_void_p()
+        check(lib.mrt_scene_create(ctx_handle, C.byref(self.handle)))
+        for k, v in (options or {}).items():
+            check(lib.mrt_scene_set_option(self.handle, k.encode(), float(v)))
+        from .scene import flatten_scene
+        for pos, nrm, xf, subs, source in flatten_scene(scene, share=True):
+            mid = C.c_int32()
+            if source >= 0:
+                check(lib.mrt_scene_add_instance(self.handle, source, ptr(xf), C.byref(mid)))
+                continue
+            pos = np.ascontiguousarray(pos, np.float32)
+            nrm = np.ascontiguousarray(nrm, np.float32)
+            check(lib.mrt_scene_add_mesh(self.handle, ptr(pos), 12, ptr(nrm), 12, pos.shape[0], ptr(xf), C.byref(mid)))
+            for idx, mat in subs:
+                idx = np.ascontiguousarray(idx, np.uint32)
+                check(lib.mrt_mesh_add_submesh(self.handle, mid.value, ptr(idx), idx.shape[0], C.byref(mat), None))
+        self.set_lights(scene.lights)
+
+
+class GroupRenderer:
+    """Renderer over the n GPUs of one node in ONE process (mrt_group_*): the scene is replicated, the image sharded by 8x8 screen tile
+    (tile_id % n == rank), `gather()` runs the one reduce(sum) per output image (RCCL over xGMI; peer copies + add when a device is
+    named twice).  The reference creates a single MTLDevice (Renderer.swift:46-59); this widens that seam."""
+
+    def __init__(self, size, scene, devices, seed=1, max_bounces=3, scene_options=None):
+        self.size = (int(size[0]), int(size[1]))
+        self.scene = scene
+        ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        self.group = C.c_void_p()
+        check(lib.mrt_group_create(ids, len(devices), C.byref(self.group)))
+        self.handle = C.c_void_p()
+        self._template = None
+        try:
+            c0 = C.c_void_p()
+            check(lib.mrt_group_context(self.group, 0, C.byref(c0)))
+            self._template = _TemplateScene(c0, scene, scene_options)
+            check(lib.mrt_group_renderer_create(self.group, self._template.handle, self.size[0], self.size[1], int(seed), int(max_bounces), C.byref(self.handle)))
+            check(lib.mrt_group_set_camera(self.handle, C.byref(scene.camera)))
+        except Exception:
+            self.close()
+            raise
+
+    @property
+    def world(self):
+        n = C.c_int32()
+        check(lib.mrt_group_size(self.group, C.byref(n)))
+        return n.value
+
+    @property
+    def reduce_mode(self):
+        m = C.c_int32(); buf = C.create_string_buffer(256)
+        check(lib.mrt_group_reduce_mode(self.group, C.byref(m), buf, 256))
+        return m.value, buf.value.decode()
+
+    def set_reduce_mode(self, mode):
+        check(lib.mrt_group_set_reduce_mode(self.group, int(mode)))
+
+    def set_option(self, key, value):
+        check(lib.mrt_group_set_option(self.handle, key.encode(), float(value)))
+
+    def rank_option(self, rank, key):
+        r = C.c_void_p(); v = C.c_double()
+        check(lib.mrt_group_renderer_rank(self.handle, int(rank), C.byref(r)))
+        check(lib.mrt_renderer_get_option(r, key.encode(), C.byref(v)))
+        return v.value
+
+    def draw(self, frames=1, wait=False):
+        check(lib.mrt_group_render(self.handle, int(frames)))
+        if wait:
+            self.wait()
+
+    def wait(self):
+        check(lib.mrt_group_wait(self.handle))
+
+    @property
+    def framesCompleted(self):
+        v = C.c_uint64()
+        check(lib.mrt_group_frames_completed(self.handle, C.byref(v)))
+        return v.value
+
+    def gather(self, to_host=True):
+        """The assembled image: (h, w, 4) float32, row 0 = bottom (None with to_host=False: it stays on the root device)."""
+        if not to_host:
+            check(lib.mrt_group_gather(self.handle, None, 0))
+            return None
+        out = np.empty((self.size[1], self.size[0], 4), np.float32)
+        check(lib.mrt_group_gather(self.handle, ptr(out), out.nbytes))
+        return out
+
+    @property
+    def stats(self):
+        s = RenderStats()
+        check(lib.mrt_group_stats(self.handle, C.byref(s)))
+        return s
+
+    def close(self):
+        if self.handle:
+            lib.mrt_group_renderer_destroy(self.handle)
+            self.handle = C.c_void_p()
+        if self._template is not None:
+            self._template.close()
+            self._template = None
+        if self.group:
+            lib.mrt_group_destroy(self.group)
+            self.group = C.c_void_p()
 
     def __enter__(self):
         return self

@@ -61,3 +61,19 @@ def test_cpp_mirror_two_level_matches_python_two_level(mrt, gpu_ctx):
     checksum = float(np.sum(acc[..., 0].astype(np.float64) + acc[..., 1].astype(np.float64) + acc[..., 2].astype(np.float64)))
     assert abs(float(m.group(6)) - checksum) <= 1e-6 * max(1.0, abs(checksum))
     r.close()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_group_renderer_matches_single_device(mrt, gpu_ctx):
+    """mrt::GroupRenderer (mrt_group_*) over a group that names device 0 twice == mrt::Renderer on that device."""
+    _build()
+    w, h, frames = 160, 90, 5
+    one = subprocess.run([EXE, str(w), str(h), str(frames)], capture_output=True, text=True, cwd=ROOT)
+    grp = subprocess.run([EXE, str(w), str(h), str(frames), "-", "0", "0,0"], capture_output=True, text=True, cwd=ROOT)
+    assert one.returncode == 0 and grp.returncode == 0, one.stderr + grp.stderr
+    a = re.search(r"closest=(\d+) shadow=(\d+) ms=\S+ checksum=(\S+)", one.stdout)
+    b = re.search(r"group=2 frames=(\d+) completed=(\d+) closest=(\d+) shadow=(\d+) checksum=(\S+) reduce=\"(.*)\"", grp.stdout)
+    assert a and b, one.stdout + grp.stdout
+    assert int(b.group(1)) == frames and int(b.group(2)) == frames
+    assert (a.group(1), a.group(2), a.group(3)) == (b.group(3), b.group(4), b.group(5))     # same rays, same image (the checksum is printed from the same doubles)
+    assert "peer copies" in b.group(6)

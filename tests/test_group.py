@@ -1,0 +1,64 @@
+"""Device group (mrt_group_*, include/mrt_abi.h): one process, n devices, replicated scene, tile_id % n shards, ONE reduce(sum) per output
+image.  The GPU box has one GPU, so n > 1 groups name device 0 several times: everything but the ncclReduce call itself runs (RCCL refuses
+duplicate devices; such a group assembles with peer copies + add, which is also selectable on a real multi-GPU group)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plain(mrt, ctx, sc, w, h, frames, bounces=3):
+    r = mrt.Renderer((w, h), sc, ctx=ctx, max_bounces=bounces)
+    r.draw(frames, wait=True)
+    a, st = r.accumulation(), r.stats
+    r.close()
+    return a, st
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_group_image_is_bit_identical_to_one_device(mrt, orc, gpu_ctx, n):
+    from test_gpu_parity import assert_parity, oracle_render
+    w, h, frames = 200, 120, 6
+    sc = mrt.CornellScene((w, h))
+    ref, st = _plain(mrt, gpu_ctx, sc, w, h, frames)
+    with mrt.GroupRenderer((w, h), sc, [0] * n) as g:
+        assert g.world == n
+        mode, note = g.reduce_mode
+        assert mode == 1 and (("one device" in note) if n == 1 else ("more than once" in note))
+        assert g.rank_option(0, "frame_batch") == min(32, 4 * n)
+        g.draw(frames)
+        img = g.gather()
+        assert g.framesCompleted == frames
+        gs = g.stats
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert (gs.closest_rays, gs.shadow_rays, gs.primary_rays, gs.frames) == (st.closest_rays, st.shadow_rays, st.primary_rays, frames)
+    oimg, _ = oracle_render(orc, mrt, sc, w, h, frames)
+    assert_parity(img, oimg, exact_frac=1.0)
+
+
+def test_group_accumulates_across_calls_and_options_reach_every_rank(mrt, gpu_ctx):
+    w, h = 96, 64
+    sc = mrt.SCENES["dragon_small"]((w, h)) if "dragon_small" in mrt.SCENES else mrt.CornellScene((w, h))
+    ref, _ = _plain(mrt, gpu_ctx, sc, w, h, 5, bounces=4)
+    with mrt.GroupRenderer((w, h), sc, [0, 0], max_bounces=4) as g:
+        g.set_option("frames_in_flight", 3)
+        assert g.rank_option(1, "frames_in_flight") == 3
+        g.draw(2); g.draw(3)
+        a = g.gather()
+        b = g.gather()                       # gathering twice does not change the image
+        g.gather(to_host=False)
+    assert np.array_equal(a, ref) and np.array_equal(a, b)
+
+
+def test_group_rejects_bad_arguments(mrt):
+    import ctypes as C
+    from metal_raytracing_amd._ffi import lib
+    g = C.c_void_p()
+    assert lib.mrt_group_create(None, 1, C.byref(g)) != 0
+    ids = (C.c_int32 * 1)(99)
+    assert lib.mrt_group_create(ids, 1, C.byref(g)) != 0 and not g
+    ids = (C.c_int32 * 1)(0)
+    assert lib.mrt_group_create(ids, 0, C.byref(g)) != 0
+    assert lib.mrt_group_create(ids, 1, C.byref(g)) == 0
+    assert lib.mrt_group_set_reduce_mode(g, 7) != 0
+    assert lib.mrt_group_destroy(g) == 0

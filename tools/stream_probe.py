@@ -6,7 +6,10 @@ import numpy as np
 import metal_raytracing_amd as m
 from trav_stats import primary_rays
 w, h = 1920, 1080
-sc = m.DragonScene((w, h)); ctx = m.Context(0); ds = m.DeviceScene(ctx, sc)
+import json
+opts = json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}
+print("scene options", opts)
+sc = m.DragonScene((w, h)); ctx = m.Context(0); ds = m.DeviceScene(ctx, sc, opts)
 rays = primary_rays(w, h)
 hit = ds.intersect_closest(rays); ok = hit["type"] == 1
 P = rays[ok, 0:3] + rays[ok, 4:7] * hit["distance"][ok, None]
@@ -18,7 +21,7 @@ L = np.array([0, 1.98, 0], np.float32) + rng.uniform(-0.25, 0.25, (n, 3)).astype
 dl = L - r2[:, 0:3]; dist = np.linalg.norm(dl, axis=1); dl /= dist[:, None]
 r3 = r2.copy(); r3[:, 4:7] = dl; r3[:, 7] = dist - 1e-3
 for name, rr, anyh in (("primary", rays, False), ("diffuse", r2, False), ("shadow", r3, True)):
-    for pw in (64, 256, 1024):
+    for pw in (256,):
         st = ds.stream_stats(rr, any_hit=anyh, per_wave=pw).astype(np.float64)
         it, live, node, tri, rf, rfl = (st[:, k].sum() for k in range(6))
         print(f"{name:8s} per_wave={pw:5d}: wave-iterations {it:9.0f} ({it*64/len(rr):6.1f} lane-slots/ray)  live {live/it/64*100:5.1f}%  node lanes {node/it/64*100:5.1f}%  tri lanes {tri/it/64*100:5.1f}%  refills/wave {rf/len(st):5.1f}  lanes/refill {rfl/max(rf,1):5.1f}", flush=True)
