@@ -73,6 +73,17 @@ def parse():
     return ap.parse_args()
 
 
+def csrc_hash():
+    """sha256 over the library's sources (metal-raytracing_amd/csrc/*.{hip,h,cpp}, Makefile): tools/summarize_profiles.py stores it with the counters
+    it summarises, and the counter-derived fields of the bench line are emitted only when the running tree has the same hash."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "metal-raytracing_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def committed_profile():
     """Per-dispatch HBM bytes of the dominant kernel and VALU instructions per frame from the rocprofv3 PMC passes kept under
     profiles/ (tools/collect_profiles.sh; FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
@@ -91,12 +102,13 @@ def committed_profile():
 
 def cpu_baseline(mrt, scene, w, h, bounces, threads):
     """The oracle (CPU restatement, kind 'port') on the GPU box's host cores: one full frame of the
-    same workload, same seeds.  Reported, never the thing shipped.  (SURVEY §8(d) asks for -O3 -march=native on all cores;
-    the oracle is built -O2 -march=x86-64-v3 so that one binary runs on every box, and uses min(nproc, 16) threads — the GPU
-    box's CPU share for one GPU.  It is the stated non-target baseline; nothing rides on the ratio.)"""
+    same workload, same seeds.  Reported, never the thing shipped.  SURVEY §8(d): built here, on this box, with -O3 -march=native
+    (oracle/Makefile target `native`; no fast-math, no contraction: the same bits as the portable build the tests use) and run on
+    all host cores.  It is the stated non-target baseline; nothing rides on the ratio."""
+    os.environ["MRT_ORACLE_NATIVE"] = "1"        # the timing leg uses the -O3 -march=native build (SURVEY §8(d)); the tests keep the portable one
     import oracle as O
-    O.build_oracle()
-    threads = threads or min(os.cpu_count() or 1, 16)
+    O.build_oracle(force=True)                     # always rebuilt HERE: -march=native is only valid on the machine that compiled it
+    threads = threads or (os.cpu_count() or 1)     # all host cores of the box
     osc = O.OracleScene(mrt.flatten_scene(scene), scene.lights)
     r = O.OracleRenderer(osc, w, h, seed=1, max_bounces=bounces, camera=scene.camera)
     t0 = time.perf_counter()
@@ -104,7 +116,7 @@ def cpu_baseline(mrt, scene, w, h, bounces, threads):
     dt = time.perf_counter() - t0
     closest, shadow = r.counters()
     img = r.accumulation()
-    return {"value": (closest + shadow) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": (closest + shadow) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "build": O.ORACLE_BUILD,
             "sample": f"1 full frame of the same workload ({w}x{h} spp=1, {bounces} bounces, {closest + shadow} rays) in {dt:.2f} s",
             "ms_per_frame": dt * 1e3}, img
 
@@ -126,6 +138,17 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames,
            "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU",
            "kernel_ms_serialised": {k: round(statistics.median(v), 4) for k, v in per_kernel.items()}}
+    # the default pass size alone on the GPU: one stream, 4-frame passes (the regime in which the dominant kernel's standalone duration is
+    # consistent with ms_per_step; profiles/r03_kernel_stats_serial4.csv is rocprofv3's view of the same regime)
+    q.set_option("frame_batch", 4); q.draw(8, wait=True)
+    four = {}
+    for _ in range(6):
+        q.draw(4, wait=True)
+        for k, (ms, n) in q.kernel_times.items():
+            if n:
+                four.setdefault(k, []).append(ms / n)
+    out["kernel_ms_serialised_four_frame_pass"] = {k: round(statistics.median(v), 4) for k, v in four.items()}
+    q.set_option("frame_batch", 1); q.draw(2, wait=True)
     # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
     q.set_option("megakernel", 1); q.draw(3, wait=True)
     mk = []
@@ -229,6 +252,22 @@ def main():
         frame_bytes = st.bytes_alg / max(1, st.frames)
         frame_gbs = frame_bytes * st.frames / dt / 1e9
         prof = committed_profile()
+        default_opts = not a.opt and not a.sopt and a.builder is None and a.frames_in_flight is None
+        single_dragon = world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3)
+        # counters under profiles/ describe ONE configuration (dragon 1080p, default options, one GPU) of ONE source tree: anything else gets null
+        prof_applies = bool(prof) and single_dragon and default_opts and prof.get("csrc_sha256") == csrc_hash()
+        prof_note = None if prof_applies else ("no committed profile" if not prof else "committed counters not shown: " + ("they were collected on a different source tree (csrc hash differs; rerun tools/collect_profiles.sh)" if single_dragon and default_opts else "they describe dragon 1920x1080, 3 bounces, default options, one GPU — not this run"))
+        two_level = bool(r.device_scene.stats.instances) and any(kv.startswith("instancing=1") for kv in a.sopt)
+        if not fused:
+            kernel_label = "k_extend (rope, one launch per bounce)"
+        elif r.get_option("wide_bounce") == 0:
+            kernel_label = "k_trace_mixed (rope layout, bounce + shadow traversal)"
+        elif r.get_option("wide_stream") == 0 and not two_level:
+            kernel_label = "k_trace_mixed_wide (8-wide layout, one ray per lane)"
+        else:
+            pers = int(r.get_option("persistent"))
+            pulls = pers == 1 or (pers == 2 and 2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 1024)
+            kernel_label = ("k_trace_mixed_wide_persist" if pulls else "k_trace_mixed_wide_stream") + ("<two-level>" if two_level else "") + " (bounce + shadow traversal)"
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -237,21 +276,24 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene {w}x{h} spp=1, {a.bounces} bounces, closest-hit + shadow rays counted on device",
                        "scene_sources": scene.describe(), "triangles": int(sst.triangles), "bvh_nodes": int(sst.bvh_nodes),
-                       "bvh_build_ms": round(sst.build_ms, 3), "sah_cost": round(sst.sah_cost, 3),
+                       "bvh_build_ms": round(sst.build_ms, 3), "bvh_build_mtris_per_s": round(sst.triangles / max(sst.build_ms, 1e-6) / 1e3, 1), "sah_cost": round(sst.sah_cost, 3),
                        "rays_per_frame": {"closest": closest / steps_total, "shadow": shadow / steps_total, "primary": primary / steps_total},
                        "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
-                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")), "persistent_traversal": int(r.get_option("persistent")),
+                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")), "lanes_used": int(r.get_option("lanes_used")),
+                       "lane_bytes": int(r.get_option("lane_bytes")), "persistent_traversal": int(r.get_option("persistent")),
                        "ms_per_step_is": "wall time of the timed region / steps with passes of frame_batch frames overlapped on frames_in_flight streams (inverse throughput); the per-frame device time is latency.ms_per_frame",
                        "device": r.ctx.device_name},
-            "roofline": {"bound": "hbm", "kernel": "k_trace_mixed_wide_persist (bounce + shadow traversal)" if fused else "k_extend",
+            "roofline": {"bound": "hbm", "kernel": kernel_label,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected"), "traffic_source": prof.get("_source"),
+                         "traffic": (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected") if prof_applies else None,
+                         "traffic_source": prof.get("_source") if prof_applies else None, "traffic_note": prof_note,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
                          "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY,
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n,
                          # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 12 streams x 4-frame passes) and of the serialised frame
-                         "avg_launch_ms_rocprof_driver_command": round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None,
-                         "avg_launch_ms_rocprof_serialised_one_frame": round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None,
+                         "avg_launch_ms_rocprof_driver_command": (round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
+                         "avg_launch_ms_rocprof_serialised_one_frame": (round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None) if prof_applies else None,
+                         "avg_launch_ms_rocprof_serialised_four_frames": (round((prof.get("kernel_avg_us_serial4") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
                          "avg_launch_ms_note": "kernel start/stop events of the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is the duration under overlap (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone; the serialised duration is latency.kernel_ms_serialised.trace",
                          "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
                          "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
@@ -263,7 +305,6 @@ def main():
             if world > 1:
                 r.write_accum_from(sr.buffer.data_ptr(), w * h * 16)      # show the assembled image, not this rank's shard
             mrt.save_png(a.png, r.tonemapped())
-        single_dragon = world == 1 and (a.scene, w, h, a.bounces) == ("dragon", 1920, 1080, 3)
         if world == 1 and not a.no_latency:
             # ceilings calibrated on this chip, now: v_fma_f32 issue rate with every SIMD full, divergent-gather rate from a table of the scene's size
             import ctypes as C
@@ -273,7 +314,7 @@ def main():
                                   "gather16_GBps_128MiB_table": round(cal[2] / 1e9, 1), "gather80_GBps_128MiB_table": round(cal[3] / 1e9, 1),
                                   "note": "only fp32 add/mul/fma and and/or/xor/mov/lshr issue at this rate on gfx950; min/max, conversions, compares, shifts left, bit-field and 24-bit integer ops take ~1.8x as long, rcp/sqrt 3.5x (tools/valu_rates.hip, profiles/r02_valu_rates.json)"}
             valu = prof.get("valu_wave_insts_per_frame")
-            if valu and single_dragon:
+            if valu and prof_applies:
                 rate = valu / (dt / a.steps)
                 out["valu_issue"] = {"wave_insts_per_frame": round(valu), "source": prof.get("_source"), "achieved_Ginst_per_s": round(rate / 1e9, 1),
                                      "peak_Ginst_per_s_calibrated_v_fma_f32": round(cal[0] / 1e9, 1), "frac": round(rate / cal[0], 4),
@@ -285,6 +326,14 @@ def main():
                                      "cycle_weighted_frac_at_fma_load_clock": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
         if world == 1 and not a.no_latency:
             out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
+            out["ms_per_frame"] = out["latency"]["ms_per_frame"]      # SURVEY §8(d)'s ms/frame (one frame alone on the GPU), next to ms_per_step (inverse throughput)
+            t4 = out["latency"]["kernel_ms_serialised_four_frame_pass"].get("trace")
+            if t4 and fused:
+                b4 = (BYTES_PER_CLOSEST_RAY * (closest - primary) + BYTES_PER_SHADOW_RAY * shadow) / steps_total * 4 / a.bounces
+                out["roofline"]["serialised_four_frame_launch"] = {"avg_launch_ms": t4, "algorithmic_bytes_per_launch": round(b4), "achieved": round(b4 / (t4 * 1e-3) / 1e9, 2),
+                                                                   "frac": round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                                                                   "kernel_time_per_frame_ms": round(t4 * a.bounces / 4, 4),
+                                                                   "note": "one stream, 4-frame passes: the dominant kernel alone at the default pass size; kernel_time_per_frame_ms <= ms_per_step is the consistency check"}
             # the dominant kernel ALONE: one-frame launches on one stream (the latency leg's own start/stop events), algorithmic bytes of one frame's
             # bounce + shadow rays spread over its max_bounces launches — the kernel-level figure that profiles/r02_kernel_stats_serial.csv reproduces
             t_ser = out["latency"]["kernel_ms_serialised"].get("trace")

@@ -325,6 +325,11 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
 int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, MRTIntersection *out);
 /* Diagnostics: fill of the 8-wide nodes: out12[c] = nodes with c children (c = 0..8), [9] internal children, [10] leaf children, [11] triangles. */
 int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
+/* The index validation mrt_scene_commit runs (scene option "validate", default 1): every child / packet / instance index of the committed
+ * 8-wide layout, the instance rows and the TLAS lies inside its array and children come after their parents; MRT_ERR_STATE + message
+ * otherwise.  mrt_debug_poke_wnode overwrites one 32-bit word (0..19) of one 8-wide node — for the validator's own test only.            */
+int mrt_debug_validate(MRTScene scene);
+int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t value, uint32_t *old_value);
 /* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of
  * `triangles` triangles whose BVH keeps `nodes` nodes (0 = unknown) cannot be addressed by the traversal layouts.      */
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes);

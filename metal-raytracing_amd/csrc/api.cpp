@@ -173,6 +173,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
     else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
     else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
@@ -436,6 +437,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "materials") { REQUIRE(value == 0 || (value == 1 && r->r.max_bounces <= 16), "materials must be 0 or 1 (and max_bounces <= 16: the lobe choice uses Halton dimension 2 + 5 * max_bounces + bounce < 100)"); r->r.materials = value != 0; }
     else if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
     else if (k == "primary_hint") r->r.primary_hint = value != 0;
+    else if (k == "halton_table") { REQUIRE(value == 0 || value == 1 || value == 2, "halton_table must be 0 (digit loops), 1 (table) or 2 (table for dimension 1 only)"); r->r.halton_table = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
@@ -462,6 +464,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "materials") *value = r->r.materials ? 1 : 0;
     else if (k == "persistent") *value = r->r.persistent;
     else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;
+    else if (k == "halton_table") *value = r->r.halton_table;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
@@ -578,6 +581,25 @@ int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12) {
     if (!scene->committed) { mrt::set_error("mrt_debug_wide_histogram: scene not committed"); return MRT_ERR_STATE; }
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::wide_histogram(scene->dev, scene->ctx->stream, out12);
+    MRT_CATCH
+}
+// the commit-time validator on demand, and a way for its test to break one word of one 8-wide node (tests/test_instancing.py)
+int mrt_debug_validate(MRTScene scene) {
+    MRT_TRY
+    REQUIRE(scene, "mrt_debug_validate: scene is NULL");
+    if (!scene->committed) { mrt::set_error("mrt_debug_validate: scene not committed"); return MRT_ERR_STATE; }
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    return mrt::validate_layout(scene->dev, scene->ctx->stream, false);
+    MRT_CATCH
+}
+int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t value, uint32_t *old_value) {
+    MRT_TRY
+    REQUIRE(scene && scene->committed && node < scene->dev.num_wnodes && word < 4 * mrt::WNODE_STRIDE, "mrt_debug_poke_wnode: bad argument");
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    uint32_t *p = reinterpret_cast<uint32_t *>(scene->dev.wnodes.p + (size_t)mrt::WNODE_STRIDE * node) + word;
+    if (old_value) MRT_HIP(hipMemcpy(old_value, p, 4, hipMemcpyDeviceToHost));
+    MRT_HIP(hipMemcpy(p, &value, 4, hipMemcpyHostToDevice));
+    return MRT_OK;
     MRT_CATCH
 }
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes) {

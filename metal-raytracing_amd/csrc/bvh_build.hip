@@ -673,6 +673,7 @@ SceneView DeviceScene::view() const {
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
+    v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / 3) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
     v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
@@ -724,12 +725,14 @@ void pack_material(const MRTMaterial &m, float4 *out3) {
 }
 
 int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+    out.validate = opt.validate != 0;
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
     out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
     // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
-    return build_flat(refs, opt, stream, out);
+    if (int rc = build_flat(refs, opt, stream, out)) return rc;
+    return out.validate ? validate_layout(out, stream, false) : MRT_OK;
 }
 
 // One world-space BVH over the given (geometry, transform) pairs: the whole flattened scene, or one BLAS (a single mesh under the identity).

@@ -42,6 +42,9 @@ struct Renderer {
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<uint32_t> hint;               // per pixel: the packet its primary ray hit last (k_trace_primary tests it first); 0xFFFFFFFF = none
     bool primary_hint = true;
+    DevBuf<float4> htab;                 // Halton table: 128-byte rows, one per Halton index the first 65 536 frames can reach (renderer.hip k_halton_table)
+    DevBuf<float> hprim;                 // halton_table = 2: dimension 1 only
+    int halton_table = 0;                // 0 = digit loops (default: measured fastest), 1 = full table, 2 = table for dimension 1 only
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)

@@ -42,7 +42,35 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // of the primary queue and sample buffer entries [s * npix, (s + 1) * npix); k_accumulate applies the sub-frames in order.
     uint32_t npix, capacity;
     int32_t batch;
+    // Halton table (renderer option halton_table): row i = every value a path of up to HTAB_BOUNCES bounces draws for Halton index i, or nullptr
+    // when this launch's indices / bounce are not covered (the kernels then run the digit loop of device_math.h)
+    const float4 *htab;
+    const float *hprim;          // halton_table = 2: only dimension 1 of the pixel jitter (base 3, 13 digits: the longest digit loop), one float per index (4.4 MB)
 };
+
+// The Halton values are a pure function of (index, dimension), the index is seed offset + frame < 2^20 + frames, and one frame evaluates ~22 M
+// of them with a digit loop of 100-400 issue cycles each (most of k_shade, a fifth of k_trace_primary): the table holds them
+// for every index the first HTAB_FRAMES frames can reach — 19 M values, fewer than ONE frame computes — one 128-byte row per index:
+//   float4 0: dims 0, 1 (pixel jitter, Raytracing.metal:202-203)       float4 2 + 2b, 3 + 2b: dims 2 + 5b .. 6 + 5b of bounce b < 3 (:272, :281-290, :384-385)
+// so that a hit reads ONE 32-byte segment instead of running five digit loops.  Same function, same floats: the image does not change.
+constexpr uint32_t HTAB_BOUNCES = 3, HTAB_ROW = 8, HTAB_FRAMES = 65536;
+constexpr uint32_t HTAB_ROWS = (1u << 20) + HTAB_FRAMES + 64;
+__global__ void k_halton_dim1(float *__restrict__ tab, uint32_t rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) tab[i] = halton_dev((int)i, 1);
+}
+__global__ void k_halton_table(float4 *__restrict__ tab, uint32_t rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float4 *row = tab + (size_t)HTAB_ROW * i;
+    row[0] = make_float4(halton_dev((int)i, 0), halton_dev((int)i, 1), 0.0f, 0.0f);
+    row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t b = 0; b < HTAB_BOUNCES; b++) {
+        const int d = 2 + 5 * (int)b;
+        row[2 + 2 * b] = make_float4(halton_dev((int)i, d), halton_dev((int)i, d + 1), halton_dev((int)i, d + 2), halton_dev((int)i, d + 3));
+        row[3 + 2 * b] = make_float4(halton_dev((int)i, d + 4), 0.0f, 0.0f, 0.0f);
+    }
+}
 
 constexpr uint32_t DEAD_PIXEL = 0xFFFFFFFFu;
 
@@ -68,7 +96,10 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     uint32_t offset = seeds[sub * fp.npix + pix];                        // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
-    float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
+    float r0, r1;                                                        // :202-203
+    if (fp.htab) { const float4 q = fp.htab[(size_t)HTAB_ROW * (uint32_t)idx]; r0 = q.x; r1 = q.y; }
+    else if (fp.hprim) { r0 = halton_dev(idx, 0); r1 = fp.hprim[(uint32_t)idx]; }
+    else { r0 = halton_dev(idx, 0); r1 = halton_dev(idx, 1); }
     float px = (float)x + r0, py = (float)y + r1;                        // :204
     float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
     uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
@@ -570,8 +601,8 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS>
-__global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+template <bool MATERIALS, bool TAB>      // TAB: the bounce's Halton values come from the table (fp.htab covers this launch); else the digit loops
+__global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
@@ -627,6 +658,10 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
         int idx = (int)(seeds[pix] + fp.sampleIndex);                  // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
+        // the five Halton values of this bounce: one 32-byte segment of the table row, or the digit loops (wave-uniform choice)
+        constexpr bool tab = TAB;
+        float4 hq = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float hq4 = 0.0f;
+        if (tab) { const float4 *__restrict__ row = fp.htab + (size_t)HTAB_ROW * (uint32_t)idx + 2 + 2 * fp.bounce; hq = row[0]; hq4 = row[1].x; }
         norg = P + nrm * 1e-3f;                                          // :350, :390
         color = mk3(C);
         bool diffuse = true;
@@ -667,7 +702,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
                 const float ud = trn > 0.0f ? (ul - trn) / (1.0f - trn) : ul;
                 const float ps = (ks > 0.0f && ns > 0.0f) ? ks / (ks + kd) : 0.0f;
                 if (ud < ps) {                                           // specular lobe
-                    const float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);
+                    const float hx = tab ? hq.w : halton_dev(idx, dim0 + 3), hy = tab ? hq4 : halton_dev(idx, dim0 + 4);
                     const float a2 = 2.0f / (ns + 2.0f);
                     const float ct2 = (1.0f - hy) / (1.0f + (a2 - 1.0f) * hy);
                     const float ct = __builtin_sqrtf(ct2), st = __builtin_sqrtf(1.0f - ct2);
@@ -686,13 +721,13 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
             }
         }
         if (diffuse) {
-        float ls = halton_dev(idx, dim0 + 0);                            // :272
+        float ls = tab ? hq.x : halton_dev(idx, dim0 + 0);               // :272
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
         const LightDev L = s.lights[li];
         int ltype = __float_as_int(L.position.w);
         if (ltype == MRTLightTypeAreaLight) {                            // :281-290, :94-128
-            float ax = halton_dev(idx, dim0 + 1) * 2.0f - 1.0f;
-            float ay = halton_dev(idx, dim0 + 2) * 2.0f - 1.0f;
+            float ax = (tab ? hq.y : halton_dev(idx, dim0 + 1)) * 2.0f - 1.0f;
+            float ay = (tab ? hq.z : halton_dev(idx, dim0 + 2)) * 2.0f - 1.0f;
             f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
             ldir = sp - P;
             ldist = length3(ldir);
@@ -725,7 +760,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(SceneView s, FrameParam
         want_shadow = length3(lcol) > 0.0001f;                           // :341
         want_next = fp.bounce + 1 < fp.max_bounces;
         if (want_next) {
-            float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
+            float hx = tab ? hq.w : halton_dev(idx, dim0 + 3), hy = tab ? hq4 : halton_dev(idx, dim0 + 4);   // :384-385
             ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
         }
         }
@@ -1126,6 +1161,19 @@ int Renderer::render(int n_frames) {                                   // Render
     const bool mega = megakernel && !two_level && !materials && !wide && sv.num_wnodes > 0;
     const int batch_max = mega ? 1 : ((fused || two_level || materials) && !wide) ? alloc_batch : 1;
     fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
+    fp.htab = nullptr; fp.hprim = nullptr;
+    if (halton_table == 2 && !hprim.p) {
+        MRT_HIP(hprim.alloc(HTAB_ROWS));
+        hipLaunchKernelGGL(k_halton_dim1, dim3(cdiv(HTAB_ROWS, 256)), dim3(256), 0, stream, hprim.p, HTAB_ROWS);
+        MRT_HIP(hipEventRecord(ev_fork, stream));
+        for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
+    }
+    if (halton_table == 1 && !htab.p) {                                      // built once per renderer: fewer Halton values than one frame evaluates
+        MRT_HIP(htab.alloc((size_t)HTAB_ROW * HTAB_ROWS));
+        hipLaunchKernelGGL(k_halton_table, dim3(cdiv(HTAB_ROWS, 256)), dim3(256), 0, stream, htab.p, HTAB_ROWS);
+        MRT_HIP(hipEventRecord(ev_fork, stream));
+        for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
+    }
     hipEvent_t last_acc = nullptr;
     int pass = 0;
     for (int f = 0; f < n_frames; pass++) {
@@ -1137,6 +1185,11 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
+        // the table covers this pass when its largest Halton index — seed offset (< 2^20) + sub-frame + sample index — is a row of it
+        const bool covered = (uint64_t)fp.sampleIndex + (uint64_t)B + (1ull << 20) <= (uint64_t)HTAB_ROWS;
+        const float4 *const htab_pass = (halton_table == 1 && htab.p && covered) ? htab.p : nullptr;
+        fp.htab = htab_pass;
+        fp.hprim = (halton_table == 2 && hprim.p && covered) ? hprim.p : nullptr;
         if (mega) {
             // one launch per frame on the pass's stream; frames are sequential (a path's last act is the running average with the previous target)
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
@@ -1190,14 +1243,14 @@ int Renderer::render(int n_frames) {                                   // Render
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
+                fp.htab = (uint32_t)b < HTAB_BOUNCES ? htab_pass : nullptr;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                if (materials) launch_timed(timed(MRT_KERNEL_SHADE), k_shade<true>, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
-                else launch_timed(timed(MRT_KERNEL_SHADE), k_shade<false>, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                                   L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
+                auto shade_kernel = materials ? (fp.htab ? k_shade<true, true> : k_shade<true, false>) : (fp.htab ? k_shade<false, true> : k_shade<false, false>);
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
@@ -1238,12 +1291,13 @@ int Renderer::render(int n_frames) {                                   // Render
             int q = 0;
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
+                fp.htab = (uint32_t)b < HTAB_BOUNCES ? htab_pass : nullptr;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
                 EvPair *ev = nullptr;
                 if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
                 if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                hipLaunchKernelGGL(k_shade<false>, dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
+                hipLaunchKernelGGL((fp.htab ? k_shade<false, true> : k_shade<false, false>), dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                    L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
@@ -1271,8 +1325,25 @@ int Renderer::render(int n_frames) {                                   // Render
     return MRT_OK;
 }
 
+#ifdef MRT_DEBUG_BOUNDS
+static int check_bounds_record() {
+    uint32_t v = 0;
+    MRT_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bounds_violation), 4));
+    if (v) {
+        static const char *kinds[] = {"?", "8-wide node", "triangle packet", "wtlas_index slot", "instance id"};
+        const uint32_t zero = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bounds_violation), &zero, 4);
+        set_error(std::string("MRT_DEBUG_BOUNDS: the stream traversal followed an index outside its array: ") + kinds[std::min(v >> 28, 4u)] + " " + std::to_string(v & 0x0FFFFFFFu));
+        return MRT_ERR_STATE;
+    }
+    return MRT_OK;
+}
+#else
+static int check_bounds_record() { return MRT_OK; }
+#endif
+
 int Renderer::wait() {
     MRT_HIP(hipStreamSynchronize(stream));
+    if (int rc = check_bounds_record()) return rc;
     { uint64_t done = 0; if (int rc = poll_completed(&done)) return rc; }
     if (pending_timing) {
         float ms = 0;
@@ -1406,7 +1477,7 @@ int query_stream(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, 
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * sizeof(MRTIntersection), hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
-    return MRT_OK;
+    return check_bounds_record();
 }
 
 int probe_halton(hipStream_t stream, const int32_t *i, const int32_t *d, size_t n, float *out) {

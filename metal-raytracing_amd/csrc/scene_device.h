@@ -95,6 +95,7 @@ struct SceneView {           // passed by value to kernels
     const float4 *bnodes;        // rope nodes of all BLASes, 4 x float4 each; followed, in the same allocation, by
     const float4 *bpackets;      // their triangle packets (object space), 3 x float4 each
     uint32_t num_inst;
+    uint32_t num_wpackets, num_wtlas;   // entries of wpackets / wtlas_index (the -DMRT_DEBUG_BOUNDS build checks every index against these)
     uint32_t num_wnodes;
     uint32_t num_nodes;
     uint32_t num_tris;
@@ -136,6 +137,7 @@ struct BuildOptions {
     int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
     int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
     float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
+    int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
                               // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS
 };
@@ -158,6 +160,7 @@ struct DeviceScene {
     std::vector<InstanceDev> h_inst;                           // host copy: transform updates rewrite the rows and rebuild the TLAS only
     std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each
     float tlas_ms = 0;                                         // host + upload time of the last TLAS build
+    bool validate = true, validated_blas = false;              // commit-time index validation (two_level.hip validate_layout); BLAS part already checked
     SceneView view() const;
 };
 
@@ -171,6 +174,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched
+int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only);      // every index of the 8-wide layout / instance rows inside its array; MRT_ERR_STATE + message otherwise
 int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out);
 
 }  // namespace mrt

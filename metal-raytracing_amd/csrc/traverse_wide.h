@@ -39,6 +39,16 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_COOP_MODE
 #define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
 #endif
+// -DMRT_DEBUG_BOUNDS (tools/build_variant.sh bounds "-DMRT_DEBUG_BOUNDS"): every node, packet and instance index the stream traversal is about
+// to follow is checked against its array; the first violation is recorded (kind << 28 | index) and the index replaced by 0, and the host
+// turns a non-zero record into MRT_ERR_STATE at the next wait (renderer.hip).  The release build has no such checks: the commit-time
+// validator (two_level.hip validate_layout) is what keeps bad indices out of the arrays.
+#ifdef MRT_DEBUG_BOUNDS
+__device__ uint32_t g_bounds_violation = 0;
+#define MRT_BOUND(idx, limit, kind) do { if ((idx) >= (limit)) { atomicMax(&g_bounds_violation, ((uint32_t)(kind) << 28) | min((uint32_t)(idx), 0x0FFFFFFFu)); (idx) = 0; } } while (0)
+#else
+#define MRT_BOUND(idx, limit, kind) do { } while (0)
+#endif
 // ((1 << width) - 1) << offset in one instruction (width, offset taken mod 32)
 MRT_DEV uint32_t bfm_b32(uint32_t width, uint32_t offset) { uint32_t r; asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(width), "v"(offset)); return r; }
 MRT_DEV float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // -> v_cvt_f32_ubyteK
@@ -399,7 +409,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             // into object space, and fetch the BLAS root in this same iteration
             const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
             t_mask &= t_mask - 1u;
-            const uint32_t id = s.wtlas_index[t_base + k];
+            uint32_t tl_slot = t_base + k;
+            MRT_BOUND(tl_slot, s.num_wtlas, 3);
+            uint32_t id = s.wtlas_index[tl_slot];
+            MRT_BOUND(id, s.num_inst, 4);
             const InstanceDev &I = s.inst[id];
             tl_pack = (t_base << 8) | t_mask;
             uint32_t sp = (g_mask >> 16) & 0xFFu;
@@ -438,6 +451,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         if (has_tri || helping) {
             if (has_tri) { tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u; t_mask = t_rest; }
             else tri_pk = help_pk;
+            MRT_BOUND(tri_pk, s.num_wpackets, 2);
             const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
         }
@@ -448,6 +462,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             n0 = pk[0]; n1 = pk[1]; n2 = pk[2];
         }
         if (want_node) {
+            MRT_BOUND(pending, s.num_wnodes, 1);
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
             n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }

@@ -244,6 +244,86 @@ __global__ void k_relocate_wide(float4 *__restrict__ wnodes, uint32_t n, uint32_
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Commit-time validation of the 8-wide layout (and, for two-level scenes, of the instance rows, the index arrays and the rope TLAS): every
+// index a traversal kernel will follow must lie inside its array, and every internal child must come after its parent (BFS numbering: no
+// cycles, so every walk ends).  A work-in-progress build of the two-level path once ended in "Memory access fault by GPU" at the first
+// query after a commit: an index outside its array is now refused HERE, with a message, instead of being dereferenced by a
+// kernel.  Cost: one download of the nodes checked (80 B each) and a host loop — about a millisecond per 100 K nodes, once per commit; a
+// TLAS-only update re-checks only the TLAS slots, the instance rows and the index arrays (microseconds).
+int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only) {
+    auto bad = [&](const std::string &what) { set_error("scene layout validation failed: " + what); return MRT_ERR_STATE; };
+    const bool two = sc.num_inst > 0;
+    const uint32_t NW = sc.num_wnodes;
+    const size_t packets = sc.wpackets.p ? sc.wpackets.n / 3 : 0;
+    std::vector<uint32_t> wtl, tl;
+    if (two) {
+        const size_t I = sc.num_inst;
+        if (sc.h_inst.size() != I) return bad("instance table size");
+        const size_t rope_nodes = sc.bpackets_offset / 4, rope_packets = sc.bnodes.n >= sc.bpackets_offset ? (sc.bnodes.n - sc.bpackets_offset) / 3 : 0;
+        for (size_t i = 0; i < I; i++) {
+            const InstanceDev &d = sc.h_inst[i];
+            const std::string who = "instance " + std::to_string(i);
+            if (d.ntri == 0) continue;
+            if ((size_t)d.node_base >= std::max<size_t>(rope_nodes, 1)) return bad(who + ": node_base outside bnodes");
+            if ((size_t)d.packet_base + d.ntri > rope_packets) return bad(who + ": packet range outside bpackets");
+            if ((size_t)d.ts_base + d.ntri > sc.tri_shade.n) return bad(who + ": shading records outside tri_shade");
+            if ((size_t)d.vbase >= sc.normals.n) return bad(who + ": vbase outside normals");
+            if (NW) {
+                if (d.ntri <= 8u) { if ((size_t)d.packet_base + d.ntri > packets) return bad(who + ": inlined packets outside wpackets"); }
+                else if (d.wroot < sc.tlas_wcap || d.wroot >= NW) return bad(who + ": wroot outside the BLAS part of wnodes");
+            }
+            for (int r = 0; r < 3; r++) { const float4 q = d.w2o[r]; if (!(std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z) && std::isfinite(q.w))) return bad(who + ": world->object row is not finite"); }
+        }
+        tl.resize(sc.tlas_index.n);
+        MRT_HIP(hipMemcpyAsync(tl.data(), sc.tlas_index.p, tl.size() * 4, hipMemcpyDeviceToHost, stream));
+        if (NW) { wtl.resize(sc.wtlas_index.n); MRT_HIP(hipMemcpyAsync(wtl.data(), sc.wtlas_index.p, wtl.size() * 4, hipMemcpyDeviceToHost, stream)); }
+        // rope TLAS (64-byte nodes: lo | a, hi | b, esc[8])
+        const size_t tn = sc.stats.bvh_nodes;
+        std::vector<float4> rn(4 * tn);
+        if (tn) MRT_HIP(hipMemcpyAsync(rn.data(), sc.nodes.p, rn.size() * 16, hipMemcpyDeviceToHost, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        // (index arrays are allocated with at least one element; entries past the live instances are never referenced by a node)
+        for (size_t k = 0; k < tn; k++) {
+            uint32_t a, b, esc[8]; memcpy(&a, &rn[4 * k].w, 4); memcpy(&b, &rn[4 * k + 1].w, 4); memcpy(esc, &rn[4 * k + 2], 32);
+            const std::string who = "TLAS rope node " + std::to_string(k);
+            if (a & NODE_LEAF) { const size_t first = a & 0x7FFFFFFFu; if (first + b > tl.size()) return bad(who + ": instance range outside tlas_index"); for (size_t j = first; j < first + b; j++) if (tl[j] >= I) return bad(who + ": instance id out of range"); }
+            else if (a >= tn || (b & NODE_INDEX_MASK) >= tn || a <= k || (b & NODE_INDEX_MASK) <= k) return bad(who + ": child index");
+            for (int o = 0; o < 8; o++) if (esc[o] != NODE_TERM && (esc[o] >= tn || esc[o] <= k)) return bad(who + ": escape link");
+        }
+    }
+    if (!NW) return MRT_OK;
+    if (WNODE_STRIDE != 5) return MRT_OK;
+    const uint32_t first = 0, last = (two && tlas_only) ? std::min(NW, sc.tlas_wcap) : NW;
+    std::vector<float4> wn(5 * (size_t)(last - first));
+    MRT_HIP(hipMemcpyAsync(wn.data(), sc.wnodes.p + 5 * (size_t)first, wn.size() * 16, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    for (uint32_t i = first; i < last; i++) {
+        uint32_t w0[4], w1[4]; memcpy(w0, &wn[5 * (size_t)(i - first)], 16); memcpy(w1, &wn[5 * (size_t)(i - first) + 1], 16);
+        const uint32_t imask = w0[3] >> 24, child_base = w1[0], tri_base = w1[1], meta[2] = {w1[2], w1[3]};
+        const bool in_tlas = two && i < sc.tlas_wcap;
+        const std::string who = std::string(in_tlas ? "8-wide TLAS node " : "8-wide node ") + std::to_string(i);
+        const uint32_t ninner = (uint32_t)__builtin_popcount(imask);
+        if (ninner) {
+            if (child_base <= i) return bad(who + ": children do not come after their parent");
+            const uint32_t lim = in_tlas ? std::min(NW, sc.tlas_wcap) : NW;
+            if ((uint64_t)child_base + ninner > lim) return bad(who + ": internal children outside " + (in_tlas ? "the TLAS slots" : "wnodes"));
+            if (two && !in_tlas && child_base < sc.tlas_wcap) return bad(who + ": a BLAS node points into the TLAS slots");
+        }
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t m = (meta[sl >> 2] >> (8 * (sl & 3))) & 0xFFu, cnt = m >> 5, off = m & 31u;
+            if (!cnt) continue;
+            if ((imask >> sl) & 1u) return bad(who + ": slot " + std::to_string(sl) + " is both an internal and a leaf child");
+            if (off + cnt > 32u) return bad(who + ": leaf range beyond the 32-bit triangle mask");
+            if (in_tlas) {
+                if ((size_t)tri_base + off + cnt > wtl.size()) return bad(who + ": instance slot outside wtlas_index");
+                for (uint32_t j = 0; j < cnt; j++) if (wtl[(size_t)tri_base + off + j] >= sc.num_inst) return bad(who + ": instance id out of range");
+            } else if ((size_t)tri_base + off + cnt > packets) return bad(who + ": triangle packets outside wpackets");
+        }
+    }
+    return MRT_OK;
+}
+
 // instance rows + TLAS from the current transforms; BLAS data (out.bnodes, tri_shade, normals ...) is left alone
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -291,6 +371,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
     out.stats.bvh_nodes = tb.nodes.size() / 4;          // TLAS nodes; the BLAS nodes are counted in scene_bytes
     out.stats.max_depth = tb.depth;
     out.tlas_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (out.validate) { if (int rc = validate_layout(out, stream, out.validated_blas)) return rc; out.validated_blas = true; }
     return MRT_OK;
 }
 
@@ -394,6 +475,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
     out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
+    out.validated_blas = false;            // the BLAS part of wnodes is new: update_tlas checks all of it this time
     return update_tlas(meshes, stream, out);
 }
 

@@ -11,13 +11,16 @@ import numpy as np
 
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(_REPO, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libmrt_oracle.so")
+# MRT_ORACLE_NATIVE=1 (set by bench.py's cpu_baseline leg before the import): the -O3 -march=native build, made on the box it runs on
+ORACLE_NATIVE = os.environ.get("MRT_ORACLE_NATIVE", "") == "1"
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libmrt_oracle_native.so" if ORACLE_NATIVE else "libmrt_oracle.so")
+ORACLE_BUILD = "-O3 -march=native" if ORACLE_NATIVE else "-O2 -march=x86-64-v3"
 
 
 def build_oracle(force=False):
     src = os.path.join(ORACLE_DIR, "mrt_oracle.cpp")
     if force or not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["native"] if ORACLE_NATIVE else []))
     return ORACLE_LIB
 
 

@@ -253,3 +253,26 @@ def test_flattened_instances_equal_separately_added_meshes(mrt, orc, gpu_ctx):
     ref = orc.OracleRenderer(flat, w, h, camera=sc.camera); ref.render(2)
     assert_parity(a.accumulation(), ref.accumulation(), exact_frac=1.0)
     a.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("instancing", [0, 1])
+def test_commit_validates_every_index_of_the_layout(mrt, gpu_ctx, instancing):
+    """mrt_scene_commit checks that every child / packet / instance index of the 8-wide layout lies inside its array (the class of error behind
+    a GPU memory fault seen once on a work-in-progress tree): a broken word is refused with a message, not dereferenced."""
+    import ctypes as C
+    from metal_raytracing_amd._ffi import lib
+    sc = _scene(mrt, (64, 48))
+    ds = mrt.DeviceScene(gpu_ctx, sc, {"instancing": instancing})
+    assert lib.mrt_debug_validate(ds.handle) == 0
+    old = C.c_uint32()
+    # word 4 = child_base, word 5 = tri_base of node 0: the flattened scene's root has internal children, the 6-instance TLAS root only leaf children
+    cases = [(0, 5, 0x7FFFFFF0, "outside")] if instancing else [(0, 4, 0x00FFFFF0, "outside"), (0, 4, 0, "after their parent")]
+    for node, word, value, what in cases:
+        assert lib.mrt_debug_poke_wnode(ds.handle, node, word, value, C.byref(old)) == 0
+        rc = lib.mrt_debug_validate(ds.handle)
+        msg = lib.mrt_last_error().decode()
+        assert lib.mrt_debug_poke_wnode(ds.handle, node, word, old.value, None) == 0
+        assert rc == 5 and "validation failed" in msg and what in msg, (rc, msg)
+    assert lib.mrt_debug_validate(ds.handle) == 0
+    ds.close()

@@ -13,8 +13,10 @@ def kname(n):
     return m.group(1) if m else n.split("(")[0]
 
 
-res = {"tag": tag}
-for mode in ("driver", "serial"):
+sys.path.insert(0, ROOT)
+import bench
+res = {"tag": tag, "csrc_sha256": bench.csrc_hash()}      # bench.py shows these counters only for the source tree they were collected on
+for mode in ("driver", "serial", "serial4"):
     ks = glob.glob(out + f"/trace_{mode}/**/*kernel_stats.csv", recursive=True)
     if not ks:
         continue
