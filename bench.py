@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_irregular", "cornell", "dragon4", "garden"])
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_irregular", "dragon_hostile", "cornell", "dragon4", "garden"])
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--shard", default="tile", choices=["tile", "sample"], help="N > 1: 8x8 screen-tile sharding (north_star, strong scaling, default) or sample-index sharding (weak scaling)")
     ap.add_argument("--builder", type=int, default=None)
@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg and the on-chip calibration")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
+    ap.add_argument("--group-devices", default=None, help="--gpus N without torch.distributed.run: device ids of the C-ABI device group (default 0..N-1; '0,0' rehearses N = 2 on a one-GPU box)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
     ap.add_argument("--dump-accum", default=None, help="write the assembled RGBA32F accumulation buffer (warm-up + timed frames) here as .npy (rank 0)")
     return ap.parse_args()
@@ -164,6 +165,48 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     return out
 
 
+def main_group(a):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run: one process drives the N GPUs through the C ABI's device group
+    (include/mrt_abi.h mrt_group_*: replicated scene, tile_id % N shards, ONE ncclReduce(sum) per output image, RCCL opened by the library).
+    The driver's launch (torch.distributed.run, one rank per GPU) takes the other path; both report the same metric."""
+    import metal_raytracing_amd as mrt
+    w, h = a.width, a.height
+    scene = mrt.SCENES[a.scene]((w, h))
+    opts = {} if a.builder is None else {"builder": a.builder}
+    for kv in a.sopt:
+        k, v = kv.split("="); opts[k] = float(v)
+    devices = [int(x) for x in a.group_devices.split(",")] if a.group_devices else list(range(a.gpus))
+    if len(devices) != a.gpus:
+        sys.exit("--group-devices must name --gpus devices")
+    g = mrt.GroupRenderer((w, h), scene, devices, seed=1, max_bounces=a.bounces, scene_options=opts)
+    for kv in a.opt:
+        k, v = kv.split("="); g.set_option(k, float(v))
+    if a.frames_in_flight is not None:
+        g.set_option("frames_in_flight", a.frames_in_flight)
+    g.draw(a.warmup); g.gather(to_host=False)              # warm-up: W untimed steps and one reduce (communicator set-up is not timed)
+    first = g.stats
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.draw(a.steps)                                         # enqueued on every device, returns at once
+    g.gather(to_host=False)                                 # waits for the frames, then the ONE reduce of the RGBA32F buffer into device 0
+    dt = time.perf_counter() - t0
+    st = g.stats
+    closest, shadow, primary = st.closest_rays - first.closest_rays, st.shadow_rays - first.shadow_rays, st.primary_rays - first.primary_rays
+    mode, note = g.reduce_mode
+    out = {"metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
+           "value": round((closest + shadow) / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{a.scene} scene {w}x{h} spp=1, {a.bounces} bounces, closest-hit + shadow rays counted on device", "scene_sources": scene.describe(),
+                      "launch": "one process, C-ABI device group (mrt_group_*)", "shard": "tile", "reduce": note, "reduce_mode": mode,
+                      "frame_batch": int(g.rank_option(0, "frame_batch")), "frames_in_flight": int(g.rank_option(0, "frames_in_flight")),
+                      "rays_per_frame": {"closest": closest / a.steps, "shadow": shadow / a.steps, "primary": primary / a.steps}},
+           "roofline": None, "cpu_baseline": None}
+    if a.dump_accum:
+        np.save(a.dump_accum, g.gather())
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,7 +226,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     elif a.gpus > 1:
-        sys.exit("launch with torch.distributed.run for --gpus > 1")
+        return main_group(a)             # one process, N devices: the C ABI's device group (mrt_group_*), no torch.distributed
 
     import metal_raytracing_amd as mrt
     from metal_raytracing_amd.distributed import ShardedRenderer

@@ -210,6 +210,7 @@ typedef struct MRTMeshData_ *MRTMeshData;
 int mrt_obj_load(const char *obj_path, MRTMeshData *out);
 int mrt_dragon_proxy(MRTMeshData *out);             /* exactly 871 414 triangles               */
 int mrt_dragon_proxy_irregular(MRTMeshData *out);   /* same count / extents / material, irregular connectivity, shuffled order (sensitivity check) */
+int mrt_dragon_proxy_hostile(MRTMeshData *out);     /* same count / extents / material; triangle sizes over 100 : 1 and 1 % slivers of up to 50 x their edge (stress test of the builder) */
 int mrt_bunny_proxy(MRTMeshData *out);              /* exactly  69 451 triangles               */
 int mrt_meshdata_free(MRTMeshData m);
 int mrt_meshdata_counts(MRTMeshData m, size_t *nverts, int32_t *nsubmeshes);

@@ -141,6 +141,7 @@ SIGNATURES = {
     "mrt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "mrt_dragon_proxy": (C.c_int, [C.POINTER(_P)]),
     "mrt_dragon_proxy_irregular": (C.c_int, [C.POINTER(_P)]),
+    "mrt_dragon_proxy_hostile": (C.c_int, [C.POINTER(_P)]),
     "mrt_bunny_proxy": (C.c_int, [C.POINTER(_P)]),
     "mrt_meshdata_free": (C.c_int, [_P]),
     "mrt_meshdata_counts": (C.c_int, [_P, C.POINTER(_SZ), _PI32]),

@@ -173,6 +173,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "presplit") { REQUIRE(value >= 0, "presplit must be >= 0 (0 = off; k: triangles longer than k x the mean extent are split into references)"); scene->opt.presplit = (float)value; }
     else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
     else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
@@ -301,6 +302,15 @@ int mrt_dragon_proxy_irregular(MRTMeshData *out) {
     REQUIRE(out, "mrt_dragon_proxy_irregular: out is NULL");
     std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
     mrt::make_dragon_proxy_irregular(m->m);
+    *out = m.release();
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_dragon_proxy_hostile(MRTMeshData *out) {
+    MRT_TRY
+    REQUIRE(out, "mrt_dragon_proxy_hostile: out is NULL");
+    std::unique_ptr<MRTMeshData_> m(new MRTMeshData_());
+    mrt::make_dragon_proxy_hostile(m->m);
     *out = m.release();
     return MRT_OK;
     MRT_CATCH

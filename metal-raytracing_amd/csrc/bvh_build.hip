@@ -94,6 +94,97 @@ __global__ void k_flatten(const SubRec *__restrict__ recs, int nrec, const float
     }
 }
 
+// ------------------------------------------------------------------ triangle pre-splitting (scene option presplit)
+// A triangle much longer than its neighbours (a sliver of a scanned mesh, a fin) has a box that overlaps hundreds of others: every ray through
+// that box pays a triangle test, and the agglomerative builder cannot separate what the boxes do not separate.  Early split clipping (Ernst &
+// Greiner 2007; Karras & Aila 2013 §4): such a triangle enters the build as k REFERENCES, one per slab of its box along its longest axis, each
+// with the bounds of the part of the triangle inside that slab.  A reference is a leaf like any other; its packet is the whole triangle, so a
+// ray may test a split triangle more than once and gets the same answer each time — the closest hit stays the minimum over (t, id), the image
+// does not change.  k = ceil(extent / (presplit x mean extent of all triangles)), at most 32; a uniformly tessellated mesh is not split at all.
+MRT_DEV float comp3(const f3 &v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+// deterministic mean: sum of (largest box extent / scene extent) in 2^-30 fixed point
+__global__ void k_extent_sum(const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi, const uint32_t *__restrict__ cbounds, uint32_t T, unsigned long long *__restrict__ sum) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (gid < T) {
+        const float4 lo = leaf_lo[gid], hi = leaf_hi[gid];
+        const float scene = fmaxf(fmaxf(ord2f(cbounds[3]) - ord2f(cbounds[0]), ord2f(cbounds[4]) - ord2f(cbounds[1])), ord2f(cbounds[5]) - ord2f(cbounds[2]));
+        const float e = fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
+        const float r = scene > 0.0f ? fminf(e / scene, 4.0f) : 0.0f;
+        v = (unsigned long long)(r * 1073741824.0f);
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+}
+MRT_DEV uint32_t split_pieces(float4 lo, float4 hi, float scene, unsigned long long sum, uint32_t T, float factor, uint32_t max_pieces, int &ax, float &ext) {
+    const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    ax = 0; ext = ex; if (ey > ext) { ext = ey; ax = 1; } if (ez > ext) { ext = ez; ax = 2; }
+    const float mean = (float)((double)sum / 1073741824.0 / (double)T) * scene;
+    if (!(mean > 0.0f) || !(ext > factor * mean)) return 1u;
+    const float k = ceilf(ext / (factor * mean));
+    return (uint32_t)fminf(fmaxf(k, 1.0f), (float)max_pieces);
+}
+__global__ void k_split_count(const float4 *__restrict__ tri_world, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi, const uint32_t *__restrict__ cbounds, uint32_t T,
+                              const unsigned long long *__restrict__ sum, float factor, uint32_t max_pieces, uint32_t *__restrict__ count) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= T) return;
+    const float scene = fmaxf(fmaxf(ord2f(cbounds[3]) - ord2f(cbounds[0]), ord2f(cbounds[4]) - ord2f(cbounds[1])), ord2f(cbounds[5]) - ord2f(cbounds[2]));
+    int ax; float ext;
+    uint32_t k = split_pieces(leaf_lo[gid], leaf_hi[gid], scene, *sum, T, factor, max_pieces, ax, ext);
+    if (k > 1u) {
+        // only SLIVERS are split: longest edge more than eight times the height over it.  Slabs across the long axis of a sliver are short pieces of it; slabs
+        // across a large but fat triangle (a floor quad) would be strips as long as the triangle — boxes worse than the one they replace (measured: DragonScene
+        // 11.3 -> 8.8 Grays/s when its walls and floor were cut into 32 strips each)
+        const f3 e1 = mk3(tri_world[3 * (size_t)gid + 1]), e2 = mk3(tri_world[3 * (size_t)gid + 2]), e3 = e2 - e1;
+        const f3 c = cross3(e1, e2);
+        const float area2 = __builtin_sqrtf(dot3(c, c));
+        const float l2 = fmaxf(fmaxf(dot3(e1, e1), dot3(e2, e2)), dot3(e3, e3));
+        if (!(l2 > 8.0f * area2)) k = 1u;
+    }
+    count[gid] = k;
+}
+__global__ void k_split_emit(const float4 *__restrict__ tri_world, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi, const uint32_t *__restrict__ count,
+                             const uint32_t *__restrict__ offset, uint32_t T, float4 *__restrict__ ref_lo, float4 *__restrict__ ref_hi, uint32_t *__restrict__ ref_tri) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= T) return;
+    const uint32_t k = count[gid], base = offset[gid];
+    const float4 blo = leaf_lo[gid], bhi = leaf_hi[gid];
+    if (k <= 1u) { ref_lo[base] = blo; ref_hi[base] = bhi; ref_tri[base] = gid; return; }
+    const float4 p0 = tri_world[3 * (size_t)gid], p1 = tri_world[3 * (size_t)gid + 1], p2 = tri_world[3 * (size_t)gid + 2];
+    const f3 v[3] = {mk3(p0), mk3(p0) + mk3(p1), mk3(p0) + mk3(p2)};       // v0 + e is within an ulp of the vertex: far inside the padding below
+    const float ex = bhi.x - blo.x, ey = bhi.y - blo.y, ez = bhi.z - blo.z;
+    int ax = 0; float ext = ex; if (ey > ext) { ext = ey; ax = 1; } if (ez > ext) { ext = ez; ax = 2; }
+    const float lo_ax = ax == 0 ? blo.x : ax == 1 ? blo.y : blo.z, hi_ax = ax == 0 ? bhi.x : ax == 1 ? bhi.y : bhi.z;
+    for (uint32_t p = 0; p < k; p++) {
+        // the same expression gives piece p's upper and piece p + 1's lower bound: no gap between neighbours
+        const float a = p == 0 ? lo_ax : lo_ax + ext * ((float)p / (float)k), b = p + 1 == k ? hi_ax : lo_ax + ext * ((float)(p + 1) / (float)k);
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        auto take = [&](f3 q) { lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z); hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z); };
+        for (int i = 0; i < 3; i++) {
+            const f3 vi = v[i], vj = v[(i + 1) % 3];
+            const float ci = comp3(vi, ax), cj = comp3(vj, ax);
+            if (ci >= a && ci <= b) take(vi);
+            for (int s_ = 0; s_ < 2; s_++) {
+                const float pl = s_ ? b : a;
+                if ((ci < pl) != (cj < pl)) {
+                    const float t = (pl - ci) / (cj - ci);
+                    f3 q = vi + (vj - vi) * t;
+                    if (ax == 0) q.x = pl; else if (ax == 1) q.y = pl; else q.z = pl;
+                    take(q);
+                }
+            }
+        }
+        if (lo[0] > hi[0]) { lo[0] = blo.x; lo[1] = blo.y; lo[2] = blo.z; hi[0] = bhi.x; hi[1] = bhi.y; hi[2] = bhi.z; lo[ax] = a; hi[ax] = b; }      // (rounding left the slab empty: its part of the box)
+        for (int c = 0; c < 3; c++) {       // pad as k_flatten does, and never beyond the triangle's own padded box
+            const float m = fmaxf(fabsf(lo[c]), fabsf(hi[c])), e = 1e-5f * m + 1e-6f;
+            lo[c] -= e; hi[c] += e;
+        }
+        ref_lo[base + p] = make_float4(fmaxf(lo[0], blo.x), fmaxf(lo[1], blo.y), fmaxf(lo[2], blo.z), 0.0f);
+        ref_hi[base + p] = make_float4(fminf(hi[0], bhi.x), fminf(hi[1], bhi.y), fminf(hi[2], bhi.z), 0.0f);
+        ref_tri[base + p] = gid;
+    }
+}
+
 // ------------------------------------------------------------------ morton
 __device__ __forceinline__ uint64_t spread21(uint64_t x) {
     x &= 0x1fffffull;
@@ -361,11 +452,11 @@ __global__ void k_emit_nodes(TreeArrays t, uint32_t nnodes, const uint32_t *__re
 }
 
 __global__ void k_emit_packets(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ leaf_offset, uint32_t leaf_base, uint32_t n,
-                               const float4 *__restrict__ tri_world, float4 *__restrict__ packets) {
+                               const float4 *__restrict__ tri_world, const uint32_t *__restrict__ ref_tri /* nullptr: reference r is triangle r */, float4 *__restrict__ packets) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t rank = leaf_offset[leaf_base + j];
-    uint32_t gid = vals[j];
+    uint32_t gid = ref_tri ? ref_tri[vals[j]] : vals[j];
     packets[3 * (size_t)rank + 0] = tri_world[3 * (size_t)gid + 0];
     packets[3 * (size_t)rank + 1] = tri_world[3 * (size_t)gid + 1];
     packets[3 * (size_t)rank + 2] = tri_world[3 * (size_t)gid + 2];
@@ -675,7 +766,7 @@ SceneView DeviceScene::view() const {
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / 3) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
     v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
-    v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = (uint32_t)stats.triangles;
+    v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = num_packets;      // entries of `packets` (>= triangles when long triangles were pre-split into references)
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
 }
@@ -795,29 +886,21 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     if (T == 0) {       // empty scene: every ray misses
         MRT_HIP(out.nodes.alloc(8)); out.packets_offset = 4;
         MRT_HIP(hipStreamSynchronize(stream));
-        out.stats.bvh_nodes = 0; out.stats.bvh_leaves = 0;
+        out.stats.bvh_nodes = 0; out.stats.bvh_leaves = 0; out.num_packets = 0;
         out.stats.scene_bytes = 0;
         return MRT_OK;
     }
 
-    const uint32_t n = (uint32_t)T;
-    const uint32_t nnodes = 2 * n - 1;
-    const uint32_t leaf_base = n - 1;
+    const uint32_t T32 = (uint32_t)T;
     DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
-    DevBuf<float4> tri_world, leaf_lo, leaf_hi, node_lo, node_hi;
-    DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat;
+    DevBuf<float4> tri_world, tri_lo, tri_hi, ref_lo, ref_hi, node_lo, node_hi;
+    DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat, ref_tri;
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<float> cost;
     DevBuf<uint8_t> collapsed, mask;
     MRT_HIP(d_pos.alloc(h_pos.size())); MRT_HIP(d_idx.alloc(h_idx.size())); MRT_HIP(d_recs.alloc(recs.size()));
-    MRT_HIP(tri_world.alloc(3 * (size_t)n)); MRT_HIP(leaf_lo.alloc(n)); MRT_HIP(leaf_hi.alloc(n));
-    MRT_HIP(node_lo.alloc(nnodes)); MRT_HIP(node_hi.alloc(nnodes));
-    MRT_HIP(cbounds.alloc(6)); MRT_HIP(keys_a.alloc(n)); MRT_HIP(keys_b.alloc(n)); MRT_HIP(vals_a.alloc(n)); MRT_HIP(vals_b.alloc(n));
-    const uint32_t sort_blocks = cdiv(n, SORT_TILE);
-    MRT_HIP(ghist.alloc(256 * (size_t)sort_blocks));
-    MRT_HIP(parent.alloc(nnodes)); MRT_HIP(left.alloc(n)); MRT_HIP(right.alloc(n)); MRT_HIP(flags.alloc(nnodes));
-    MRT_HIP(ntri.alloc(nnodes)); MRT_HIP(size.alloc(nnodes)); MRT_HIP(cost.alloc(nnodes)); MRT_HIP(collapsed.alloc(nnodes)); MRT_HIP(mask.alloc(nnodes));
-    MRT_HIP(new_index.alloc(nnodes)); MRT_HIP(leaf_offset.alloc(nnodes)); MRT_HIP(stat.alloc(4));
+    MRT_HIP(tri_world.alloc(3 * (size_t)T32)); MRT_HIP(tri_lo.alloc(T32)); MRT_HIP(tri_hi.alloc(T32));
+    MRT_HIP(cbounds.alloc(6)); MRT_HIP(stat.alloc(4));
 
     struct EventPair {           // destroyed on every return path
         hipEvent_t a = nullptr, b = nullptr;
@@ -833,12 +916,47 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
         MRT_HIP(hipMemcpyAsync(cbounds.p, init, sizeof init, hipMemcpyHostToDevice, stream));
     }
-    MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
     MRT_HIP(hipMemsetAsync(stat.p, 0, stat.bytes(), stream));
     const int B = 256;
-    hipLaunchKernelGGL(k_flatten, dim3(cdiv(n, B)), dim3(B), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, n,
-                       tri_world.p, out.tri_shade.p, leaf_lo.p, leaf_hi.p, cbounds.p);
-    hipLaunchKernelGGL(k_morton, dim3(cdiv(n, B)), dim3(B), 0, stream, leaf_lo.p, leaf_hi.p, cbounds.p, n, keys_a.p, vals_a.p);
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, B)), dim3(B), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, T32,
+                       tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
+    // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
+    uint32_t n = T32;
+    const float4 *leaf_lo_p = tri_lo.p, *leaf_hi_p = tri_hi.p;
+    const uint32_t *ref_tri_p = nullptr;
+    if (opt.presplit > 0.0f && T32 >= 64) {
+        DevBuf<unsigned long long> esum; DevBuf<uint32_t> cnt, off;
+        MRT_HIP(esum.alloc(1)); MRT_HIP(cnt.alloc((size_t)T32 + 1)); MRT_HIP(off.alloc((size_t)T32 + 1));
+        MRT_HIP(hipMemsetAsync(esum.p, 0, 8, stream));
+        MRT_HIP(hipMemsetAsync(cnt.p + T32, 0, 4, stream));
+        hipLaunchKernelGGL(k_extent_sum, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p);
+        hipLaunchKernelGGL(k_split_count, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p, opt.presplit, 32u, cnt.p);
+        MRT_HIP(hipMemcpyAsync(off.p, cnt.p, ((size_t)T32 + 1) * 4, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, off.p, T32 + 1);      // off[T] = number of references
+        uint32_t total = 0;
+        MRT_HIP(hipMemcpyAsync(&total, off.p + T32, 4, hipMemcpyDeviceToHost, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        if (total > T32 && (uint64_t)total <= 2ull * T32) {           // (more than twice the triangles: the criterion is wrong for this mesh; build unsplit)
+            n = total;
+            MRT_HIP(ref_lo.alloc(n)); MRT_HIP(ref_hi.alloc(n)); MRT_HIP(ref_tri.alloc(n));
+            hipLaunchKernelGGL(k_split_emit, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cnt.p, off.p, T32, ref_lo.p, ref_hi.p, ref_tri.p);
+            MRT_HIP(hipStreamSynchronize(stream));                    // cnt / off die at scope exit
+            leaf_lo_p = ref_lo.p; leaf_hi_p = ref_hi.p; ref_tri_p = ref_tri.p;
+        }
+    }
+    out.num_packets = n;
+    if (int rc = layout_limits(n, 0)) return rc;
+    const uint32_t nnodes = 2 * n - 1;
+    const uint32_t leaf_base = n - 1;
+    MRT_HIP(node_lo.alloc(nnodes)); MRT_HIP(node_hi.alloc(nnodes));
+    MRT_HIP(keys_a.alloc(n)); MRT_HIP(keys_b.alloc(n)); MRT_HIP(vals_a.alloc(n)); MRT_HIP(vals_b.alloc(n));
+    const uint32_t sort_blocks = cdiv(n, SORT_TILE);
+    MRT_HIP(ghist.alloc(256 * (size_t)sort_blocks));
+    MRT_HIP(parent.alloc(nnodes)); MRT_HIP(left.alloc(n)); MRT_HIP(right.alloc(n)); MRT_HIP(flags.alloc(nnodes));
+    MRT_HIP(ntri.alloc(nnodes)); MRT_HIP(size.alloc(nnodes)); MRT_HIP(cost.alloc(nnodes)); MRT_HIP(collapsed.alloc(nnodes)); MRT_HIP(mask.alloc(nnodes));
+    MRT_HIP(new_index.alloc(nnodes)); MRT_HIP(leaf_offset.alloc(nnodes));
+    MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
+    hipLaunchKernelGGL(k_morton, dim3(cdiv(n, B)), dim3(B), 0, stream, leaf_lo_p, leaf_hi_p, cbounds.p, n, keys_a.p, vals_a.p);
     // 8 passes of 8 bits over 64-bit keys; after the 8 swaps the sorted data is back in the first pair
     auto radix_sort = [&](uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, uint32_t count, uint32_t *hist) {
         const uint32_t nb = cdiv(count, SORT_TILE);
@@ -865,7 +983,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(bsum.alloc(cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc(2));
         MRT_HIP(clo.alloc(n)); MRT_HIP(chi.alloc(n)); MRT_HIP(nlo.alloc(n)); MRT_HIP(nhi.alloc(n));
         MRT_HIP(hipMemsetAsync(counter.p, 0, 8, stream));
-        hipLaunchKernelGGL(k_ploc_init, dim3(cdiv(n, B)), dim3(B), 0, stream, n, leaf_base, vin, leaf_lo.p, leaf_hi.p, cid.p, clo.p, chi.p);
+        hipLaunchKernelGGL(k_ploc_init, dim3(cdiv(n, B)), dim3(B), 0, stream, n, leaf_base, vin, leaf_lo_p, leaf_hi_p, cid.p, clo.p, chi.p);
         uint32_t m = n;
         int guard = 0;
         while (m > 1) {
@@ -887,7 +1005,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(1), 0, stream, cid.p, parent.p);
         MRT_HIP(hipStreamSynchronize(stream));   // scratch buffers die at scope exit
     }
-    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo.p, leaf_hi.p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0);
+    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
     // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
     // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
@@ -896,7 +1014,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     float4 *const packets_p = out.nodes.p + 4 * (size_t)nnodes;
     out.packets_offset = 4 * (size_t)nnodes;
     hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, out.nodes.p);
-    hipLaunchKernelGGL(k_emit_packets, dim3(cdiv(n, B)), dim3(B), 0, stream, vin, leaf_offset.p, leaf_base, n, tri_world.p, packets_p);
+    hipLaunchKernelGGL(k_emit_packets, dim3(cdiv(n, B)), dim3(B), 0, stream, vin, leaf_offset.p, leaf_base, n, tri_world.p, ref_tri_p, packets_p);
     MRT_HIP(hipEventRecord(ev1, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
@@ -923,7 +1041,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.stats.max_depth = (int32_t)h_stat[0];
     out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;
     out.stats.build_ms = ms;
-    out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)n * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
+    out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)T * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
     out.num_wnodes = 0; out.wide_depth = 0;
     // a wide node addresses its leaf triangles with a 32-bit mask: 8 leaf children x max_leaf triangles must fit
     if (opt.wide && opt.max_leaf <= 4) {

@@ -375,7 +375,11 @@ static void icosphere(int level, std::vector<P3> &v, std::vector<uint32_t> &f) {
 }
 }  // namespace
 
-void make_dragon_proxy_irregular(MeshData &out) {
+// hostile = the stress variant of the same assembly (same triangle count, extents and material): a 100 : 1 range of triangle sizes (the belly
+// is a coarse level-4 blob, one hind leg a level-7 blob of half the size) and every 100th triangle pulled out into a sliver up to 50 times
+// its edge (a duplicated vertex: the surface gets a fin and a hole, as scanned meshes have) — long thin triangles whose boxes overlap
+// hundreds of others, the case the builder's triangle pre-splitting exists for.
+static void dragon_irregular_impl(MeshData &out, bool hostile) {
     const double PI = 3.14159265358979323846;
     ProcMesh pm;
     pm.v.reserve(440000); pm.idx.reserve(871414 * 3);
@@ -401,11 +405,15 @@ void make_dragon_proxy_irregular(MeshData &out) {
         for (size_t k = 0; k < sf.size(); k += 3) pm.tri(base + sf[k], base + sf[k + 1], base + sf[k + 2]);
     };
     blob(7, spine(0.30), P3{0.42, 0.30, 0.26}, 0.55, 0.10, 9.0);                // chest
-    blob(7, spine(0.62), P3{0.40, 0.26, 0.24}, 0.45, 0.12, 11.0);               // belly / hind
+    blob(hostile ? 4 : 7, spine(0.62), P3{0.40, 0.26, 0.24}, 0.45, 0.12, 11.0); // belly / hind
     blob(6, spine(0.93), P3{0.16, 0.14, 0.12}, 0.50, 0.08, 7.0);                // head
     blob(6, spine(0.08), P3{0.20, 0.08, 0.07}, 0.60, 0.10, 6.0);                // tail
     for (int l = 0; l < 2; l++) { P3 r = spine(0.30); blob(5, P3{r.x + 0.05, r.y - 0.42, r.z + (l ? 0.22 : -0.22)}, P3{0.07, 0.26, 0.07}, 0.40, 0.06, 5.0); }   // fore legs
-    for (int l = 0; l < 2; l++) { P3 r = spine(0.62); blob(4, P3{r.x - 0.03, r.y - 0.40, r.z + (l ? 0.20 : -0.20)}, P3{0.07, 0.24, 0.07}, 0.40, 0.06, 5.0); }   // hind legs
+    for (int l = 0; l < 2; l++) {                                                // hind legs
+        P3 r = spine(0.62);
+        const bool fine = hostile && l == 0;
+        blob(fine ? 7 : 4, P3{r.x - 0.03, r.y - 0.40, r.z + (l ? 0.20 : -0.20)}, fine ? P3{0.028, 0.10, 0.028} : P3{0.07, 0.24, 0.07}, 0.40, 0.06, 5.0);
+    }
     for (int k = 0; k < 3; k++) { P3 r = spine(0.35 + 0.2 * k); blob(2, P3{r.x, r.y + 0.34, r.z}, P3{0.03, 0.09, 0.03}, 0.2, 0.0, 1.0); }                        // dorsal spikes
     for (int k = 0; k < 2; k++) { P3 r = spine(0.96); blob(0, P3{r.x - 0.02, r.y + 0.17, r.z + (k ? 0.05 : -0.05)}, P3{0.02, 0.08, 0.02}, 0.0, 0.0, 1.0); }     // horns
     {   // an octahedron (8) and a triangular bipyramid (6) make the count exact
@@ -420,6 +428,21 @@ void make_dragon_proxy_irregular(MeshData &out) {
         for (int k = 0; k < 3; k++) b[k] = pm.add(P3{c2.x, c2.y + e * cos(2 * PI * k / 3), c2.z + e * sin(2 * PI * k / 3)});
         b[3] = pm.add(P3{c2.x - 2 * e, c2.y, c2.z}); b[4] = pm.add(P3{c2.x + 2 * e, c2.y, c2.z});
         for (int k = 0; k < 3; k++) { pm.tri(b[k], b[(k + 1) % 3], b[4]); pm.tri(b[(k + 1) % 3], b[k], b[3]); }
+    }
+    if (hostile) {          // slivers: every 100th triangle keeps a and c and gets b' = a + f (b - a), f up to 50, kept inside the mesh's box
+        P3 lo{1e30, 1e30, 1e30}, hi{-1e30, -1e30, -1e30};
+        for (auto &q : pm.v) { lo.x = std::min(lo.x, q.x); lo.y = std::min(lo.y, q.y); lo.z = std::min(lo.z, q.z); hi.x = std::max(hi.x, q.x); hi.y = std::max(hi.y, q.y); hi.z = std::max(hi.z, q.z); }
+        const size_t nt = pm.idx.size() / 3;
+        for (size_t t = 37; t < nt; t += 100) {
+            const P3 a = pm.v[pm.idx[3 * t]], b = pm.v[pm.idx[3 * t + 1]];
+            const P3 e = b - a;
+            const double len = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
+            if (!(len > 0.0)) continue;
+            const double f = std::min(50.0, 0.25 / len);
+            P3 q = a + e * f;
+            q.x = std::min(hi.x, std::max(lo.x, q.x)); q.y = std::min(hi.y, std::max(lo.y, q.y)); q.z = std::min(hi.z, std::max(lo.z, q.z));
+            pm.idx[3 * t + 1] = pm.add(q);
+        }
     }
     // shuffle the vertex numbering and the triangle order (Fisher-Yates, fixed seed)
     {
@@ -442,6 +465,8 @@ void make_dragon_proxy_irregular(MeshData &out) {
     const double half[3] = {0.45, 0.317, 0.20};
     finish(pm, half, "Dragon", mat, out);
 }
+void make_dragon_proxy_irregular(MeshData &out) { dragon_irregular_impl(out, false); }
+void make_dragon_proxy_hostile(MeshData &out) { dragon_irregular_impl(out, true); }
 
 // Bunny stand-in: 65 792 + 3 264 + 395 = 69 451 triangles (Stanford bunny count).
 void make_bunny_proxy(MeshData &out) {

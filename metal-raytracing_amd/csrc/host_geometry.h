@@ -24,6 +24,7 @@ struct MeshData {                      // what MDLMesh/MTKMesh hold for the hot 
 bool load_obj(const std::string &path, MeshData &out);
 void make_dragon_proxy(MeshData &out);
 void make_dragon_proxy_irregular(MeshData &out);   // same count, extents and material; irregular connectivity, shuffled order
+void make_dragon_proxy_hostile(MeshData &out);     // same count / extents / material; 100 : 1 triangle sizes and 1 % slivers up to 50 x their edge
 void make_bunny_proxy(MeshData &out);
 void make_transform(const float position[3], const float rotation[3], float scale, float out16[16]);
 void default_camera(int width, int height, MRTCamera *out);

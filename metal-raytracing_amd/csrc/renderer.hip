@@ -280,7 +280,7 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
     return 64u * (uint32_t)std::min<size_t>(16, std::max<size_t>(6, batches));
 }
 #ifndef MRT_WIDE_STREAM_WAVES
-#define MRT_WIDE_STREAM_WAVES 7
+#define MRT_WIDE_STREAM_WAVES (MRT_WIDE_SPEC ? 6 : 7)      // the second triangle group costs two registers: 80 instead of 72 (no spills); the frame rate does not depend on 6 or 7 waves per SIMD
 #endif
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,

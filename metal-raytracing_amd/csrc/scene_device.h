@@ -137,6 +137,7 @@ struct BuildOptions {
     int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
     int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
     float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
+    float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
                               // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS
@@ -145,6 +146,7 @@ struct BuildOptions {
 struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
+    uint32_t num_packets = 0;        // triangle packets per layout = build references (stats.triangles, or more when long triangles were pre-split)
     uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;

@@ -36,6 +36,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_SCALED
 #define MRT_WIDE_SCALED 1   // stream kernels: box distances in units of the ray's limit, interval ends from the clamp modifier (wide_node_test<true>)
 #endif
+#ifndef MRT_WIDE_SPEC
+#define MRT_WIDE_SPEC 1     // flattened scenes: a lane that still has triangles to test visits its next node anyway and keeps that node's triangles in a second group (below)
+#endif
 #ifndef MRT_COOP_MODE
 #define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
 #endif
@@ -277,6 +280,15 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); float ix = 0, iy = 0, iz = 0; bool nx = false, ny = false, nz = false; uint32_t oct = 0;
     float best_t = 0.0f; uint32_t best_pk = 0xFFFFFFFFu;     // closest hit so far: distance and packet (0xFFFFFFFF = none); id, U, V are re-read at emit time
     uint32_t g_base = 0, g_mask = 0, t_base = 0, t_mask = 0;   // g_mask: imask | permuted hit bits << 8 | stack depth << 16
+    // Node visits ahead of the triangle tests (flattened scenes).  A node's leaf children leave up to 32 pending triangles, tested one per iteration; a lane
+    // used to visit its next node only together with the LAST of them, so that in an average iteration half the live lanes sat out the node test — the
+    // expensive part of the iteration, paid by the whole wave (rocprofv3: 37 % of the lanes active per VALU instruction).  Now a lane with pending triangles
+    // visits its next node in the same iteration and parks that node's triangles in a second group (u_base, u_mask); it sits out only while both groups
+    // are occupied.  The visit sees a limit the pending triangles may still shorten — more children accepted than strictly needed, never fewer — and the
+    // closest hit stays the minimum over (t, id) whatever the order: the image is unchanged.  A ray then needs about max(node visits, triangle tests)
+    // iterations instead of their sum.
+    constexpr bool SPEC = !TWO_LEVEL && MRT_WIDE_SPEC != 0;
+    uint32_t u_base = 0, u_mask = 0;
     for (;;) {
         const unsigned long long m_idle = __ballot(!live);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
@@ -326,6 +338,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     tagw = __float_as_uint(bw_);
                     // enter the root as the only "hit child" of a pseudo group: base 0, no internal-child bits -> node 0; empty stack
                     g_base = 0; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;
+                    if (SPEC) { u_base = 0; u_mask = 0; }
                     live = true;
                     if (TWO_LEVEL) {
                         wray[lane] = ax_; wray[64 + lane] = ay_; wray[128 + lane] = az_; wray[192 + lane] = bx_; wray[256 + lane] = by_; wray[320 + lane] = bz_;
@@ -345,7 +358,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             ss->prev = now_; if (draining && ss->drain_t0 == 0ull) ss->drain_t0 = now_;
         }
 #endif
-        if (ss) { ss->iters++; ss->live_sum += (uint32_t)__popcll(__ballot(live)); ss->tri_sum += (uint32_t)__popcll(__ballot(live && t_mask != 0)); ss->node_sum += (uint32_t)__popcll(__ballot(live && t_mask == 0)); }
+        if (ss) { ss->iters++; ss->live_sum += (uint32_t)__popcll(__ballot(live)); }
         // One memory round trip per iteration.  A lane with at most one triangle left to test already knows the next node
         // it will visit (the nearest remaining hit child, or the top of its stack), so it fetches that node (80 B) together
         // with the triangle packet (48 B), tests the triangle, then the node's eight boxes against the possibly shorter ray.
@@ -363,6 +376,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 t_base = tl_pack >> 8; t_mask = tl_pack & 0xFFu;
             }
         }
+        if (SPEC && t_mask == 0u && u_mask != 0u) { t_base = u_base; t_mask = u_mask; u_mask = 0u; }      // the first group is used up: the second takes its place
         const bool in_blas = TWO_LEVEL && (g_mask >> 24) != 0u;
         // Drain phase (rocprofv3 / tools/wave_times.py: the last 30 % of a launch run on < 2 % of the waves, each walking one or two grazing rays
         // that test 100-200 triangles one per iteration).  The finished lanes help: the pending triangles of ONE such ray are tested by idle
@@ -391,7 +405,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter
         bool has_tri = live && t_mask != 0 && !has_inst;
         uint32_t t_rest = t_mask & (t_mask - 1u);               // triangles left after this iteration's first one
-        bool want_node = live && t_rest == 0u && !has_inst;
+        bool want_node = live && (t_rest == 0u || (SPEC && u_mask == 0u)) && !has_inst;      // a place for the node's triangles after this iteration's test
 #if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
         {
             const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
@@ -404,6 +418,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         const bool has_tri2 = false;
 #endif
         uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
+        bool last_step = false;         // flattened scenes: nothing but this iteration's triangle is left of the ray — it is finished when the test is done
         if (TWO_LEVEL && has_inst) {
             // enter the next instance of the TLAS leaf: park the TLAS group (always, also without siblings left: the exit pops it), take the ray
             // into object space, and fetch the BLAS root in this same iteration
@@ -431,7 +446,11 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             if ((g_mask & 0xFF00u) == 0) {
                 const uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16, isp = TWO_LEVEL ? g_mask >> 24 : 0u;
                 if (TWO_LEVEL && isp != 0u && sp == isp) want_node = false;      // the BLAS's last triangle is tested in this iteration; the lane leaves in the next
-                else if (sp == 0) { want_node = false; if (!has_tri) { live = false; unreported = true; } }
+                else if (sp == 0) {         // no node left: the ray ends with its last triangle (helpers may just have taken the first group's: the second one still counts)
+                    want_node = false;
+                    if (!has_tri) { if (!SPEC || u_mask == 0u) { live = false; unreported = true; } }
+                    else if (!TWO_LEVEL && t_rest == 0u && u_mask == 0u) last_step = true;
+                }
                 else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= ((sp - 1u) << 16) | (isp << 24); }
             }
             if (want_node) {
@@ -442,6 +461,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 pending = g_base + (uint32_t)__popc(g_mask & 0xFFu & ((1u << slot) - 1u));
             }
         }
+        if (ss) { ss->tri_sum += (uint32_t)__popcll(__ballot(has_tri)); ss->node_sum += (uint32_t)__popcll(__ballot(want_node)); }
         float4 r0, r1, r2, n0, n1, n2, n3, n4;        // loaded under has_tri / want_node and used under the same predicates;
         // an empty asm "defines" them on the other paths without the 28 v_mov a zero initialiser costs per iteration
         asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r2.x), "=v"(r2.y), "=v"(r2.z));
@@ -513,8 +533,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
             g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
-            t_base = __float_as_uint(n1.y); t_mask = tri_hits;
+            if (SPEC && t_mask != 0u) { u_base = __float_as_uint(n1.y); u_mask = tri_hits; }      // (u is empty here: the lane asked for a node with t_rest != 0 only then)
+            else { t_base = __float_as_uint(n1.y); t_mask = tri_hits; }
         }
+        if (last_step && live) { live = false; unreported = true; }
     }
 }
 

@@ -377,7 +377,8 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
 
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt_in, hipStream_t stream, DeviceScene &out) {
     const size_t I = meshes.size();
-    BuildOptions opt = opt_in; opt.instancing = 0;                      // a BLAS is a flat scene of one mesh: rope layout (queries, A/B path) + 8-wide layout (render kernels)
+    BuildOptions opt = opt_in; opt.instancing = 0;
+    opt.presplit = 0.0f;                                                // one packet per triangle in a BLAS: the instance rows address packets by triangle count (ntri)                      // a BLAS is a flat scene of one mesh: rope layout (queries, A/B path) + 8-wide layout (render kernels)
     // distinct geometries, in order of first use
     std::vector<int> blas_of(I, -1); std::vector<size_t> blas_src;
     std::map<size_t, int> seen;

@@ -118,6 +118,15 @@ def dragon_proxy_irregular():
         lib.mrt_meshdata_free(h)
 
 
+def dragon_proxy_hostile():
+    h = C.c_void_p()
+    check(lib.mrt_dragon_proxy_hostile(C.byref(h)))
+    try:
+        return _meshdata_to_python(h, "dragon-hostile")
+    finally:
+        lib.mrt_meshdata_free(h)
+
+
 def bunny_proxy():
     h = C.c_void_p()
     check(lib.mrt_bunny_proxy(C.byref(h)))
@@ -127,7 +136,7 @@ def bunny_proxy():
         lib.mrt_meshdata_free(h)
 
 
-_PROXIES = {"dragon": dragon_proxy, "dragon-irregular": dragon_proxy_irregular, "bunny": bunny_proxy}
+_PROXIES = {"dragon": dragon_proxy, "dragon-irregular": dragon_proxy_irregular, "dragon-hostile": dragon_proxy_hostile, "bunny": bunny_proxy}
 _mesh_cache = {}
 
 
@@ -219,6 +228,17 @@ class IrregularDragonScene(DragonScene):
         self.models[1] = Model(name="dragon-irregular", position=d.position, rotation=d.rotation, scale=d.scale)
 
 
+class HostileDragonScene(DragonScene):
+    """DragonScene with the stress stand-in: triangle sizes over a 100 : 1 range and 1 % of the triangles pulled into slivers of up to 50 times
+    their edge.  A scanned dragon is closer to this than to a uniform tube grid; the rate on it is bounded by a test (tests/test_hostile.py)."""
+
+    def __init__(self, size):
+        super().__init__(size)
+        d = self.models[1]
+        assert d.name == "dragon"
+        self.models[1] = Model(name="dragon-hostile", position=d.position, rotation=d.rotation, scale=d.scale)
+
+
 class CornellScene(Scene):
     """BASELINE.json configs[0]: plane.obj x5 + sphere.obj, one area light.  Not a
     reference scene — built from reference assets for the CPU-runnable plumbing case."""
@@ -274,7 +294,7 @@ class GardenScene(Scene):
         ]
 
 
-SCENES = {"dragon": DragonScene, "dragon_irregular": IrregularDragonScene, "cornell": CornellScene, "dragon4": InstancedDragonScene, "garden": GardenScene}
+SCENES = {"dragon": DragonScene, "dragon_irregular": IrregularDragonScene, "dragon_hostile": HostileDragonScene, "cornell": CornellScene, "dragon4": InstancedDragonScene, "garden": GardenScene}
 
 
 def _geometry_key(mesh):

@@ -56,6 +56,26 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_one_rank_image(tmp_path):
     assert a.shape == (180, 320, 4) and np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+def test_bench_group_path_assembles_the_one_rank_image(tmp_path):
+    """`bench.py --gpus 2` without torch.distributed.run drives the C ABI's device group (mrt_group_*); rehearsed here with a group that names
+    this box's GPU twice: same image as one rank, n_gpus = 2, strong scaling, ray counts conserved."""
+    import numpy as np
+    common = ["--steps", "6", "--warmup", "2", "--width", "320", "--height", "180", "--no-cpu-baseline", "--no-strict", "--no-latency"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-accum", one], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group-devices", "0,0", *common, "--dump-accum", two], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    d1 = json.loads([l for l in p1.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0 and "device group" in d["config"]["launch"]
+    assert d1["config"]["rays_per_frame"] == d["config"]["rays_per_frame"]
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a, b)
+
+
 def test_bench_argparse_defaults():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
