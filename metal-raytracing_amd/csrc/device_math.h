@@ -152,4 +152,50 @@ MRT_DEV uint32_t seed_hash_dev(uint32_t seed, uint32_t idx) {
     return h & 0xFFFFFu;
 }
 
+// Ray / hit queue traffic is streamed: written once by one kernel, read once by the next, ~0.85 GB per frame through 32 MB of L2 whose job is
+// to hold the BVH for the traversal's gathers.  MRT_STREAM_NT marks those accesses non-temporal (global_load / global_store ... nt).
+#ifndef MRT_STREAM_NT
+#define MRT_STREAM_NT 1     // measured: +4.5 % steady state, +3.7 % at 20 steps (same box, three alternations)
+#endif
+#ifndef MRT_STREAM_NT2
+#define MRT_STREAM_NT2 0    // also: the per-pixel sample buffer (read-modify-write by the shadow rays), the accumulation targets, the seed table
+#endif
+typedef float mrt_vf4 __attribute__((ext_vector_type(4)));
+MRT_DEV float4 qload(const float4 *p) {
+#if MRT_STREAM_NT
+    const mrt_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const mrt_vf4 *>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+MRT_DEV void qstore(float4 *p, float4 a) {
+#if MRT_STREAM_NT
+    const mrt_vf4 v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<mrt_vf4 *>(p));
+#else
+    *p = a;
+#endif
+}
+
+MRT_DEV float4 q2load(const float4 *p) {
+#if MRT_STREAM_NT2
+    const mrt_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const mrt_vf4 *>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+MRT_DEV void q2store(float4 *p, float4 a) {
+#if MRT_STREAM_NT2
+    const mrt_vf4 v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<mrt_vf4 *>(p));
+#else
+    *p = a;
+#endif
+}
+MRT_DEV uint32_t q2load(const uint32_t *p) {
+#if MRT_STREAM_NT2
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 MRT_DEV float xorsign(float v, uint32_t sgn) { return __uint_as_float(__float_as_uint(v) ^ sgn); }

@@ -94,7 +94,7 @@ __global__ void k_seed(uint32_t *__restrict__ seeds, uint32_t n, uint32_t seed) 
 // Raytracing.metal:175, :202-221
 MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, uint32_t sub, int x, int y, f3 &org, f3 &dir) {
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
-    uint32_t offset = seeds[sub * fp.npix + pix];                        // :175 (+ sub-frame index)
+    uint32_t offset = q2load(&seeds[sub * fp.npix + pix]);               // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
     float r0, r1;                                                        // :202-203
     if (fp.htab) { const float4 q = fp.htab[(size_t)HTAB_ROW * (uint32_t)idx]; r0 = q.x; r1 = q.y; }
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
     primary_ray(fp, seeds, sub, x, y, org, dir);
     // the direction goes to HBM (16 B per pixel: the memory system has headroom, the vector ALUs do not — k_shade reads it back
     // instead of repeating two Halton values, two divisions and a normalisation per pixel)
-    dirs[(size_t)sub * fp.capacity + slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));
+    qstore(&dirs[(size_t)sub * fp.capacity + slot], make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x)));
     TravHit h;
     bool hit;
     if (!TWO_LEVEL && hint != nullptr) {
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
         if (h.pk != guess) hint[pixel] = h.pk;
     }
     else hit = TWO_LEVEL ? traverse_instanced<false>(s, org, dir, 0.0f, __builtin_inff(), h) : traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
-    hits_s[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    qstore(&hits_s[slot], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
 }
 
 template <bool TWO_LEVEL>
@@ -294,13 +294,13 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
     traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
-            A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
-                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
             } else {
-                hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
         });
 }
@@ -330,13 +330,13 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
     traverse_wide_stream<TWO_LEVEL>(s, SharedCounter{work, n, chunk}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
-            A = sh ? srayA[tag] : rayA[tag]; B = sh ? srayB[tag] : rayB[tag];
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
-                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = scon[j], a = sample[pix]; sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f); }
+                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
             } else {
-                hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
         }
 #ifdef MRT_WAVE_TIMES
@@ -623,9 +623,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
     if (sample_primary) {
         active = active && slot_to_pixel(fp, slot, px_x, px_y);
         spix = sub * fp.npix + (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-        if (active) sample_primary[spix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // Raytracing.metal:227
+        if (active) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
     }
-    float4 H = active ? hits[i] : make_float4(-1, 0, 0, 0);
+    float4 H = active ? qload(&hits[i]) : make_float4(-1, 0, 0, 0);
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
     bool want_shadow = false, want_next = false;
@@ -636,9 +636,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
         float4 A, B, C;
         if (sample_primary) {
             A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
-            B = rayB[i];                                                 // direction | sample index, written by the primary trace
+            B = qload(&rayB[i]);                                         // direction | sample index, written by the primary trace
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
-        } else { A = rayA[i]; B = rayB[i]; C = thr[i]; }
+        } else { A = qload(&rayA[i]); B = qload(&rayB[i]); C = qload(&thr[i]); }
         pix = __float_as_uint(B.w);
         uint4 ts; uint32_t inst, geom, vb = 0;
         if (s.num_inst) {           // two-level scene: the shading record belongs to the BLAS, the instance is found from the global triangle id
@@ -656,12 +656,12 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
                      (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
         nrm = normalize3(n_w);                                           // :268
         f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
-        int idx = (int)(seeds[pix] + fp.sampleIndex);                  // pix = sub * npix + pixel: the table entry already holds + sub
+        int idx = (int)(q2load(&seeds[pix]) + fp.sampleIndex);         // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
         // the five Halton values of this bounce: one 32-byte segment of the table row, or the digit loops (wave-uniform choice)
         constexpr bool tab = TAB;
         float4 hq = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float hq4 = 0.0f;
-        if (tab) { const float4 *__restrict__ row = fp.htab + (size_t)HTAB_ROW * (uint32_t)idx + 2 + 2 * fp.bounce; hq = row[0]; hq4 = row[1].x; }
+        if (tab) { const float4 *__restrict__ row = fp.htab + (size_t)HTAB_ROW * (uint32_t)idx + 2 + 2 * fp.bounce; hq = qload(&row[0]); hq4 = qload(&row[1]).x; }
         norg = P + nrm * 1e-3f;                                          // :350, :390
         color = mk3(C);
         bool diffuse = true;
@@ -784,16 +784,16 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
         uint32_t ss = (uint32_t)(base >> 32) + w_shadow[wv] + (uint32_t)__popcll(m_sh & lt);
         f3 so = P + nrm * 1e-3f;                                         // :350
         f3 con = lcol * color;                                           // :372
-        srayA[ss] = make_float4(so.x, so.y, so.z, ldist - 1e-3f);        // :356
-        srayB[ss] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
-        scon[ss] = make_float4(con.x, con.y, con.z, 0.0f);
+        qstore(&srayA[ss], make_float4(so.x, so.y, so.z, ldist - 1e-3f));        // :356
+        qstore(&srayB[ss], make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix)));
+        qstore(&scon[ss], make_float4(con.x, con.y, con.z, 0.0f));
     }
     if (want_next) {
         const bool sp = MATERIALS && special;
         uint32_t ns = (uint32_t)base + (sp ? w_spec[wv] + (uint32_t)__popcll(m_sp & lt) : w_next[wv] + (uint32_t)__popcll(m_nx & lt));
-        nrayA[ns] = make_float4(norg.x, norg.y, norg.z, __builtin_inff());      // :390
-        nrayB[ns] = make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix));   // :391
-        nthr[ns] = make_float4(color.x, color.y, color.z, 0.0f);
+        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, __builtin_inff()));      // :390
+        qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
+        qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
     }
 }
 
@@ -834,16 +834,16 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
-        const float4 sm = sample[(size_t)sub * fp.npix + pix];
+        const float4 sm = qload(&sample[(size_t)sub * fp.npix + pix]);
         const uint32_t frame = fp.frameIndex + (uint32_t)sub;
         if (frame > 0) {
-            const float4 p = sub == 0 ? prev[pix] : c;
+            const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
             float fi = (float)frame;
             float den = (float)(frame + 1);
             c.x = (sm.x + p.x * fi) / den; c.y = (sm.y + p.y * fi) / den; c.z = (sm.z + p.z * fi) / den;
         } else c = sm;
     }
-    dst[pix] = make_float4(c.x, c.y, c.z, 1.0f);
+    q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
