@@ -331,6 +331,9 @@ int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
  * otherwise.  mrt_debug_poke_wnode overwrites one 32-bit word (0..19) of one 8-wide node — for the validator's own test only.            */
 int mrt_debug_validate(MRTScene scene);
 int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t value, uint32_t *old_value);
+/* Scene option "builder" = 2's host part on caller boxes (n x float4 lo, n x float4 hi): a top-down binned-SAH binary tree — leaf order[n], left /
+ * right of the n - 1 internal nodes (ids 0 .. n-2; leaf at position j = id n-1+j), parent of all 2n - 1 nodes (0xFFFFFFFF = root).  No device needed. */
+int mrt_debug_host_sah(const float *lo4, const float *hi4, uint32_t n, uint32_t *order, uint32_t *left, uint32_t *right, uint32_t *parent);
 /* The size check mrt_scene_commit applies (host only, no device needed): MRT_OK, or MRT_ERR_UNSUPPORTED when a scene of
  * `triangles` triangles whose BVH keeps `nodes` nodes (0 = unknown) cannot be addressed by the traversal layouts.      */
 int mrt_debug_layout_limits(uint64_t triangles, uint64_t nodes);

@@ -168,7 +168,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     MRT_TRY
     REQUIRE(scene && key, "mrt_scene_set_option: bad argument");
     std::string k(key);
-    if (k == "builder") scene->opt.builder = (int)value;
+    if (k == "builder") { REQUIRE(value == 0 || value == 1 || value == 2, "builder must be 0 (Karras LBVH), 1 (PLOC) or 2 (binned SAH on the host)"); scene->opt.builder = (int)value; }
     else if (k == "max_leaf") { REQUIRE(value >= 1 && value <= 16, "max_leaf must be in [1,16]"); scene->opt.max_leaf = (int)value; }
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
@@ -609,6 +609,17 @@ int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t 
     uint32_t *p = reinterpret_cast<uint32_t *>(scene->dev.wnodes.p + (size_t)mrt::WNODE_STRIDE * node) + word;
     if (old_value) MRT_HIP(hipMemcpy(old_value, p, 4, hipMemcpyDeviceToHost));
     MRT_HIP(hipMemcpy(p, &value, 4, hipMemcpyHostToDevice));
+    return MRT_OK;
+    MRT_CATCH
+}
+// builder = 2's host part on caller boxes (n x {lo.xyz, -} and {hi.xyz, -}): leaf order, left / right of the n - 1 internal nodes, parent of all 2n - 1 (no device needed)
+int mrt_debug_host_sah(const float *lo4, const float *hi4, uint32_t n, uint32_t *order, uint32_t *left, uint32_t *right, uint32_t *parent) {
+    MRT_TRY
+    REQUIRE(lo4 && hi4 && n >= 1 && order && left && right && parent, "mrt_debug_host_sah: bad argument");
+    std::vector<uint32_t> o, l, r, p;
+    mrt::host_sah_topology(reinterpret_cast<const float4 *>(lo4), reinterpret_cast<const float4 *>(hi4), n, o, l, r, p);
+    memcpy(order, o.data(), (size_t)n * 4); memcpy(parent, p.data(), (2 * (size_t)n - 1) * 4);
+    if (n > 1) { memcpy(left, l.data(), (size_t)(n - 1) * 4); memcpy(right, r.data(), (size_t)(n - 1) * 4); }
     return MRT_OK;
     MRT_CATCH
 }

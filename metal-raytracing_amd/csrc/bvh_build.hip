@@ -713,7 +713,7 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
                 meta[sl >> 2] |= m << (8 * (sl & 3));
                 uint32_t src = leaf_offset[c];
                 for (uint32_t r = 0; r < cnt; r++)
-                    for (int j = 0; j < 3; j++) wpackets[3 * (size_t)(my_t + off_t + r) + j] = packets[3 * (size_t)(src + r) + j];
+                    for (int j = 0; j < 3; j++) wpackets[WPK * (size_t)(my_t + off_t + r) + j] = packets[3 * (size_t)(src + r) + j];
                 off_t += cnt;
             } else {
                 imask |= 1u << sl;
@@ -764,7 +764,7 @@ SceneView DeviceScene::view() const {
     v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
-    v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / 3) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
+    v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / WPK) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
     v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = num_packets;      // entries of `packets` (>= triangles when long triangles were pre-split into references)
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
@@ -968,11 +968,24 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
             std::swap(ka, kb); std::swap(va, vb);
         }
     };
-    radix_sort(keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, ghist.p);
+    if (opt.builder != 2) radix_sort(keys_a.p, keys_b.p, vals_a.p, vals_b.p, n, ghist.p);
     uint64_t *kin = keys_a.p; uint32_t *vin = vals_a.p;
     TreeArrays t{node_lo.p, node_hi.p, parent.p, left.p, right.p, flags.p, cost.p, ntri.p, size.p, collapsed.p, mask.p};
     if (n == 1) {
         MRT_HIP(hipMemsetAsync(parent.p, 0xFF, 4, stream));
+    } else if (opt.builder == 2) {
+        // the quality yardstick: topology from the host's binned-SAH builder (bvh_host_sah.cpp); everything after it is the device pipeline
+        std::vector<float4> h_lo(n), h_hi(n);
+        MRT_HIP(hipMemcpyAsync(h_lo.data(), leaf_lo_p, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+        MRT_HIP(hipMemcpyAsync(h_hi.data(), leaf_hi_p, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        std::vector<uint32_t> h_order, h_left, h_right, h_parent;
+        host_sah_topology(h_lo.data(), h_hi.data(), n, h_order, h_left, h_right, h_parent);
+        MRT_HIP(hipMemcpyAsync(vals_a.p, h_order.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipMemcpyAsync(left.p, h_left.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipMemcpyAsync(right.p, h_right.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipMemcpyAsync(parent.p, h_parent.data(), (size_t)nnodes * 4, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipStreamSynchronize(stream));          // the host vectors die at scope exit
     } else if (opt.builder == 0) {
         hipLaunchKernelGGL(k_karras, dim3(cdiv(n - 1, B)), dim3(B), 0, stream, kin, (int)n, left.p, right.p, parent.p);
     } else {
@@ -1051,7 +1064,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         const size_t max_w = opt.wide_collapse ? (size_t)n + 2 : (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
         MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
-        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(3 * (size_t)n));
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(WPK * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
         DevBuf<float> dpC; DevBuf<uint8_t> dpD;
         WideDP dp{nullptr, nullptr};

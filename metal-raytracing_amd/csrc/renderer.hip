@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
                 } else if (best_pk == 0xFFFFFFFFu) end_path = true;                                // :246-247 miss terminates the path
                 else {
                     // hit record of the winning triangle (recomputed: same arithmetic as the traversal's test)
-                    const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)best_pk;
+                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
                     const float4 q0 = pk[0];
                     float t_, U, V, ad;
                     (void)tri_test(q0, pk[1], pk[2], o, d, 0.0f, __builtin_inff(), t_, U, V, ad);
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
         if (has_tri) {
             tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u;
             t_mask = t_rest;
-            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
         }
         if (want_node) {
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
                 if (is_shadow) { best_pk = tri_pk; live = false; }                                 // any hit: done
                 else {
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                    if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);   // ties go to the lowest id
+                    if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);   // ties go to the lowest id
                     if (better) { best_t = t; best_pk = tri_pk; }
                 }
             }

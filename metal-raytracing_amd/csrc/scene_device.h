@@ -45,6 +45,10 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 #define MRT_WNODE_STRIDE 5
 #endif
 constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wide nodes in HBM (5 = packed 80 B; 8 = one 128-B line each)
+#ifndef MRT_WPACKET_STRIDE
+#define MRT_WPACKET_STRIDE 3
+#endif
+constexpr uint32_t WPK = MRT_WPACKET_STRIDE;          // float4 units between the triangle packets of the 8-wide layout (3 = packed 48 B; 4 = one 64-byte sector each, never straddling two)
 constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
 constexpr int WIDE_STACK_TWO_LEVEL = 30;   // two-level scenes: TLAS levels + 1 (the TLAS group parked at instance entry) + the deepest BLAS; 5-bit depth fields
 constexpr uint32_t WIDE_WORLD_RAY_BYTES = 6 * 64 * 4;   // two-level stream traversal: the world-space ray of every lane (o.xyz, d.xyz) parked in LDS in front of the stack
@@ -129,7 +133,7 @@ struct HostMesh {                  // what the caller handed over through mrt_sc
 };
 
 struct BuildOptions {
-    int builder = 1;          // 0 = Karras radix tree (plain LBVH), 1 = PLOC agglomeration over the Morton order
+    int builder = 1;          // 0 = Karras radix tree (plain LBVH), 1 = PLOC agglomeration over the Morton order, 2 = binned SAH built on the host (quality yardstick, seconds)
     int max_leaf = 4;         // SAH leaf collapse limit
     float cost_trav = 1.0f;   // SAH constants
     float cost_isect = 1.0f;
@@ -171,6 +175,8 @@ void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+// bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
+void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
 int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 // two_level.hip

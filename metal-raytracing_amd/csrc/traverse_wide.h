@@ -171,7 +171,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
         if (do_tri) {
             const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
             t_mask &= t_mask - 1u;
-            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)(t_base + k);
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)(t_base + k);
             const float4 r0 = pk[0], r1 = pk[1], r2 = pk[2];
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, o, d, tmin, h.t, t, U, V, ad)) {
@@ -287,6 +287,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     // are occupied.  The visit sees a limit the pending triangles may still shorten — more children accepted than strictly needed, never fewer — and the
     // closest hit stays the minimum over (t, id) whatever the order: the image is unchanged.  A ray then needs about max(node visits, triangle tests)
     // iterations instead of their sum.
+    // (two-level scenes: tried inside the BLASes — 84 instead of 80 registers and no faster, 6.27 vs 6.38 Grays/s on dragon x 4; left off there)
     constexpr bool SPEC = !TWO_LEVEL && MRT_WIDE_SPEC != 0;
     uint32_t u_base = 0, u_mask = 0;
     for (;;) {
@@ -297,7 +298,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 const bool was_any = (tagw >> 31) != 0, was_hit = best_pk != 0xFFFFFFFFu;
                 TravHit h; h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
                 if (!was_any && was_hit) {      // id and barycentrics of the winning triangle: recomputed here (same arithmetic) instead of living in 4 registers
-                    const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)best_pk;
+                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
                     const float4 q0 = pk[0];
                     float t_;
                     if (TWO_LEVEL) {            // in the object space of the hit's instance, from the parked world ray
@@ -364,6 +365,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         // with the triangle packet (48 B), tests the triangle, then the node's eight boxes against the possibly shorter ray.
         // (Measured, full frame: node-or-triangle per iteration 6.90, node then triangle with two round trips 7.24,
         // this loop 7.44 Grays/s.)
+        if (SPEC && t_mask == 0u && u_mask != 0u) { t_base = u_base; t_mask = u_mask; u_mask = 0u; }      // the first group is used up: the second takes its place
         if (TWO_LEVEL) {
             // a lane inside a BLAS with nothing of it left (no triangle pending, no hit child, stack back at the entry depth) returns to world
             // space and to the TLAS group parked at entry — in this same iteration it goes on to its next instance or TLAS node
@@ -376,7 +378,6 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 t_base = tl_pack >> 8; t_mask = tl_pack & 0xFFu;
             }
         }
-        if (SPEC && t_mask == 0u && u_mask != 0u) { t_base = u_base; t_mask = u_mask; u_mask = 0u; }      // the first group is used up: the second takes its place
         const bool in_blas = TWO_LEVEL && (g_mask >> 24) != 0u;
         // Drain phase (rocprofv3 / tools/wave_times.py: the last 30 % of a launch run on < 2 % of the waves, each walking one or two grazing rays
         // that test 100-200 triangles one per iteration).  The finished lanes help: the pending triangles of ONE such ray are tested by idle
@@ -405,7 +406,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter
         bool has_tri = live && t_mask != 0 && !has_inst;
         uint32_t t_rest = t_mask & (t_mask - 1u);               // triangles left after this iteration's first one
-        bool want_node = live && (t_rest == 0u || (SPEC && u_mask == 0u)) && !has_inst;      // a place for the node's triangles after this iteration's test
+        bool want_node = live && (t_rest == 0u || (SPEC && u_mask == 0u && (!TWO_LEVEL || in_blas))) && !has_inst;      // a place for the node's triangles after this iteration's test
 #if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
         {
             const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
@@ -472,13 +473,13 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             if (has_tri) { tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u; t_mask = t_rest; }
             else tri_pk = help_pk;
             MRT_BOUND(tri_pk, s.num_wpackets, 2);
-            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk;
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
         }
         if (has_tri2) {
             tri_pk2 = t_base + (uint32_t)__ffs((int)t_rest) - 1u;
             t_mask = t_rest & (t_rest - 1u);
-            const float4 *__restrict__ pk = s.wpackets + 3 * (size_t)tri_pk2;
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk2;
             n0 = pk[0]; n1 = pk[1]; n2 = pk[2];
         }
         if (want_node) {
@@ -493,8 +494,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 else {
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
                     if (!better) {                                      // t == best_t: ties go to the lowest (global) id (rare)
-                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + __float_as_uint(q0.w) < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
-                        else better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + __float_as_uint(q0.w) < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
+                        else better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
                     }
                     if (better) { best_t = t; best_pk = pk_index; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
                 }
@@ -519,8 +520,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 else {
                     bool better = bt < best_t || best_pk == 0xFFFFFFFFu;
                     if (!better && bt == best_t) {
-                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + bgid < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
-                        else better = bgid < __float_as_uint(s.wpackets[3 * (size_t)best_pk].w);
+                        if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + bgid < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
+                        else better = bgid < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
                     }
                     if (better) { best_t = bt; best_pk = bpk; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
                 }

@@ -255,7 +255,7 @@ int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only) {
     auto bad = [&](const std::string &what) { set_error("scene layout validation failed: " + what); return MRT_ERR_STATE; };
     const bool two = sc.num_inst > 0;
     const uint32_t NW = sc.num_wnodes;
-    const size_t packets = sc.wpackets.p ? sc.wpackets.n / 3 : 0;
+    const size_t packets = sc.wpackets.p ? sc.wpackets.n / WPK : 0;
     std::vector<uint32_t> wtl, tl;
     if (two) {
         const size_t I = sc.num_inst;
@@ -431,13 +431,13 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     all_wide = all_wide && wnodes_total < (1u << 24) && WNODE_STRIDE == 5;
     out.wnodes.release(); out.wpackets.release(); out.tlas_wcap = 0; out.blas_wdepth = 0;
     if (all_wide) {
-        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * wnodes_total)); MRT_HIP(out.wpackets.alloc(std::max<size_t>(3 * packets_total, 3)));
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * wnodes_total)); MRT_HIP(out.wpackets.alloc(std::max<size_t>(WPK * packets_total, WPK)));
         MRT_HIP(hipMemsetAsync(out.wnodes.p, 0, out.wnodes.bytes(), stream));
         for (size_t b = 0; b < B; b++) {
             const size_t wn = blas[b].num_wnodes, nt = blas[b].stats.triangles;
             if (!wn) continue;
             MRT_HIP(hipMemcpyAsync(out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], blas[b].wnodes.p, wn * WNODE_STRIDE * 16, hipMemcpyDeviceToDevice, stream));
-            MRT_HIP(hipMemcpyAsync(out.wpackets.p + 3 * (size_t)packet_base[b], blas[b].wpackets.p, nt * 48, hipMemcpyDeviceToDevice, stream));
+            MRT_HIP(hipMemcpyAsync(out.wpackets.p + WPK * (size_t)packet_base[b], blas[b].wpackets.p, nt * 16 * WPK, hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k_relocate_wide, dim3((uint32_t)((wn + 255) / 256)), dim3(256), 0, stream, out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], (uint32_t)wn, wnode_base[b], packet_base[b]);
         }
         MRT_HIP(hipGetLastError());

@@ -168,3 +168,65 @@ def test_layout_limits_reject_scenes_the_traversal_cannot_address(mrt):
     assert L(24_500_000, 0) == UNSUPPORTED                       # 64 (2n-1) + 48 n > 2^32
     assert L(1 << 26, 0) == UNSUPPORTED
     assert b"too large" in mrt.lib.mrt_last_error()
+
+
+def _sah_cost(lo, hi, order, left, right, parent):
+    """SAH of a binary tree over boxes (Ct = Ci = 1, one reference per leaf), iteratively bottom-up."""
+    n = len(order)
+    nlo = np.empty((2 * n - 1, 3), np.float64); nhi = np.empty((2 * n - 1, 3), np.float64)
+    nlo[n - 1:] = lo[order]; nhi[n - 1:] = hi[order]
+    depth = np.zeros(2 * n - 1, np.int64)
+    root = int(np.where(parent == 0xFFFFFFFF)[0][0])
+    # parents before children in a BFS from the root
+    orderq = [root]
+    for q in orderq:
+        if q < n - 1:
+            for c in (int(left[q]), int(right[q])):
+                depth[c] = depth[q] + 1; orderq.append(c)
+    assert len(orderq) == 2 * n - 1
+    for q in reversed(orderq):
+        if q < n - 1:
+            l, r = int(left[q]), int(right[q])
+            nlo[q] = np.minimum(nlo[l], nlo[r]); nhi[q] = np.maximum(nhi[l], nhi[r])
+    d = nhi - nlo
+    area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+    return float(area.sum() / area[root]), int(depth.max())
+
+
+def test_host_sah_builder_makes_a_valid_tree_of_lower_cost_than_a_median_split(mrt):
+    """Scene option builder = 2: the host part (binned SAH over reference boxes) — every reference is a leaf exactly once, every internal node
+    has two children whose parent it is, one root; and its SAH cost beats an object-median tree over the same boxes."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 20000
+    c = np.concatenate([rng.normal(0, 1, (n // 2, 3)), rng.normal(0, 0.05, (n // 2, 3)) + [3, 0, 0]]).astype(np.float32)      # two clusters of very different density
+    e = (rng.uniform(0.001, 0.02, (n, 3)) * np.where(rng.uniform(size=(n, 1)) < 0.01, 30, 1)).astype(np.float32)            # 1 % long boxes
+    lo4 = np.zeros((n, 4), np.float32); hi4 = np.zeros((n, 4), np.float32); lo4[:, :3] = c - e; hi4[:, :3] = c + e
+    order = np.zeros(n, np.uint32); left = np.zeros(n - 1, np.uint32); right = np.zeros(n - 1, np.uint32); parent = np.zeros(2 * n - 1, np.uint32)
+    mrt._ffi.check(mrt.lib.mrt_debug_host_sah(mrt._ffi.ptr(lo4), mrt._ffi.ptr(hi4), n, mrt._ffi.ptr(order), mrt._ffi.ptr(left), mrt._ffi.ptr(right), mrt._ffi.ptr(parent)))
+    assert np.array_equal(np.sort(order), np.arange(n))                                   # a permutation
+    assert (parent == 0xFFFFFFFF).sum() == 1
+    kids = np.concatenate([left, right])
+    assert np.array_equal(np.sort(kids), np.setdiff1d(np.arange(2 * n - 1), np.where(parent == 0xFFFFFFFF)[0]))      # every non-root node is a child exactly once
+    assert np.array_equal(parent[left], np.arange(n - 1)) and np.array_equal(parent[right], np.arange(n - 1))
+    cost, depth = _sah_cost(lo4[:, :3].astype(np.float64), hi4[:, :3].astype(np.float64), order, left, right, parent)
+    # object-median tree over the same boxes
+    m_order = np.zeros(n, np.uint32); m_left = np.zeros(n - 1, np.uint32); m_right = np.zeros(n - 1, np.uint32); m_parent = np.full(2 * n - 1, 0xFFFFFFFF, np.uint32)
+    cen = lo4[:, :3] + hi4[:, :3]
+    ids = np.arange(n); nxt = [0]
+    def build(b, e_, par):
+        if e_ - b == 1:
+            m_parent[n - 1 + b] = par; return n - 1 + b
+        me = nxt[0]; nxt[0] += 1; m_parent[me] = par
+        sub = ids[b:e_]; ax = int(np.argmax(cen[sub].max(0) - cen[sub].min(0)))
+        ids[b:e_] = sub[np.argsort(cen[sub, ax], kind="stable")]
+        mid = (b + e_) // 2
+        m_left[me] = build(b, mid, me); m_right[me] = build(mid, e_, me)
+        return me
+    import sys
+    sys.setrecursionlimit(10000)
+    build(0, n, 0xFFFFFFFF)
+    m_order[:] = ids
+    mcost, _ = _sah_cost(lo4[:, :3].astype(np.float64), hi4[:, :3].astype(np.float64), m_order, m_left, m_right, m_parent)
+    assert cost < 0.9 * mcost, (cost, mcost)
+    assert depth < 64

@@ -85,7 +85,7 @@ def _rays(rng, n, lo, hi, tmax=np.inf):
     return rays
 
 
-@pytest.mark.parametrize("builder,wide", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("builder,wide", [(0, 0), (1, 0), (1, 1), (2, 1)])
 @pytest.mark.parametrize("name,n", [("plane", 500), ("sphere", 3000), ("train", 3000), ("treefir", 2000), ("teapot", 1500)])
 def test_intersect_matches_brute_force(mrt, orc, gpu_ctx, name, n, builder, wide):
     class S(mrt.Scene):
@@ -140,7 +140,7 @@ def test_intersect_edge_cases(mrt, gpu_ctx):
 
 
 # ---------------------------------------------------------------- whole-frame parity
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 2])
 def test_cornell_256_spp1_parity(mrt, orc, gpu_ctx, builder):
     """BASELINE configs[0]."""
     sc = mrt.CornellScene((256, 256))
@@ -304,6 +304,12 @@ def test_1080p_builder_invariance(mrt, gpu_ctx, dragon1080):
     assert np.array_equal(r2.accumulation(), img)
     assert (r2.stats.closest_rays, r2.stats.shadow_rays) == (r.stats.closest_rays, r.stats.shadow_rays)
     r2.close()
+    # a third tree: binned SAH from the host builder, greedy 8-wide collapse, slivers pre-split into references
+    r3 = mrt.Renderer((1920, 1080), sc, ctx=gpu_ctx, scene_options={"builder": 2, "wide_collapse": 0, "presplit": 2})
+    r3.draw(1, wait=True)
+    assert np.array_equal(r3.accumulation(), img)
+    assert (r3.stats.closest_rays, r3.stats.shadow_rays) == (r.stats.closest_rays, r.stats.shadow_rays)
+    r3.close()
 
 
 def test_1080p_counts_and_determinism(mrt, gpu_ctx, dragon1080):
