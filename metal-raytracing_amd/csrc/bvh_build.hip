@@ -350,13 +350,33 @@ struct TreeArrays {
     uint8_t *mask;            // per node: near-child mask
 };
 
+struct WideDP { float *C; uint8_t *dec; };      // optimal 8-wide collapse (k_wide_dp below): 8 entries per node; C == nullptr: not wanted
+
 __device__ __forceinline__ float box_area(float4 lo, float4 hi) {
     float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
     return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
 
+// one node of the optimal 8-wide collapse (see "optimal 8-wide collapse" below): C(p, .) from the two children's entries
+__device__ __forceinline__ void wide_dp_node(const WideDP &dp, uint32_t p, uint32_t l, uint32_t r, float area, uint32_t nt, int max_leaf, float c_node, float c_tri) {
+    float cl[8], cr[8];
+    for (int i = 1; i < 8; i++) { cl[i] = dp.C[8 * (size_t)l + i]; cr[i] = dp.C[8 * (size_t)r + i]; }
+    float C[8]; uint8_t D[8];
+    float best = 3.0e38f; int bk = 1;
+    for (int k = 1; k <= 7; k++) { const float c = cl[k] + cr[8 - k]; if (c < best) { best = c; bk = k; } }
+    const float c_int = area * c_node + best;
+    const float c_leaf = nt <= (uint32_t)max_leaf ? area * (float)nt * c_tri : 3.0e38f;
+    D[0] = (uint8_t)bk; D[1] = c_leaf <= c_int ? 1 : 0; C[1] = fminf(c_leaf, c_int); C[0] = c_int;
+    for (int i = 2; i <= 7; i++) {
+        float b = 3.0e38f; int k_ = 1;
+        for (int k = 1; k < i; k++) { const float c = cl[k] + cr[i - k]; if (c < b) { b = c; k_ = k; } }
+        if (b < C[i - 1]) { C[i] = b; D[i] = (uint8_t)k_; } else { C[i] = C[i - 1]; D[i] = 0; }
+    }
+    for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)p + i] = C[i]; dp.dec[8 * (size_t)p + i] = D[i]; }
+}
+
 __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi,
-                        uint32_t n, uint32_t leaf_base, int max_leaf, float ct, float ci, int have_boxes) {
+                        uint32_t n, uint32_t leaf_base, int max_leaf, float ct, float ci, int have_boxes, WideDP dp, int dp_max_leaf, float dp_c_node, float dp_c_tri) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t node = leaf_base + j;
@@ -365,6 +385,7 @@ __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const f
     t.lo[node] = lo; t.hi[node] = hi;
     t.cost[node] = ci * box_area(lo, hi);
     t.ntri[node] = 1; t.size[node] = 1; t.collapsed[node] = 1; t.mask[node] = 0;
+    if (dp.C) { const float c = dp_c_tri * box_area(lo, hi); for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)node + i] = c; dp.dec[8 * (size_t)node + i] = i == 1 ? 1 : 0; } }
     __threadfence();
     uint32_t p = t.parent[node];
     while (p != NONE) {
@@ -396,6 +417,7 @@ __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const f
         t.size[p] = col ? 1u : 1u + t.size[l] + t.size[r];
         t.collapsed[p] = col ? 1 : 0;
         t.mask[p] = (uint8_t)m;
+        if (dp.C) wide_dp_node(dp, p, l, r, area, nt, dp_max_leaf, dp_c_node, dp_c_tri);      // same bottom-up pass: the children's entries are complete (fence above)
         __threadfence();
         node = p;
         p = t.parent[p];
@@ -553,47 +575,10 @@ __global__ void k_set_root_parent(const uint32_t *__restrict__ cid, uint32_t *__
 //   C(n, 1)  = min(C_leaf(n), C_node(n)),   C_leaf = area * triangles * c_tri  (subtrees of <= max_leaf triangles),
 //                                           C_node = area * c_node + min_k C(left, k) + C(right, 8 - k)
 //   C(n, i)  = min(C(n, i - 1), min_k C(left, k) + C(right, i - k))
-// computed bottom-up (same arrival protocol as k_refit), with the arg-min of every entry kept: dec[0] = k of C_node, dec[1] = 1 when the
+// computed bottom-up inside k_refit (wide_dp_node: one pass over the tree for boxes, SAH leaf collapse and this table), with the arg-min of every entry kept: dec[0] = k of C_node, dec[1] = 1 when the
 // leaf is cheaper, dec[i] = k of the split or 0 for "no better than i - 1 roots".  k_wide_level<true> then unfolds the decisions of a
 // wide node's root into its (at most eight) children.  The greedy collapse it replaces opens the largest child first and fills 6.0 of 8
 // slots on DragonScene; this one trades nodes against triangle tests with the constants the traversal kernel was measured at.
-struct WideDP { float *C; uint8_t *dec; };      // 8 entries per node
-__global__ void k_wide_dp(TreeArrays t, WideDP dp, uint32_t *__restrict__ flags2, uint32_t n, uint32_t leaf_base, int max_leaf, float c_node, float c_tri) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    uint32_t node = leaf_base + j;
-    {
-        const float c = c_tri * box_area(t.lo[node], t.hi[node]);
-        for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)node + i] = c; dp.dec[8 * (size_t)node + i] = i == 1 ? 1 : 0; }
-    }
-    __threadfence();
-    uint32_t p = t.parent[node];
-    while (p != NONE) {
-        uint32_t old = atomicAdd(&flags2[p], 1u);
-        if (old == 0) return;
-        __threadfence();
-        const uint32_t l = t.left[p], r = t.right[p];
-        float cl[8], cr[8];
-        for (int i = 1; i < 8; i++) { cl[i] = dp.C[8 * (size_t)l + i]; cr[i] = dp.C[8 * (size_t)r + i]; }
-        const float area = box_area(t.lo[p], t.hi[p]);
-        const uint32_t nt = t.ntri[p];
-        float C[8]; uint8_t D[8];
-        float best = 3.0e38f; int bk = 1;
-        for (int k = 1; k <= 7; k++) { const float c = cl[k] + cr[8 - k]; if (c < best) { best = c; bk = k; } }
-        const float c_int = area * c_node + best;
-        const float c_leaf = nt <= (uint32_t)max_leaf ? area * (float)nt * c_tri : 3.0e38f;
-        D[0] = (uint8_t)bk; D[1] = c_leaf <= c_int ? 1 : 0; C[1] = fminf(c_leaf, c_int); C[0] = c_int;
-        for (int i = 2; i <= 7; i++) {
-            float b = 3.0e38f; int k_ = 1;
-            for (int k = 1; k < i; k++) { const float c = cl[k] + cr[i - k]; if (c < b) { b = c; k_ = k; } }
-            if (b < C[i - 1]) { C[i] = b; D[i] = (uint8_t)k_; } else { C[i] = C[i - 1]; D[i] = 0; }
-        }
-        for (int i = 0; i < 8; i++) { dp.C[8 * (size_t)p + i] = C[i]; dp.dec[8 * (size_t)p + i] = D[i]; }
-        __threadfence();
-        p = t.parent[p];
-    }
-}
-
 // ------------------------------------------------------------------ 8-wide collapse + quantisation
 // One thread per wide node of the current level.  Greedy collapse (largest surface area first) of the
 // refitted binary tree; children that are binary inner nodes form the next level (BFS numbering, so a
@@ -931,8 +916,15 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(hipMemsetAsync(cnt.p + T32, 0, 4, stream));
         hipLaunchKernelGGL(k_extent_sum, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p);
         hipLaunchKernelGGL(k_split_count, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p, opt.presplit, 32u, cnt.p);
-        MRT_HIP(hipMemcpyAsync(off.p, cnt.p, ((size_t)T32 + 1) * 4, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, off.p, T32 + 1);      // off[T] = number of references
+        {   // exclusive scan of the counts: per-block scan, scan of the block sums, add; tot.p = number of references
+            const uint32_t nb = cdiv(T32, 1024);
+            DevBuf<uint32_t> bsum, tot; MRT_HIP(bsum.alloc(nb + 1)); MRT_HIP(tot.alloc(1));
+            hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, cnt.p, off.p, bsum.p, T32);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, off.p, bsum.p, T32, tot.p, cnt.p);
+            MRT_HIP(hipMemcpyAsync(off.p + T32, tot.p, 4, hipMemcpyDeviceToDevice, stream));
+            MRT_HIP(hipStreamSynchronize(stream));
+        }
         uint32_t total = 0;
         MRT_HIP(hipMemcpyAsync(&total, off.p + T32, 4, hipMemcpyDeviceToHost, stream));
         MRT_HIP(hipStreamSynchronize(stream));
@@ -1018,7 +1010,14 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         hipLaunchKernelGGL(k_set_root_parent, dim3(1), dim3(1), 0, stream, cid.p, parent.p);
         MRT_HIP(hipStreamSynchronize(stream));   // scratch buffers die at scope exit
     }
-    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0);
+    DevBuf<float> dpC; DevBuf<uint8_t> dpD;
+    WideDP dp{nullptr, nullptr};
+    if (opt.wide && opt.max_leaf <= 4 && opt.wide_collapse) {
+        MRT_HIP(dpC.alloc(8 * (size_t)nnodes)); MRT_HIP(dpD.alloc(8 * (size_t)nnodes));
+        dp.C = dpC.p; dp.dec = dpD.p;
+    }
+    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, 0,
+                       dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
     // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
     // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
@@ -1066,14 +1065,6 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
         MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(WPK * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
-        DevBuf<float> dpC; DevBuf<uint8_t> dpD;
-        WideDP dp{nullptr, nullptr};
-        if (opt.wide_collapse) {
-            MRT_HIP(dpC.alloc(8 * (size_t)nnodes)); MRT_HIP(dpD.alloc(8 * (size_t)nnodes));
-            dp.C = dpC.p; dp.dec = dpD.p;
-            MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
-            hipLaunchKernelGGL(k_wide_dp, dim3(cdiv(n, B)), dim3(B), 0, stream, t, dp, flags.p, n, leaf_base, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
-        }
         MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
         MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
         uint32_t n_in = 1, base_in = 0, total = 0; int depth = 0;
