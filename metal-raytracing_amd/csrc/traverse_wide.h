@@ -39,6 +39,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_SPEC
 #define MRT_WIDE_SPEC 1     // flattened scenes: a lane that still has triangles to test visits its next node anyway and keeps that node's triangles in a second group (below)
 #endif
+#if MRT_WIDE_DUAL_TRI && MRT_WIDE_SPEC
+#error "MRT_WIDE_DUAL_TRI predates the second triangle group of MRT_WIDE_SPEC and is wrong with it (it consumes the first group behind the node test's back): build with -DMRT_WIDE_SPEC=0"
+#endif
 #ifndef MRT_COOP_MODE
 #define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
 #endif

@@ -13,6 +13,13 @@ b "C2 3 lanes x 4" --steps 240 --warmup 24 --frames-in-flight 3
 b "C2 6 lanes x 4" --steps 240 --warmup 24 --frames-in-flight 6
 b "C2 irregular 20" --scene dragon_irregular --steps 20 --warmup 5
 b "C2 irregular 240" --scene dragon_irregular --steps 240 --warmup 24
+b "C2 hostile 20" --scene dragon_hostile --steps 20 --warmup 5
+b "C2 hostile 240" --scene dragon_hostile --steps 240 --warmup 24
+b "C2 hostile 240, no pre-splitting" --scene dragon_hostile --steps 240 --warmup 24 --sopt presplit=0
+b "C2 strict (max_bounces 1) 20" --bounces 1 --steps 20 --warmup 5
+b "C2 strict (max_bounces 1) 240" --bounces 1 --steps 240 --warmup 24
+b "C2 builder 2 (host binned SAH) 240" --builder 2 --steps 240 --warmup 24
+b "C2 greedy 8-wide collapse 240" --sopt wide_collapse=0 --steps 240 --warmup 24
 b "C3 4 bounces 64 frames" --bounces 4 --steps 64 --warmup 8
 b "C4 garden 4K" --scene garden --width 3840 --height 2160 --steps 48 --warmup 8
 b "C5 dragon4 flat" --scene dragon4 --steps 48 --warmup 12
