@@ -1090,8 +1090,9 @@ void Renderer::release_lane(FrameLane &L) {
 }
 int Renderer::alloc_lane(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
-    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); MRT_HIP(L.thr[k].alloc(qcap)); }
-    MRT_HIP(L.hits.alloc(qcap)); MRT_HIP(L.srayA.alloc(qcap)); MRT_HIP(L.srayB.alloc(qcap)); MRT_HIP(L.scon.alloc(qcap));
+    const unsigned qf = queue_uncached ? hipDeviceMallocUncached : hipDeviceMallocDefault;
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); MRT_HIP(L.thr[k].alloc(qcap, qf)); }
+    MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf)); MRT_HIP(L.scon.alloc(qcap, qf));
     MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     return MRT_OK;

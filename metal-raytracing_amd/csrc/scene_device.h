@@ -113,10 +113,10 @@ template <class T> struct DevBuf {
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-    hipError_t alloc(size_t count) {
+    hipError_t alloc(size_t count, unsigned flags = 0 /* hipDeviceMallocDefault; hipDeviceMallocUncached for streamed buffers (experiment) */) {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        hipError_t e = flags ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), flags) : hipMalloc((void **)&p, count * sizeof(T));
         if (e == hipSuccess) n = count; else p = nullptr;
         return e;
     }
