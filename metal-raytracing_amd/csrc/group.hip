@@ -130,7 +130,16 @@ int mrt_group_reduce_mode(MRTGroup g, int32_t *mode, char *note, size_t note_len
 }
 int mrt_group_set_reduce_mode(MRTGroup g, int32_t mode) {
     REQUIRE(g && (mode == MRT_REDUCE_RCCL || mode == MRT_REDUCE_PEER_COPY), "mrt_group_set_reduce_mode: mode must be 0 (RCCL) or 1 (peer copies)");
-    if (mode == MRT_REDUCE_RCCL && g->comms.empty() && g->ctx.size() > 1) { mrt::set_error("mrt_group_set_reduce_mode: this group has no RCCL communicators (" + g->reduce_note + ")"); return MRT_ERR_UNSUPPORTED; }
+    if (mode == MRT_REDUCE_RCCL && g->comms.empty()) {
+        // a one-device group has no communicator until it is asked for one (ncclReduce over one rank is a copy: it exercises the RCCL path on a one-GPU box)
+        const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == g->devices.size();
+        if (!distinct) { mrt::set_error("mrt_group_set_reduce_mode: this group has no RCCL communicators (" + g->reduce_note + ")"); return MRT_ERR_UNSUPPORTED; }
+        if (!g_rccl.load()) { mrt::set_error("mrt_group_set_reduce_mode: " + g_rccl.why); return MRT_ERR_UNSUPPORTED; }
+        g->comms.assign(g->devices.size(), nullptr);
+        ncclResult_t e = g_rccl.CommInitAll(g->comms.data(), (int)g->devices.size(), g->devices.data());
+        if (e != ncclSuccess) { g->comms.clear(); return rccl_fail(e, "ncclCommInitAll"); }
+        g->reduce_note = "ncclReduce(sum, float32) to rank 0";
+    }
     g->reduce = mode;
     return MRT_OK;
 }
@@ -224,7 +233,7 @@ int mrt_group_gather(MRTGroupRenderer gr, float *rgba, size_t nbytes) {
     const int n = (int)gr->r.size();
     hipStream_t s0 = g->ctx[0]->stream;
     auto src = [&](int rank) { mrt::Renderer &R = gr->r[(size_t)rank]->r; return R.accum[R.cur].p; };
-    if (n > 1 && g->reduce == MRT_REDUCE_RCCL) {
+    if (g->reduce == MRT_REDUCE_RCCL && !g->comms.empty()) {
         MRT_RCCL(g_rccl.GroupStart());
         for (int rank = 0; rank < n; rank++) {
             MRT_HIP(hipSetDevice(g->devices[(size_t)rank]));

@@ -22,6 +22,7 @@
 #include "traverse.h"
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -597,6 +598,9 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 5 : 6) k_trace_primary_wide_st
 #ifndef MRT_SHADE_THREADS
 #define MRT_SHADE_THREADS 256
 #endif
+#ifndef MRT_SHADE_XCD_BANDS
+#define MRT_SHADE_XCD_BANDS 0
+#endif
 constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
@@ -614,7 +618,16 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
     __shared__ unsigned long long blk_base;
     // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
     const uint32_t sub = sample_primary ? blockIdx.y : 0u;
-    const uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    // bounce 0 (hits in pixel-tile order): workgroup w runs on XCD w % 8, each with its own 4 MB L2.  A contiguous eighth of the image per XCD keeps that
+    // XCD's gathers (shading records, vertex normals: 21 MB over the whole image) inside its L2; the work per hit is uniform enough for the split to stay even.
+    uint32_t bx = blockIdx.x;
+#if MRT_SHADE_XCD_BANDS
+    if (sample_primary) {
+        const uint32_t per = (gridDim.x + 7u) >> 3;
+        bx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+#endif
+    const uint32_t slot = bx * SHADE_THREADS + threadIdx.x;
     const uint32_t i = sub * capacity + slot;
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
     bool active = slot < n;
@@ -1159,6 +1172,9 @@ int Renderer::render(int n_frames) {                                   // Render
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
     // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
     // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
+    // measuring aid (tools/gpu_r03t.sh): MRT_ABLATE=1 skips the primary launches, =2 the bounce / shadow traversal launches — the other kernels then run on the
+    // stale but well-formed queues of an earlier pass, so their load is realistic and the frame time shows what the skipped stage costs under overlap.  Images are garbage.
+    static const int ablate = getenv("MRT_ABLATE") ? atoi(getenv("MRT_ABLATE")) : 0;
     const bool mega = megakernel && !two_level && !materials && !wide && sv.num_wnodes > 0;
     const int batch_max = mega ? 1 : ((fused || two_level || materials) && !wide) ? alloc_batch : 1;
     fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
@@ -1237,7 +1253,8 @@ int Renderer::render(int n_frames) {                                   // Render
             auto timed = [&](int kind) -> EvPair * { if (ext_used >= (int)ev_ext.size()) return nullptr; ev_ext[ext_used].kind = kind; return &ev_ext[ext_used++]; };
             fp.bounce = 0;
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
-            if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
+            if (ablate & 1) {}
+            else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
             else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, (uint32_t *)nullptr);
             else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, primary_hint ? hint.p : (uint32_t *)nullptr);
@@ -1248,14 +1265,15 @@ int Renderer::render(int n_frames) {                                   // Render
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
-                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
+                const dim3 gs = b == 0 ? dim3(MRT_SHADE_XCD_BANDS ? (grid_shade + 7u) / 8u * 8u : grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
                 auto shade_kernel = materials ? (fp.htab ? k_shade<true, true> : k_shade<true, false>) : (fp.htab ? k_shade<false, true> : k_shade<false, false>);
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
-                if (on_wide && wide_stream && pull) {
+                if (ablate & 2) {}
+                else if (on_wide && wide_stream && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
                     // persist_chunk; 128-ray pulls of a one-frame launch are ~78 atomics per microsecond on the one counter word (limit ~88)
                     const size_t slots = 2 * (size_t)capacity * B;

@@ -62,3 +62,19 @@ def test_group_rejects_bad_arguments(mrt):
     assert lib.mrt_group_create(ids, 1, C.byref(g)) == 0
     assert lib.mrt_group_set_reduce_mode(g, 7) != 0
     assert lib.mrt_group_destroy(g) == 0
+
+
+def test_one_device_group_through_rccl(mrt, gpu_ctx):
+    """The RCCL path itself — dlopen of librccl, ncclCommInitAll, ncclGroupStart / ncclReduce(sum, float32, root 0) / ncclGroupEnd on the renderer's stream — on the one GPU
+    this box has: a reduce over one rank is a copy, so the gathered image must equal the renderer's."""
+    w, h = 160, 96
+    sc = mrt.CornellScene((w, h))
+    ref, _ = _plain(mrt, gpu_ctx, sc, w, h, 3)
+    with mrt.GroupRenderer((w, h), sc, [0]) as g:
+        g.set_reduce_mode(0)
+        mode, note = g.reduce_mode
+        assert mode == 0 and "ncclReduce" in note
+        g.draw(3)
+        img = g.gather()
+        again = g.gather()
+    assert np.array_equal(img, ref) and np.array_equal(again, ref)
