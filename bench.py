@@ -143,8 +143,8 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     # consistent with ms_per_step; profiles/r03_kernel_stats_serial4.csv is rocprofv3's view of the same regime)
     q.set_option("frame_batch", 4); q.draw(8, wait=True)
     four = {}
-    for _ in range(6):
-        q.draw(4, wait=True)
+    for _ in range(4):
+        q.draw(8, wait=True)             # two passes per call: the grid policy of a long call (half the wave slots per traversal launch), as in the default run and in the rocprofv3 trace
         for k, (ms, n) in q.kernel_times.items():
             if n:
                 four.setdefault(k, []).append(ms / n)
