@@ -447,6 +447,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "materials") { REQUIRE(value == 0 || (value == 1 && r->r.max_bounces <= 16), "materials must be 0 or 1 (and max_bounces <= 16: the lobe choice uses Halton dimension 2 + 5 * max_bounces + bounce < 100)"); r->r.materials = value != 0; }
     else if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
     else if (k == "primary_hint") r->r.primary_hint = value != 0;
+    else if (k == "throughput_chain") r->r.throughput_chain = value != 0;
     else if (k == "queue_uncached") { REQUIRE(r->r.lanes_ready == 0, "queue_uncached must be set before the first draw"); r->r.queue_uncached = value != 0; }
     else if (k == "halton_table") { REQUIRE(value == 0 || value == 1 || value == 2, "halton_table must be 0 (digit loops), 1 (table) or 2 (table for dimension 1 only)"); r->r.halton_table = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
@@ -476,6 +477,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "persistent") *value = r->r.persistent;
     else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;
     else if (k == "halton_table") *value = r->r.halton_table;
+    else if (k == "throughput_chain") *value = r->r.throughput_chain ? 1 : 0;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;

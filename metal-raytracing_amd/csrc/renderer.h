@@ -44,6 +44,7 @@ struct Renderer {
     bool primary_hint = true;
     DevBuf<float4> htab;                 // Halton table: 128-byte rows, one per Halton index the first 65 536 frames can reach (renderer.hip k_halton_table)
     DevBuf<float> hprim;                 // halton_table = 2: dimension 1 only
+    bool throughput_chain = true;        // bounce rays carry the resource slots of their path instead of a throughput record (renderer.hip FrameParams::chain)
     bool queue_uncached = false;         // experiment: ray / hit queues in uncached device memory (must be set before the first draw)
     int halton_table = 0;                // 0 = digit loops (default: measured fastest), 1 = full table, 2 = table for dimension 1 only
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)

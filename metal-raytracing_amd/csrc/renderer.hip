@@ -46,7 +46,11 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // Halton table (renderer option halton_table): row i = every value a path of up to HTAB_BOUNCES bounces draws for Halton index i, or nullptr
     // when this launch's indices / bounce are not covered (the kernels then run the digit loop of device_math.h)
     const float4 *htab;
-    const float *hprim;          // halton_table = 2: only dimension 1 of the pixel jitter (base 3, 13 digits: the longest digit loop), one float per index (4.4 MB)
+    const float *hprim;
+    // throughput chain (fused pipeline, diffuse-only, max_bounces <= 3, <= 65 536 resource slots): a bounce ray carries the resource slots of the surfaces its path has left
+    // (16 bits each, in the tmax word — always +inf for a bounce ray, and every traversal kernel takes it as such) instead of a 16-byte throughput record; the next
+    // shade multiplies the same base colours in the same order (Raytracing.metal:339), so the floats are the ones the record would have held
+    int32_t chain;          // halton_table = 2: only dimension 1 of the pixel jitter (base 3, 13 digits: the longest digit loop), one float per index (4.4 MB)
 };
 
 // The Halton values are a pure function of (index, dimension), the index is seed offset + frame < 2^20 + frames, and one frame evaluates ~22 M
@@ -198,7 +202,8 @@ __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *_
     if (i >= n_next + n_shadow) return;
     const bool shadow = i >= n_next;
     const uint32_t j = shadow ? i - n_next : i;
-    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
+    float4 A = shadow ? srayA[j] : rayA[j]; const float4 B = shadow ? srayB[j] : rayB[j];
+    if (!shadow) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
     TravHit h;
     bool hit = TWO_LEVEL ? traverse_instanced<false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, shadow) : traverse<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, nullptr, shadow);
     if (shadow) {
@@ -250,7 +255,8 @@ __global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const floa
     if (i >= n_next + n_shadow) return;
     const bool shadow = i >= n_next;
     const uint32_t j = shadow ? i - n_next : i;
-    const float4 A = shadow ? srayA[j] : rayA[j], B = shadow ? srayB[j] : rayB[j];
+    float4 A = shadow ? srayA[j] : rayA[j]; const float4 B = shadow ? srayB[j] : rayB[j];
+    if (!shadow) A.w = __builtin_inff();
     TravHit h;
     bool hit = traverse_wide<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk_dyn, nullptr, shadow);
     if (shadow) {
@@ -296,6 +302,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
@@ -332,6 +339,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_t
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
@@ -645,12 +653,20 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
     f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0), norg = mk3(0, 0, 0);
     float ldist = 0.0f; uint32_t pix = 0;
     bool special = false;                // next ray comes from a specular / dielectric lobe (materials extension): queued behind the diffuse ones
+    uint32_t chain_in = 0, chain_out = 0;   // throughput chain (FrameParams::chain)
     if (active) {
         float4 A, B, C;
         if (sample_primary) {
             A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
             B = qload(&rayB[i]);                                         // direction | sample index, written by the primary trace
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
+        } else if (fp.chain) {
+            A = qload(&rayA[i]); B = qload(&rayB[i]);
+            const uint32_t ch = __float_as_uint(A.w);          // slots of bounce 0 (low half) and, at bounce 2, of bounce 1 (high half)
+            chain_in = ch;
+            C = s.base_color[ch & 0xFFFFu];                     // (1, 1, 1) * surf0 == surf0
+            if (fp.bounce >= 2) { const float4 s1 = s.base_color[ch >> 16]; C = make_float4(C.x * s1.x, C.y * s1.y, C.z * s1.z, 0.0f); }
+            A.w = __builtin_inff();
         } else { A = qload(&rayA[i]); B = qload(&rayB[i]); C = qload(&thr[i]); }
         pix = __float_as_uint(B.w);
         uint4 ts; uint32_t inst, geom, vb = 0;
@@ -668,7 +684,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
                      (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
                      (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
         nrm = normalize3(n_w);                                           // :268
-        f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);  // :262-269
+        const uint32_t rslot = inst * (uint32_t)s.max_sub + geom;
+        f3 surf = mk3(s.base_color[rslot]);  // :262-269
+        if (fp.chain) chain_out = fp.bounce == 0 ? rslot : (chain_in & 0xFFFFu) | (rslot << 16);
         int idx = (int)(q2load(&seeds[pix]) + fp.sampleIndex);         // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
         // the five Halton values of this bounce: one 32-byte segment of the table row, or the digit loops (wave-uniform choice)
@@ -804,9 +822,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
     if (want_next) {
         const bool sp = MATERIALS && special;
         uint32_t ns = (uint32_t)base + (sp ? w_spec[wv] + (uint32_t)__popcll(m_sp & lt) : w_next[wv] + (uint32_t)__popcll(m_nx & lt));
-        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, __builtin_inff()));      // :390
+        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, fp.chain ? __uint_as_float(chain_out) : __builtin_inff()));      // :390 (tmax = inf either way, see FrameParams::chain)
         qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
-        qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
+        if (!fp.chain) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
     }
 }
 
@@ -1095,7 +1113,8 @@ int Renderer::alloc_queues() {
 
 size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
-    return (10 * qcap + (size_t)width * height * (size_t)std::max(1, alloc_batch)) * sizeof(float4);
+    const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
+    return ((need_thr ? 10 : 8) * qcap + (size_t)width * height * (size_t)std::max(1, alloc_batch)) * sizeof(float4);
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
@@ -1104,7 +1123,8 @@ void Renderer::release_lane(FrameLane &L) {
 int Renderer::alloc_lane(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
     const unsigned qf = queue_uncached ? hipDeviceMallocUncached : hipDeviceMallocDefault;
-    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); MRT_HIP(L.thr[k].alloc(qcap, qf)); }
+    const bool need_thr = !(throughput_chain && (fused || scene->num_inst) && !use_wide && !materials && max_bounces <= 3);      // else on demand (render())
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); if (need_thr) MRT_HIP(L.thr[k].alloc(qcap, qf)); }
     MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf)); MRT_HIP(L.scon.alloc(qcap, qf));
     MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
@@ -1252,6 +1272,11 @@ int Renderer::render(int n_frames) {                                   // Render
             // other frames in flight (+12 % at 12 frames)
             auto timed = [&](int kind) -> EvPair * { if (ext_used >= (int)ev_ext.size()) return nullptr; ev_ext[ext_used].kind = kind; return &ev_ext[ext_used++]; };
             fp.bounce = 0;
+            fp.chain = (throughput_chain && !materials && max_bounces <= 3 && (uint64_t)scene->stats.instances * (uint64_t)std::max(1, scene->stats.max_submeshes) <= 65536ull) ? 1 : 0;
+            if (!fp.chain && !L.thr[0].p) {           // this draw needs the throughput queues after all (materials, more than three bounces, a very large resource table)
+                const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
+                for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap));
+            }
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
             if (ablate & 1) {}
             else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
@@ -1306,6 +1331,8 @@ int Renderer::render(int n_frames) {                                   // Render
             }
         } else {
             // unfused sequence: raygen -> per bounce { extend, shade, shadow }
+            fp.chain = 0;
+            if (!L.thr[0].p) { const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch); for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap)); }
             hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
             int q = 0;
             for (int b = 0; b < max_bounces; b++) {
