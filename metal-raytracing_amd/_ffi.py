@@ -245,6 +245,8 @@ def _share_hip_runtime_with_torch():
 HIP_RUNTIME_PRELOADED = _share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
+    if os.environ.get("MRT_LIB_PATH") and not hasattr(lib, _name):
+        continue                       # an A/B build of an older tree (tools/build_variant.sh): entry points added since are simply absent
     _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch: fail loudly
     _fn.restype, _fn.argtypes = _res, _args
 

@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64, TWO_LEVEL ? 5 : 6) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
+__global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
@@ -606,6 +606,9 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? 5 : 6) k_trace_primary_wide_st
 #ifndef MRT_SHADE_THREADS
 #define MRT_SHADE_THREADS 256
 #endif
+#ifndef MRT_SHADE_WAVES
+#define MRT_SHADE_WAVES 6     // waves per SIMD k_shade is compiled for: it needs 76-78 registers; capped at 72 (7 waves) it spills 16-48 bytes and the frame is 4 % slower, at 64 (8 waves) 6 % slower
+#endif
 #ifndef MRT_SHADE_XCD_BANDS
 #define MRT_SHADE_XCD_BANDS 0
 #endif
@@ -613,8 +616,8 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool TAB>      // TAB: the bounce's Halton values come from the table (fp.htab covers this launch); else the digit loops
-__global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+template <bool MATERIALS, bool TAB, bool CHAIN>      // TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
+__global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
@@ -660,7 +663,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
             A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
             B = qload(&rayB[i]);                                         // direction | sample index, written by the primary trace
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
-        } else if (fp.chain) {
+        } else if (CHAIN) {
             A = qload(&rayA[i]); B = qload(&rayB[i]);
             const uint32_t ch = __float_as_uint(A.w);          // slots of bounce 0 (low half) and, at bounce 2, of bounce 1 (high half)
             chain_in = ch;
@@ -686,7 +689,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
         nrm = normalize3(n_w);                                           // :268
         const uint32_t rslot = inst * (uint32_t)s.max_sub + geom;
         f3 surf = mk3(s.base_color[rslot]);  // :262-269
-        if (fp.chain) chain_out = fp.bounce == 0 ? rslot : (chain_in & 0xFFFFu) | (rslot << 16);
+        if (CHAIN) chain_out = fp.bounce == 0 ? rslot : (chain_in & 0xFFFFu) | (rslot << 16);
         int idx = (int)(q2load(&seeds[pix]) + fp.sampleIndex);         // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
         // the five Halton values of this bounce: one 32-byte segment of the table row, or the digit loops (wave-uniform choice)
@@ -822,9 +825,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, 7) k_shade(SceneView s, FramePa
     if (want_next) {
         const bool sp = MATERIALS && special;
         uint32_t ns = (uint32_t)base + (sp ? w_spec[wv] + (uint32_t)__popcll(m_sp & lt) : w_next[wv] + (uint32_t)__popcll(m_nx & lt));
-        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, fp.chain ? __uint_as_float(chain_out) : __builtin_inff()));      // :390 (tmax = inf either way, see FrameParams::chain)
+        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, CHAIN ? __uint_as_float(chain_out) : __builtin_inff()));      // :390 (tmax = inf either way, see FrameParams::chain)
         qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
-        if (!fp.chain) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
+        if (!CHAIN) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
     }
 }
 
@@ -1291,7 +1294,8 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(MRT_SHADE_XCD_BANDS ? (grid_shade + 7u) / 8u * 8u : grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                auto shade_kernel = materials ? (fp.htab ? k_shade<true, true> : k_shade<true, false>) : (fp.htab ? k_shade<false, true> : k_shade<false, false>);
+                auto shade_kernel = materials ? (fp.htab ? k_shade<true, true, false> : k_shade<true, false, false>)
+                                              : fp.chain ? (fp.htab ? k_shade<false, true, true> : k_shade<false, false, true>) : (fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>);
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
@@ -1343,7 +1347,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
                 if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                hipLaunchKernelGGL((fp.htab ? k_shade<false, true> : k_shade<false, false>), dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
+                hipLaunchKernelGGL((fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>), dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
                                    L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);

@@ -1,0 +1,13 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03y; mkdir -p $O; cd $R
+V=$R/metal-raytracing_amd/variants
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+b() { python3 bench.py --steps ${STEPS:-240} --warmup ${WARM:-24} --no-cpu-baseline --no-latency --no-strict "$@" 2> $O/last.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('   value', d['value'], 'ms/step', d['ms_per_step'])" || tail -3 $O/last.err; }
+for rep in 1 2 3; do
+  echo "at_nt long"; MRT_LIB_PATH=$V/libmrt_hip_at_nt.so b; echo "at_nt 20"; MRT_LIB_PATH=$V/libmrt_hip_at_nt.so STEPS=20 WARM=5 b
+  echo "head long"; b; echo "head 20"; STEPS=20 WARM=5 b
+  echo "head thr long"; b --opt throughput_chain=0; echo "head thr 20"; STEPS=20 WARM=5 b --opt throughput_chain=0
+done
+bash tools/collect_profiles.sh r03 > $R/gpurun_out/collect_r03.log 2>&1; grep -E "ok$|failed" $R/gpurun_out/collect_r03.log | head -20
