@@ -456,6 +456,16 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "wide_stream") r->r.wide_stream = value != 0;
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
     else if (k == "primary_wide") r->r.primary_wide = value != 0;
+    else if (k == "flow") { REQUIRE(value == 0 || value == 1, "flow must be 0 or 1"); r->r.flow = (int)value; }
+    else if (k == "flow_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "flow_chunk must be a multiple of 64 in [64, 65536]"); r->r.flow_chunk = (int)value; }
+    else if (k == "flow_take") { REQUIRE(value >= 1 && value <= 16, "flow_take must be in [1, 16]"); r->r.flow_take = (int)value; }
+    else if (k == "flow_session_rays") { REQUIRE(value >= 64 && value <= (1 << 20), "flow_session_rays must be in [64, 2^20]"); r->r.flow_session_rays = (int)value; }
+    else if (k == "flow_granule") { REQUIRE(value >= 64 && value <= 4096 && ((int)value % 64) == 0, "flow_granule must be a multiple of 64 in [64, 4096]"); r->r.flow_granule = (int)value; }
+    else if (k == "flow_mix") r->r.flow_mix = value != 0;
+    else if (k == "flow_order") { REQUIRE(value == 0 || value == 1, "flow_order must be 0 or 1"); r->r.flow_order = (int)value; }
+    else if (k == "flow_exit_rays") { REQUIRE(value >= 0 && value <= 65536, "flow_exit_rays must be in [0, 65536]"); r->r.flow_exit_rays = (int)value; }
+    else if (k == "flow_idle_polls") { REQUIRE(value >= 0 && value <= 65536, "flow_idle_polls must be in [0, 65536]"); r->r.flow_idle_polls = (int)value; }
+    else if (k == "flow_slots") { REQUIRE(value >= 0 && value <= (1 << 20), "flow_slots must be in [0, 2^20]"); r->r.flow_slots = (int)value; }
     else if (k == "wide") r->r.use_wide = value != 0;
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
@@ -484,6 +494,16 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "wide_stream") *value = r->r.wide_stream ? 1 : 0;
     else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;
     else if (k == "primary_wide") *value = r->r.primary_wide ? 1 : 0;
+    else if (k == "flow") *value = r->r.flow;
+    else if (k == "flow_chunk") *value = r->r.flow_chunk;
+    else if (k == "flow_take") *value = r->r.flow_take;
+    else if (k == "flow_session_rays") *value = r->r.flow_session_rays;
+    else if (k == "flow_granule") *value = r->r.flow_granule;
+    else if (k == "flow_mix") *value = r->r.flow_mix;
+    else if (k == "flow_order") *value = r->r.flow_order;
+    else if (k == "flow_exit_rays") *value = r->r.flow_exit_rays;
+    else if (k == "flow_idle_polls") *value = r->r.flow_idle_polls;
+    else if (k == "flow_slots") *value = r->r.flow_slots > 0 ? r->r.flow_slots : r->r.flow_slots_auto;
     else if (k == "wide") *value = r->r.use_wide ? 1 : 0;
     else if (k == "sample_offset") *value = r->r.sample_offset;
     else { mrt::set_error("mrt_renderer_get_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }

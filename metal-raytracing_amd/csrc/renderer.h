@@ -20,6 +20,12 @@ struct FrameLane {
     DevBuf<float4> sample;               // [sub-frame][pixel] radiance of the batch's frames
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
+    // flow passes (renderer option flow = 1, flow.h): the bounces' queues are all live at once, so every bounce has its own shadow queue, hit records and
+    // contribution plane; allocated at the first flow pass of the lane
+    DevBuf<float4> f_dirs, f_sA[2], f_sB[2], f_hits[2], f_con[2];
+    DevBuf<uint8_t> f_lit;               // [bounce][sub-frame][pixel]
+    DevBuf<uint32_t> f_words;            // FW_* header + the queues' ready rings
+    DevBuf<const void *> f_tab;          // the kernel's table of pointers to all of these (flow.h FT_*)
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 constexpr int MAX_FRAME_BATCH = 32;
@@ -65,6 +71,19 @@ struct Renderer {
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it
     size_t slots_for_stack = ~(size_t)0;
+    // one launch per pass after the primary trace: chunks of rays flow from stage to stage inside it (flow.h); diffuse path, max_bounces <= 3, flattened scenes
+    int flow = 0;
+    int flow_chunk = 512;                // primary slots per stage-0 session (multiple of 64; smaller when the pass is small)
+    int flow_take = 8;                   // K: descriptors a traversal session pulls at a time
+    int flow_session_rays = 2048;        // rays a traversal session starts before it drains and shades its hits
+    int flow_granule = 128;              // rays per descriptor
+    int flow_mix = 1;                    // a traversal session that traces bounce rays fills up with shadow rays
+    int flow_order = 1;                  // 1: the shallowest stage with work first, 0: the deepest
+    int flow_idle_polls = 4096;          // polls without work before a wave leaves the launch whatever is outstanding (a bound, not a policy)
+    int flow_exit_rays = 512;            // a wave without work leaves when fewer rays than this PER WAVE of the launch are outstanding in the pass
+    int flow_slots = 0;                  // waves of the launch; 0 = the occupancy query's answer
+    int flow_slots_auto = 0; size_t flow_slots_for_stack = ~(size_t)0;
+    int alloc_flow(FrameLane &L);
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)

@@ -880,6 +880,8 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
     q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
+#include "flow.h"
+
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
 __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4 *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1114,14 +1116,39 @@ int Renderer::alloc_queues() {
     return MRT_OK;
 }
 
+// descriptors a flow queue's ready ring can hold: a session publishes its rays in granules of >= 64, the last one partly filled
+static inline size_t flow_written_words(size_t qcap) { return 2 * (qcap >> 6) + 4; }
 size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
     const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
-    return ((need_thr ? 10 : 8) * qcap + (size_t)width * height * (size_t)std::max(1, alloc_batch)) * sizeof(float4);
+    const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    const size_t flow_bytes = flow ? (7 * qcap + 2 * spix) * sizeof(float4) + spix * FLOW_MAX_BOUNCES + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0;
+    return ((need_thr ? 10 : 8) * qcap + spix) * sizeof(float4) + flow_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
     L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release();
+    L.f_dirs.release(); L.f_lit.release(); L.f_words.release(); L.f_tab.release();
+    for (int k = 0; k < 2; k++) { L.f_sA[k].release(); L.f_sB[k].release(); L.f_hits[k].release(); L.f_con[k].release(); }
+}
+int Renderer::alloc_flow(FrameLane &L) {
+    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch), spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    MRT_HIP(L.f_dirs.alloc(qcap));
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.f_sA[k].alloc(qcap)); MRT_HIP(L.f_sB[k].alloc(qcap)); MRT_HIP(L.f_hits[k].alloc(qcap)); MRT_HIP(L.f_con[k].alloc(spix)); }
+    MRT_HIP(L.f_lit.alloc(spix * FLOW_MAX_BOUNCES));
+    const size_t ww = flow_written_words(qcap);
+    MRT_HIP(L.f_words.alloc(FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * ww));      // header + five rings of 64-bit descriptors
+    // the kernel's table of pointers (flow.h FT_*)
+    const void *tab[FT_COUNT] = {};
+    for (int k = 0; k < 2; k++) { tab[FT_QA + k] = L.rayA[k].p; tab[FT_QB + k] = L.rayB[k].p; }
+    tab[FT_SA] = L.srayA.p; tab[FT_SB] = L.srayB.p; tab[FT_HITS] = L.hits.p; tab[FT_CON] = L.sample.p;
+    for (int k = 0; k < 2; k++) { tab[FT_SA + 1 + k] = L.f_sA[k].p; tab[FT_SB + 1 + k] = L.f_sB[k].p; tab[FT_HITS + 1 + k] = L.f_hits[k].p; tab[FT_CON + 1 + k] = L.f_con[k].p; }
+    for (int k = 0; k < FLOW_MAX_BOUNCES; k++) tab[FT_LIT + k] = L.f_lit.p + (size_t)k * spix;
+    for (int k = 0; k < FLOW_QUEUES; k++) tab[FT_RING + k] = reinterpret_cast<unsigned long long *>(L.f_words.p + FLOW_HEADER_WORDS) + (size_t)k * ww;
+    tab[FT_DIRS] = L.f_dirs.p;
+    MRT_HIP(L.f_tab.alloc(FT_COUNT));
+    MRT_HIP(hipMemcpy(L.f_tab.p, tab, sizeof tab, hipMemcpyHostToDevice));
+    return MRT_OK;
 }
 int Renderer::alloc_lane(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
@@ -1230,6 +1257,7 @@ int Renderer::render(int n_frames) {                                   // Render
         const float4 *const htab_pass = (halton_table == 1 && htab.p && covered) ? htab.p : nullptr;
         fp.htab = htab_pass;
         fp.hprim = (halton_table == 2 && hprim.p && covered) ? hprim.p : nullptr;
+        bool flow_pass = false;
         if (mega) {
             // one launch per frame on the pass's stream; frames are sequential (a path's last act is the running average with the previous target)
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
@@ -1281,13 +1309,54 @@ int Renderer::render(int n_frames) {                                   // Render
                 for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap));
             }
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
+            // flow pass (flow.h): after the primary trace ONE launch carries the pass; the bounces' queues, hit records and contribution planes are all live at once
+            flow_pass = flow != 0 && fp.chain && on_wide && wide_stream && !two_level && !materials && max_bounces <= FLOW_MAX_BOUNCES && (size_t)capacity * B < (size_t(1) << 27) && !ablate;
+            FlowArgs fa{};
+            if (flow_pass) {
+                if (!L.f_words.p) { if (int rc = alloc_flow(L)) return rc; }
+                const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch), spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+                (void)qcap;
+                fa.counts = bc; fa.words = L.f_words.p;
+                fa.tab = L.f_tab.p;
+                fa.n_primary = (uint32_t)((size_t)capacity * B);
+                fa.idle_polls = (uint32_t)std::max(0, flow_idle_polls);
+                fa.exit_rays = 0;         // (set below, with the launch's size)
+                fa.take = (uint32_t)std::max(1, std::min(flow_take, (int)FLOW_MAX_TAKE));
+                fa.granule = (uint32_t)std::max(64, flow_granule) / 64u * 64u;
+                fa.session_rays = (uint32_t)std::min<size_t>((size_t)std::max(64, flow_session_rays), (size_t)60 * fa.granule);
+                fa.lit_stride = (uint32_t)spix; fa.mix = flow_mix != 0 ? 1u : 0u;
+                fa.breadth_first = flow_order != 0 ? 1u : 0u;
+                if (flow_slots_for_stack != stack_bytes) {
+                    int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+                    MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
+                    MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow, 64, stack_bytes));
+                    flow_slots_auto = std::max(1, per_cu) * prop.multiProcessorCount; flow_slots_for_stack = stack_bytes;
+                }
+                // primary slots per stage-0 session: at least two sessions per wave of the launch, so that every wave starts with work and the stage ends evenly
+                const size_t slots = (size_t)(flow_slots > 0 ? flow_slots : flow_slots_auto);
+                uint32_t chunk = (uint32_t)std::max(64, flow_chunk) / 64u * 64u;
+                while (chunk > 64u && (size_t)fa.n_primary / chunk < 2 * slots) chunk -= 64u;
+                chunk = std::min(chunk, 64u * fa.granule);                  // a session publishes at most 64 descriptors per queue
+                fa.chunk = chunk;
+                fa.exit_rays = (uint32_t)std::min<size_t>((size_t)std::max(0, flow_exit_rays) * slots + 1, 0x7FFFFFFFu);
+                MRT_HIP(hipMemsetAsync(L.f_words.p, 0, L.f_words.bytes(), st));
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, (size_t)max_bounces * spix, st));
+            }
+            float4 *const dirs = flow_pass ? L.f_dirs.p : L.rayB[1].p;
             if (ablate & 1) {}
-            else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
-            else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, capacity, rpw_p);
-            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, (uint32_t *)nullptr);
-            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, L.rayB[1].p, primary_hint ? hint.p : (uint32_t *)nullptr);
+            else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
+            else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
+            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
+            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
+            if (flow_pass) {
+                const size_t slots = (size_t)(flow_slots > 0 ? flow_slots : flow_slots_auto);
+                const size_t sessions = cdiv(fa.n_primary, fa.chunk);
+                launch_timed(timed(MRT_KERNEL_TRACE), k_flow, dim3((uint32_t)std::max<size_t>(1, std::min(slots, sessions))), dim3(64), stack_bytes, st, sv, fp, fa, (const uint32_t *)seeds.p);
+                if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
+                launch_timed(timed(MRT_KERNEL_ACCUMULATE), k_accumulate_flow, dim3(grid), dim3(64), 0, st, fp, fa, (const float4 *)accum[cur].p, accum[1 - cur].p, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+            }
             int q = 0;                                                  // shade(b) writes next rays into queue q
-            for (int b = 0; b < max_bounces; b++) {
+            for (int b = 0; b < max_bounces && !flow_pass; b++) {
                 fp.bounce = b;
                 fp.htab = (uint32_t)b < HTAB_BOUNCES ? htab_pass : nullptr;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
@@ -1355,8 +1424,8 @@ int Renderer::render(int n_frames) {                                   // Render
             }
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
-        if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        {
+        if (last_acc && !flow_pass) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
+        if (!flow_pass) {
             EvPair *ev = nullptr;
             if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
             launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
@@ -1393,6 +1462,20 @@ static int check_bounds_record() { return MRT_OK; }
 
 int Renderer::wait() {
     MRT_HIP(hipStreamSynchronize(stream));
+#ifdef MRT_FLOW_STATS
+    if (lanes[0].f_words.p) {         // the last pass of lane 0: ticks of 10 ns summed over the launch's waves
+        std::vector<uint32_t> w(FLOW_HEADER_WORDS);
+        MRT_HIP(hipMemcpy(w.data(), lanes[0].f_words.p, FLOW_HEADER_WORDS * 4, hipMemcpyDeviceToHost));
+        auto W = [&](int k) { return (double)w[(FW_STATS + k) * FLOW_LINE]; };
+        fprintf(stderr, "flow queues: Q %u %u %u, SQ %u %u %u, pending+primary %u, errors %u, tails %u %u %u %u %u, heads %u %u %u %u %u\n", w[FW_TRUE_Q * FLOW_LINE], w[(FW_TRUE_Q + 1) * FLOW_LINE], w[(FW_TRUE_Q + 2) * FLOW_LINE],
+                w[FW_TRUE_S * FLOW_LINE], w[(FW_TRUE_S + 1) * FLOW_LINE], w[(FW_TRUE_S + 2) * FLOW_LINE], w[FW_PENDING * FLOW_LINE] + (uint32_t)((size_t)capacity * alloc_batch), w[FW_ERROR * FLOW_LINE],
+                w[FW_TAIL * FLOW_LINE], w[(FW_TAIL + 1) * FLOW_LINE], w[(FW_TAIL + 2) * FLOW_LINE], w[(FW_TAIL + 3) * FLOW_LINE], w[(FW_TAIL + 4) * FLOW_LINE],
+                w[FW_HEAD * FLOW_LINE], w[(FW_HEAD + 1) * FLOW_LINE], w[(FW_HEAD + 2) * FLOW_LINE], w[(FW_HEAD + 3) * FLOW_LINE], w[(FW_HEAD + 4) * FLOW_LINE]);
+        fprintf(stderr, "flow claims: %.0f calls, %.0f descriptors, %.1f ms in successful claims, %.1f ms in contested ones\n", W(11), W(15), W(0) * 1e-5, W(2) * 1e-5);
+        fprintf(stderr, "flow stats (lane 0, last pass): waves %.0f, wave time %.1f ms: traversal sessions %.1f (%.0f sessions, %.0f bounce rays, %.0f shadow rays), shade %.1f (%.0f sessions, %.0f rays), publish %.1f, idle %.1f (%.0f polls)\n",
+                W(14), W(7) * 1e-5, W(1) * 1e-5, W(10), W(8), W(9), W(3) * 1e-5, W(13), W(12), W(6) * 1e-5, W(4) * 1e-5, W(5));
+    }
+#endif
     if (int rc = check_bounds_record()) return rc;
     { uint64_t done = 0; if (int rc = poll_completed(&done)) return rc; }
     if (pending_timing) {
@@ -1443,6 +1526,7 @@ int Renderer::stats(MRTRenderStats *out) {
     unsigned long long t[4];
     MRT_HIP(hipMemcpy(t, totals.p, sizeof t, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
+    if (t[3] != 0) { set_error("flow: " + std::to_string(t[3]) + " pass(es) ended with rays left in their queues"); return MRT_ERR_STATE; }
     out->frames = frames_rendered; out->closest_rays = t[0]; out->shadow_rays = t[1]; out->primary_rays = t[2];
     // 96 B per closest ray, 72 B per shadow ray, 36 B per pixel (20 on frame 0), + one read of the scene per frame
     uint64_t px = owned_pixels;

@@ -1,0 +1,75 @@
+"""Flow passes (renderer option flow = 1, csrc/flow.h): after the primary trace ONE launch carries a pass; chunks of rays are handed from wave to
+wave inside it.  The image must be the wavefront pipeline's, and the oracle's, bit for bit — whatever the chunk size, the session length, the
+number of waves, and however early idle waves leave."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def render(mrt, ctx, sc, size, frames, draws=1, **opts):
+    r = mrt.Renderer(size, sc, ctx=ctx)
+    for k, v in opts.items():
+        r.set_option(k, v)
+    for _ in range(draws):
+        r.draw(frames, wait=True)
+    img = r.accumulation().copy(); st = r.stats
+    r.close()
+    return img, st
+
+
+@pytest.fixture(scope="module")
+def small_dragon(mrt, gpu_ctx):
+    sc = mrt.DragonScene((320, 200))
+    ref, st0 = render(mrt, gpu_ctx, sc, (320, 200), 8, draws=2)
+    r = mrt.Renderer((320, 200), sc, ctx=gpu_ctx)
+    r.set_option("flow", 1)
+    yield r, ref, st0
+    r.close()
+
+
+DEFAULTS = dict(flow_chunk=512, flow_take=8, flow_granule=128, flow_session_rays=2048, flow_mix=1, flow_order=1, flow_slots=0, flow_idle_polls=4096, flow_exit_rays=512, frame_batch=4, frames_in_flight=12)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(flow_chunk=64, flow_take=1, flow_granule=64, flow_session_rays=64), dict(flow_chunk=4096, flow_take=16, flow_granule=512, flow_session_rays=65536), dict(flow_order=0), dict(flow_mix=0), dict(flow_take=2, flow_session_rays=64), dict(flow_slots=64), dict(flow_slots=1),
+                                  dict(flow_idle_polls=0), dict(flow_exit_rays=0), dict(flow_exit_rays=65536), dict(frame_batch=1), dict(frame_batch=8, frames_in_flight=2)], ids=str)
+def test_flow_image_is_the_pipelines(small_dragon, opts):
+    r, ref, st0 = small_dragon
+    for k, v in {**DEFAULTS, **opts}.items():
+        r.set_option(k, v)
+    r.frameIndex = 0; r.reset_stats()
+    r.draw(8, wait=True); r.draw(8, wait=True)
+    st1 = r.stats
+    assert np.array_equal(r.accumulation().view(np.uint32), ref.view(np.uint32))
+    assert (st1.closest_rays, st1.shadow_rays, st1.primary_rays) == (st0.closest_rays, st0.shadow_rays, st0.primary_rays)
+
+
+@pytest.mark.parametrize("bounces", [1, 2, 3])
+def test_flow_matches_oracle(mrt, orc, gpu_ctx, bounces):
+    from test_gpu_parity import assert_parity, oracle_render
+    sc = mrt.CornellScene((96, 96))
+    ref, _ = oracle_render(orc, mrt, sc, 96, 96, 3, bounces=bounces)
+    r = mrt.Renderer((96, 96), sc, ctx=gpu_ctx, max_bounces=bounces)
+    r.set_option("flow", 1)
+    r.draw(3, wait=True)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    r.close()
+
+
+def test_flow_1080p_dragon_and_ragged_size(mrt, gpu_ctx):
+    sc = mrt.DragonScene((1920, 1080))
+    ref, st0 = render(mrt, gpu_ctx, sc, (1920, 1080), 12)
+    img, st1 = render(mrt, gpu_ctx, sc, (1920, 1080), 12, flow=1)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert (st1.closest_rays, st1.shadow_rays) == (st0.closest_rays, st0.shadow_rays)
+    ref, _ = render(mrt, gpu_ctx, sc, (333, 211), 5)
+    img, _ = render(mrt, gpu_ctx, sc, (333, 211), 5, flow=1, frames_in_flight=3)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_flow_falls_back_where_it_does_not_apply(mrt, gpu_ctx):
+    """materials, more than three bounces: the option is accepted and the wavefront pipeline runs"""
+    sc = mrt.CornellScene((160, 100))
+    ref, _ = render(mrt, gpu_ctx, sc, (160, 100), 4, materials=1)
+    img, _ = render(mrt, gpu_ctx, sc, (160, 100), 4, materials=1, flow=1)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
