@@ -257,7 +257,6 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
     MRT_TRY
     REQUIRE(scene && rays && out8 && per_wave >= 64 && nwaves * (size_t)per_wave >= n, "mrt_debug_stream_stats: bad argument");
     if (!scene->committed) { mrt::set_error("mrt_debug_stream_stats: scene not committed"); return MRT_ERR_STATE; }
-    if (scene->dev.num_inst) { mrt::set_error("mrt_debug_stream_stats: not available for two-level scenes"); return MRT_ERR_UNSUPPORTED; }
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::query_stream_stats(scene->dev, scene->ctx->stream, rays, n, any_hit, per_wave, out8, nwaves);
     MRT_CATCH

@@ -287,10 +287,13 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
     return 64u * (uint32_t)std::min<size_t>(16, std::max<size_t>(6, batches));
 }
 #ifndef MRT_WIDE_STREAM_WAVES
+#ifndef MRT_TWO_LEVEL_WAVES
+#define MRT_TWO_LEVEL_WAVES 6
+#endif
 #define MRT_WIDE_STREAM_WAVES (MRT_WIDE_SPEC ? 6 : 7)      // the second triangle group costs two registers: 80 instead of 72 (no spills); the frame rate does not depend on 6 or 7 waves per SIMD
 #endif
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+__global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave) {
     extern __shared__ uint32_t stk_dyn[];
@@ -320,7 +323,7 @@ __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: ite
 // Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
 // `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
 template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64, TWO_LEVEL ? 6 : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+__global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
                                                                 const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk) {
     extern __shared__ uint32_t stk_dyn[];
@@ -948,6 +951,7 @@ __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *_
 }
 
 // stream-traversal lane accounting (diagnostics): per wave {iterations, sum of live lanes, node lanes, tri lanes, refills, refilled lanes}
+template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t per_wave, uint32_t depth, uint32_t *__restrict__ out) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * per_wave;
@@ -955,7 +959,7 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     const uint32_t end = min(n, begin + per_wave);
     StreamStats ss{0, 0, 0, 0, 0, 0};
     uint32_t sink = 0;
-    traverse_wide_stream(s, OneRange{begin, end}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, end}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
             A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
@@ -1589,7 +1593,9 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * nwaves));
     MRT_HIP(hipMemsetAsync(d_o.p, 0, 32 * nwaves, stream));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_query_stream_stats, dim3((uint32_t)nwaves), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
+    const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : 0);
+    if (sc.num_inst) hipLaunchKernelGGL(k_query_stream_stats<true>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
+    else hipLaunchKernelGGL(k_query_stream_stats<false>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());

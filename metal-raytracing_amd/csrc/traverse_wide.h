@@ -39,6 +39,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_SPEC
 #define MRT_WIDE_SPEC 1     // flattened scenes: a lane that still has triangles to test visits its next node anyway and keeps that node's triangles in a second group (below)
 #endif
+#ifndef MRT_WIDE_SPEC_TWO_LEVEL
+#define MRT_WIDE_SPEC_TWO_LEVEL 0     // the same inside the BLASes of two-level scenes: measured twice, no gain
+#endif
 #if MRT_WIDE_DUAL_TRI && MRT_WIDE_SPEC
 #error "MRT_WIDE_DUAL_TRI predates the second triangle group of MRT_WIDE_SPEC and is wrong with it (it consumes the first group behind the node test's back): build with -DMRT_WIDE_SPEC=0"
 #endif
@@ -290,8 +293,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     // are occupied.  The visit sees a limit the pending triangles may still shorten — more children accepted than strictly needed, never fewer — and the
     // closest hit stays the minimum over (t, id) whatever the order: the image is unchanged.  A ray then needs about max(node visits, triangle tests)
     // iterations instead of their sum.
-    // (two-level scenes: tried inside the BLASes — 84 instead of 80 registers and no faster, 6.27 vs 6.38 Grays/s on dragon x 4; left off there)
-    constexpr bool SPEC = !TWO_LEVEL && MRT_WIDE_SPEC != 0;
+    // (two-level scenes: tried inside the BLASes, MRT_WIDE_SPEC_TWO_LEVEL — 86 instead of 80 registers and no faster, twice: 6.27 vs 6.38 and 6.65 vs 6.63 Grays/s on dragon x 4; left off there)
+    constexpr bool SPEC = (TWO_LEVEL ? MRT_WIDE_SPEC_TWO_LEVEL : MRT_WIDE_SPEC) != 0;
     uint32_t u_base = 0, u_mask = 0;
     for (;;) {
         const unsigned long long m_idle = __ballot(!live);
@@ -350,7 +353,9 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     }
                 }
                 batch_used += min(avail, n_idle);
+#ifndef MRT_STATS_BOTH
                 if (ss) { ss->refills++; ss->refill_lanes += min(avail, n_idle); }
+#endif
                 continue;
             }
         }
@@ -466,6 +471,9 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
         if (ss) { ss->tri_sum += (uint32_t)__popcll(__ballot(has_tri)); ss->node_sum += (uint32_t)__popcll(__ballot(want_node)); }
+#ifdef MRT_STATS_BOTH      // diagnostics build (tools/two_level_probe.py): in place of the refill counters, lane-iterations that do a triangle AND a node / that enter an instance
+        if (ss) { ss->refills += (uint32_t)__popcll(__ballot(has_tri && want_node)); ss->refill_lanes += (uint32_t)__popcll(__ballot(TWO_LEVEL && has_inst)); }
+#endif
         float4 r0, r1, r2, n0, n1, n2, n3, n4;        // loaded under has_tri / want_node and used under the same predicates;
         // an empty asm "defines" them on the other paths without the 28 v_mov a zero initialiser costs per iteration
         asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r2.x), "=v"(r2.y), "=v"(r2.z));
