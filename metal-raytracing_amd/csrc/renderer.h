@@ -84,6 +84,8 @@ struct Renderer {
     int flow_slots = 0;                  // waves of the launch; 0 = the occupancy query's answer
     int flow_slots_auto = 0; size_t flow_slots_for_stack = ~(size_t)0;
     int alloc_flow(FrameLane &L);
+    int alloc_planes(FrameLane &L);
+    int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)

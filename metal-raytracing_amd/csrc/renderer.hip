@@ -295,7 +295,7 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave, uint8_t *__restrict__ lit) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -306,10 +306,14 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
             if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
+            else if (lit) tag = __float_as_uint(B.w);   // shadow planes: the ray reports to its pixel's byte
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
-                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
+                if (!hit) {
+                    if (lit) lit[j] = 1;
+                    else { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
+                }
             } else {
                 qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
@@ -325,7 +329,7 @@ __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: ite
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -343,10 +347,14 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
             if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
+            else if (lit) tag = __float_as_uint(B.w);   // shadow planes: the ray reports to its pixel's byte
         },
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
-                if (!hit) { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
+                if (!hit) {
+                    if (lit) lit[j] = 1;
+                    else { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
+                }
             } else {
                 qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
@@ -619,7 +627,7 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool TAB, bool CHAIN>      // TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
+template <bool MATERIALS, bool TAB, bool CHAIN, bool PLANES = false>      // PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
 __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
@@ -650,7 +658,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
     if (sample_primary) {
         active = active && slot_to_pixel(fp, slot, px_x, px_y);
         spix = sub * fp.npix + (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-        if (active) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
+        if (active && !PLANES) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
     }
     float4 H = active ? qload(&hits[i]) : make_float4(-1, 0, 0, 0);
     uint32_t gid = __float_as_uint(H.w);
@@ -823,7 +831,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         f3 con = lcol * color;                                           // :372
         qstore(&srayA[ss], make_float4(so.x, so.y, so.z, ldist - 1e-3f));        // :356
         qstore(&srayB[ss], make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix)));
-        qstore(&scon[ss], make_float4(con.x, con.y, con.z, 0.0f));
+        if (PLANES) q2store(&scon[pix], make_float4(con.x, con.y, con.z, 0.0f)); else qstore(&scon[ss], make_float4(con.x, con.y, con.z, 0.0f));
     }
     if (want_next) {
         const bool sp = MATERIALS && special;
@@ -877,6 +885,48 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
             const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
             float fi = (float)frame;
             float den = (float)(frame + 1);
+            c.x = (sm.x + p.x * fi) / den; c.y = (sm.y + p.y * fi) / den; c.z = (sm.z + p.z * fi) / den;
+        } else c = sm;
+    }
+    q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
+}
+
+// Shadow planes (renderer option shadow_planes, default; also what a flow pass uses): shade(b) leaves the light's contribution in con[b][pixel], a shadow ray that gets
+// through sets lit[b][pixel] (one byte), and the pixel's sample is the sum of the contributions whose byte is set, in bounce order — the additions of
+// Raytracing.metal:371-373 on the same floats in the same order as the read-modify-write of one sample buffer made them (0 + c0, + c1, + c2).  Per shadow ray
+// that is 16 bytes written and one byte instead of 32 bytes through the queue and a 32-byte read-modify-write inside the traversal loop.
+MRT_DEV float4 planes_sample(const float4 *const (&con)[3], const uint8_t *__restrict__ lit, size_t lit_stride, int max_bounces, size_t sp) {
+    float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+        if (b < max_bounces && lit[(size_t)b * lit_stride + sp]) { const float4 cc = qload(&con[b][sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }
+    return sm;
+}
+__global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const float4 *__restrict__ con0, const float4 *__restrict__ con1, const float4 *__restrict__ con2, const uint8_t *__restrict__ lit, uint32_t lit_stride,
+                                                          const float4 *__restrict__ prev, float4 *__restrict__ dst, unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long closest = primary, shadow = 0;
+        for (int b = 0; b < fp.max_bounces; b++) {
+            unsigned long long c = bounce_counts[b];
+            if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
+            shadow += c >> 32;
+            bounce_counts[b] = 0;
+            bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
+        }
+        totals[0] += closest; totals[1] += shadow; totals[2] += primary;
+    }
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    const uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    const float4 *const con[3] = {con0, con1, con2};
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
+        const float4 sm = planes_sample(con, lit, lit_stride, fp.max_bounces, (size_t)sub * fp.npix + pix);
+        const uint32_t frame = fp.frameIndex + (uint32_t)sub;
+        if (frame > 0) {
+            const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
+            const float fi = (float)frame, den = (float)(frame + 1);
             c.x = (sm.x + p.x * fi) / den; c.y = (sm.y + p.y * fi) / den; c.z = (sm.z + p.z * fi) / den;
         } else c = sm;
     }
@@ -1126,8 +1176,10 @@ size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
     const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
     const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
-    const size_t flow_bytes = flow ? (7 * qcap + 2 * spix) * sizeof(float4) + spix * FLOW_MAX_BOUNCES + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0;
-    return ((need_thr ? 10 : 8) * qcap + spix) * sizeof(float4) + flow_bytes;
+    const size_t planes_bytes = (flow || shadow_planes) ? 2 * spix * sizeof(float4) + spix * FLOW_MAX_BOUNCES : 0;
+    const size_t flow_bytes = planes_bytes + (flow ? 7 * qcap * sizeof(float4) + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0);
+    const bool need_scon = need_thr || !shadow_planes;
+    return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + flow_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
@@ -1135,11 +1187,17 @@ void Renderer::release_lane(FrameLane &L) {
     L.f_dirs.release(); L.f_lit.release(); L.f_words.release(); L.f_tab.release();
     for (int k = 0; k < 2; k++) { L.f_sA[k].release(); L.f_sB[k].release(); L.f_hits[k].release(); L.f_con[k].release(); }
 }
+int Renderer::alloc_planes(FrameLane &L) {
+    const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    for (int k = 0; k < 2; k++) MRT_HIP(L.f_con[k].alloc(spix));
+    MRT_HIP(L.f_lit.alloc(spix * FLOW_MAX_BOUNCES));
+    return MRT_OK;
+}
 int Renderer::alloc_flow(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch), spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
     MRT_HIP(L.f_dirs.alloc(qcap));
-    for (int k = 0; k < 2; k++) { MRT_HIP(L.f_sA[k].alloc(qcap)); MRT_HIP(L.f_sB[k].alloc(qcap)); MRT_HIP(L.f_hits[k].alloc(qcap)); MRT_HIP(L.f_con[k].alloc(spix)); }
-    MRT_HIP(L.f_lit.alloc(spix * FLOW_MAX_BOUNCES));
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.f_sA[k].alloc(qcap)); MRT_HIP(L.f_sB[k].alloc(qcap)); MRT_HIP(L.f_hits[k].alloc(qcap)); }
     const size_t ww = flow_written_words(qcap);
     MRT_HIP(L.f_words.alloc(FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * ww));      // header + five rings of 64-bit descriptors
     // the kernel's table of pointers (flow.h FT_*)
@@ -1159,7 +1217,8 @@ int Renderer::alloc_lane(FrameLane &L) {
     const unsigned qf = queue_uncached ? hipDeviceMallocUncached : hipDeviceMallocDefault;
     const bool need_thr = !(throughput_chain && (fused || scene->num_inst) && !use_wide && !materials && max_bounces <= 3);      // else on demand (render())
     for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); if (need_thr) MRT_HIP(L.thr[k].alloc(qcap, qf)); }
-    MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf)); MRT_HIP(L.scon.alloc(qcap, qf));
+    MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf));
+    if (need_thr || !shadow_planes) MRT_HIP(L.scon.alloc(qcap, qf));          // the contribution queue: with shadow planes only the passes they do not cover need it (allocated then, render())
     MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     return MRT_OK;
@@ -1261,7 +1320,7 @@ int Renderer::render(int n_frames) {                                   // Render
         const float4 *const htab_pass = (halton_table == 1 && htab.p && covered) ? htab.p : nullptr;
         fp.htab = htab_pass;
         fp.hprim = (halton_table == 2 && hprim.p && covered) ? hprim.p : nullptr;
-        bool flow_pass = false;
+        bool flow_pass = false, used_planes = false;
         if (mega) {
             // one launch per frame on the pass's stream; frames are sequential (a path's last act is the running average with the previous target)
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
@@ -1347,6 +1406,15 @@ int Renderer::render(int n_frames) {                                   // Render
                 MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, (size_t)max_bounces * spix, st));
             }
             float4 *const dirs = flow_pass ? L.f_dirs.p : L.rayB[1].p;
+            // shadow planes: contribution per pixel and bounce + one byte per shadow ray that got through, instead of the contribution queue and the read-modify-write of the sample buffer
+            const bool planes_pass = !flow_pass && shadow_planes != 0 && fp.chain && on_wide && wide_stream && !materials && !shadow_rope && max_bounces <= FLOW_MAX_BOUNCES && !ablate;
+            const size_t plane_stride = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+            if (planes_pass) {
+                if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, (size_t)max_bounces * plane_stride, st));
+            }
+            used_planes = planes_pass;
+            if (!planes_pass && !flow_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             if (ablate & 1) {}
             else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
             else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
@@ -1368,9 +1436,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(MRT_SHADE_XCD_BANDS ? (grid_shade + 7u) / 8u * 8u : grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
                 auto shade_kernel = materials ? (fp.htab ? k_shade<true, true, false> : k_shade<true, false, false>)
+                                              : planes_pass ? (fp.htab ? k_shade<false, true, true, true> : k_shade<false, false, true, true>)
                                               : fp.chain ? (fp.htab ? k_shade<false, true, true> : k_shade<false, false, true>) : (fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>);
+                float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
+                uint8_t *const lit_b = planes_pass ? L.f_lit.p + (size_t)b * plane_stride : nullptr;
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
+                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
@@ -1392,13 +1463,13 @@ int Renderer::render(int n_frames) {                                   // Render
                     const uint32_t chunk_arg = chunk;
 #endif
                     if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg, lit_b);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg, lit_b);
                 }
                 else if (on_wide && (wide_stream || two_level)) {
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, dim3(cdiv(2 * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, 0, rpw_m);
-                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m);
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, dim3(cdiv(2 * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, 0, rpw_m, lit_b);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, dim3(cdiv((shadow_rope ? 1 : 2) * (size_t)capacity * B, rpw_m)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m, lit_b);
                     if (shadow_rope && !two_level) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 }
                 else if (on_wide) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
@@ -1410,6 +1481,7 @@ int Renderer::render(int n_frames) {                                   // Render
             // unfused sequence: raygen -> per bounce { extend, shade, shadow }
             fp.chain = 0;
             if (!L.thr[0].p) { const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch); for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap)); }
+            if (!L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
             int q = 0;
             for (int b = 0; b < max_bounces; b++) {
@@ -1432,7 +1504,9 @@ int Renderer::render(int n_frames) {                                   // Render
         if (!flow_pass) {
             EvPair *ev = nullptr;
             if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
-            launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+            if (used_planes) launch_timed(ev, k_accumulate_planes, dim3(grid), dim3(64), 0, st, fp, (const float4 *)L.sample.p, (const float4 *)L.f_con[0].p, (const float4 *)L.f_con[1].p, (const uint8_t *)L.f_lit.p,
+                                          (uint32_t)((size_t)width * height * (size_t)std::max(1, alloc_batch)), (const float4 *)accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+            else launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
         }
         MRT_HIP(hipEventRecord(L.accumulated, st));
         last_acc = L.accumulated;

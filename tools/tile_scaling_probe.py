@@ -9,6 +9,7 @@ import metal_raytracing_amd as mrt
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--worlds", default="1,2,4,8"); ap.add_argument("--batches", default="1,2,4,8,16,32")
+ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable), e.g. flow=1")
 a = ap.parse_args()
 w, h = 1920, 1080
 scene = mrt.DragonScene((w, h))
@@ -18,6 +19,8 @@ for world in [int(x) for x in a.worlds.split(",")]:
         r = mrt.Renderer((w, h), scene, seed=1)
         if world > 1: r.set_shard(0, world)
         r.set_option("frame_batch", fb)
+        for kv in a.opt:
+            k, v = kv.split("="); r.set_option(k, float(v))
         best = None
         for rep in range(3):
             r.draw(a.warmup); r.wait(); r.reset_stats()
