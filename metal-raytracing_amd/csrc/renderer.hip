@@ -1221,6 +1221,7 @@ int Renderer::alloc_lane(FrameLane &L) {
     if (need_thr || !shadow_planes) MRT_HIP(L.scon.alloc(qcap, qf));          // the contribution queue: with shadow planes only the passes they do not cover need it (allocated then, render())
     MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
+    if (shadow_planes && !need_thr) { if (int rc = alloc_planes(L)) return rc; }
     return MRT_OK;
 }
 
