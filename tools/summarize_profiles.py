@@ -5,7 +5,7 @@ out, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 os.makedirs(P, exist_ok=True)
-KERNELS = ("k_trace_primary", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_shade", "k_accumulate")
+KERNELS = ("k_trace_primary", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_shade", "k_accumulate", "k_accumulate_planes")
 
 
 def kname(n):
@@ -59,7 +59,7 @@ res["valu_busy_pct"] = {k: d.get("VALUBusy") for k, d in pm.items()}
 res["valu_lane_utilization_pct"] = {k: d.get("VALUUtilization") for k, d in pm.items()}
 # VALU wave-instructions per FRAME: per 4-frame pass there is 1 primary, max_bounces shade, max_bounces trace and 1 accumulate dispatch
 B, BOUNCES = 4, 3
-per_pass = {"k_trace_primary": 1, "k_shade": BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1}
+per_pass = {"k_trace_primary": 1, "k_shade": BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1, "k_accumulate_planes": 1}
 insts = sum(pm[k].get("SQ_INSTS_VALU", 0.0) * n for k, n in per_pass.items() if k in pm)
 if insts:
     res["valu_wave_insts_per_frame"] = insts / B
