@@ -77,7 +77,7 @@ enum : int {
     FT_SA = 4, FT_SB = 7,            // SQ[b]: shadow rays appended by shade(b)
     FT_HITS = 10,                    // [0]: the pass's primary hits (k_trace_primary), index = sub-frame * capacity + slot; [b >= 1]: closest hits of Q[b - 1], by queue position
     FT_CON = 13,                     // [b][sub-frame * npix + pixel]: the light's contribution at bounce b (Raytracing.metal:372)
-    FT_LIT = 16,                     // [b][sub-frame * npix + pixel] = 1 (a byte): the shadow ray of bounce b was not occluded (:371)
+    FT_LIT = 16,                     // [b]: byte b of pixel 0's word; [4 * (sub-frame * npix + pixel) + b] = 1: the shadow ray of bounce b was not occluded (:371)
     FT_RING = 19,                    // [q]: descriptors in the order they were published: first entry | count << 32 (count > 0); zero at launch
     FT_DIRS = 24,                    // primary directions | sample index (k_trace_primary)
     FT_COUNT = 25
@@ -90,7 +90,6 @@ struct FlowArgs {
     uint32_t chunk;                  // primary slots per stage-0 session (multiple of 64)
     uint32_t take;                   // K: descriptors a claim takes at most (<= FLOW_MAX_TAKE)
     uint32_t session_rays;           // rays a traversal session may start before it drains and shades (<= 64 granules of bounce rays)
-    uint32_t lit_stride;             // bytes between the lit planes of consecutive bounces
     uint32_t mix;                    // 1: a session that traces bounce rays fills up with shadow rays
     uint32_t granule;                // rays per descriptor (multiple of 64): what a session appended is published in pieces of this size
     uint32_t breadth_first;          // 1: the shallowest stage with work first (even stages, large queues); 0: the deepest (short queues, a long tail)
@@ -203,7 +202,6 @@ __global__ void __launch_bounds__(64, MRT_FLOW_WAVES) k_flow(SceneView s, FrameP
             st.budget = fa.session_rays;
             float4 *__restrict__ const hits_b = flow_ptr<float4>(fa, FT_HITS + st.cstage);
             uint8_t *__restrict__ const lit0 = flow_ptr<uint8_t>(fa, FT_LIT);
-            const size_t lit_stride = fa.lit_stride;
             traverse_wide_stream<false>(s, FlowSource{fa, st, lane, nb}, stk_dyn,
                 [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
                     A = flow_ld16(st.rA, i); B = flow_ld16(st.rB, i);
@@ -211,7 +209,7 @@ __global__ void __launch_bounds__(64, MRT_FLOW_WAVES) k_flow(SceneView s, FrameP
                     else { tag = i; is_any = 0u; A.w = __builtin_inff(); }        // a bounce ray's tmax word carries the throughput chain
                 },
                 [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
-                    if (is_any) { if (!hit) lit0[(size_t)(j >> 27) * lit_stride + (j & 0x7FFFFFFu)] = 1; }
+                    if (is_any) { if (!hit) lit0[4 * (size_t)(j & 0x7FFFFFFu) + (j >> 27)] = 1; }
                     else hits_b[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                 });
             flow_drain();
@@ -415,7 +413,7 @@ __global__ void __launch_bounds__(64) k_accumulate_flow(FrameParams fp, FlowArgs
         const size_t sp = (size_t)sub * fp.npix + pix;
         float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int b = 0; b < fp.max_bounces; b++)
-            if (static_cast<const uint8_t *>(fa.tab[FT_LIT + b])[sp]) { const float4 cc = qload(&static_cast<const float4 *>(fa.tab[FT_CON + b])[sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }
+            if (static_cast<const uint8_t *>(fa.tab[FT_LIT])[4 * sp + b]) { const float4 cc = qload(&static_cast<const float4 *>(fa.tab[FT_CON + b])[sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }
         const uint32_t frame = fp.frameIndex + (uint32_t)sub;
         if (frame > 0) {
             const float4 p = sub == 0 ? q2load(&prev[pix]) : c;

@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
                 if (!hit) {
-                    if (lit) lit[j] = 1;
+                    if (lit) lit[4 * (size_t)j] = 1;          // (lit points at this bounce's byte of pixel 0: four bytes per pixel and frame)
                     else { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
                 }
             } else {
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
                 if (!hit) {
-                    if (lit) lit[j] = 1;
+                    if (lit) lit[4 * (size_t)j] = 1;          // (lit points at this bounce's byte of pixel 0: four bytes per pixel and frame)
                     else { const uint32_t pix = __float_as_uint(srayB[j].w); float4 cc = qload(&scon[j]), a = q2load(&sample[pix]); q2store(&sample[pix], make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f)); }
                 }
             } else {
@@ -892,17 +892,18 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
 }
 
 // Shadow planes (renderer option shadow_planes, default; also what a flow pass uses): shade(b) leaves the light's contribution in con[b][pixel], a shadow ray that gets
-// through sets lit[b][pixel] (one byte), and the pixel's sample is the sum of the contributions whose byte is set, in bounce order — the additions of
+// through sets lit[pixel][b] (one byte of the four a pixel has per frame), and the pixel's sample is the sum of the contributions whose byte is set, in bounce order — the additions of
 // Raytracing.metal:371-373 on the same floats in the same order as the read-modify-write of one sample buffer made them (0 + c0, + c1, + c2).  Per shadow ray
 // that is 16 bytes written and one byte instead of 32 bytes through the queue and a 32-byte read-modify-write inside the traversal loop.
-MRT_DEV float4 planes_sample(const float4 *const (&con)[3], const uint8_t *__restrict__ lit, size_t lit_stride, int max_bounces, size_t sp) {
+MRT_DEV float4 planes_sample(const float4 *const (&con)[3], const uint8_t *__restrict__ lit, int max_bounces, size_t sp) {
     float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t flags = reinterpret_cast<const uint32_t *>(lit)[sp];      // byte b: the shadow ray of bounce b got through
 #pragma unroll
     for (int b = 0; b < 3; b++)
-        if (b < max_bounces && lit[(size_t)b * lit_stride + sp]) { const float4 cc = qload(&con[b][sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }
+        if (b < max_bounces && ((flags >> (8 * b)) & 0xFFu) != 0u) { const float4 cc = qload(&con[b][sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }
     return sm;
 }
-__global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const float4 *__restrict__ con0, const float4 *__restrict__ con1, const float4 *__restrict__ con2, const uint8_t *__restrict__ lit, uint32_t lit_stride,
+__global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const float4 *__restrict__ con0, const float4 *__restrict__ con1, const float4 *__restrict__ con2, const uint8_t *__restrict__ lit,
                                                           const float4 *__restrict__ prev, float4 *__restrict__ dst, unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long closest = primary, shadow = 0;
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
     const float4 *const con[3] = {con0, con1, con2};
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
-        const float4 sm = planes_sample(con, lit, lit_stride, fp.max_bounces, (size_t)sub * fp.npix + pix);
+        const float4 sm = planes_sample(con, lit, fp.max_bounces, (size_t)sub * fp.npix + pix);
         const uint32_t frame = fp.frameIndex + (uint32_t)sub;
         if (frame > 0) {
             const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
@@ -1176,7 +1177,7 @@ size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
     const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
     const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
-    const size_t planes_bytes = (flow || shadow_planes) ? 2 * spix * sizeof(float4) + spix * FLOW_MAX_BOUNCES : 0;
+    const size_t planes_bytes = (flow || shadow_planes) ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const size_t flow_bytes = planes_bytes + (flow ? 7 * qcap * sizeof(float4) + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0);
     const bool need_scon = need_thr || !shadow_planes;
     return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + flow_bytes;
@@ -1190,11 +1191,11 @@ void Renderer::release_lane(FrameLane &L) {
 int Renderer::alloc_planes(FrameLane &L) {
     const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
     for (int k = 0; k < 2; k++) MRT_HIP(L.f_con[k].alloc(spix));
-    MRT_HIP(L.f_lit.alloc(spix * FLOW_MAX_BOUNCES));
+    MRT_HIP(L.f_lit.alloc(spix * 4));          // [sub-frame][pixel][bounce]: one 32-bit word per pixel and frame
     return MRT_OK;
 }
 int Renderer::alloc_flow(FrameLane &L) {
-    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch), spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
     if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
     MRT_HIP(L.f_dirs.alloc(qcap));
     for (int k = 0; k < 2; k++) { MRT_HIP(L.f_sA[k].alloc(qcap)); MRT_HIP(L.f_sB[k].alloc(qcap)); MRT_HIP(L.f_hits[k].alloc(qcap)); }
@@ -1205,7 +1206,7 @@ int Renderer::alloc_flow(FrameLane &L) {
     for (int k = 0; k < 2; k++) { tab[FT_QA + k] = L.rayA[k].p; tab[FT_QB + k] = L.rayB[k].p; }
     tab[FT_SA] = L.srayA.p; tab[FT_SB] = L.srayB.p; tab[FT_HITS] = L.hits.p; tab[FT_CON] = L.sample.p;
     for (int k = 0; k < 2; k++) { tab[FT_SA + 1 + k] = L.f_sA[k].p; tab[FT_SB + 1 + k] = L.f_sB[k].p; tab[FT_HITS + 1 + k] = L.f_hits[k].p; tab[FT_CON + 1 + k] = L.f_con[k].p; }
-    for (int k = 0; k < FLOW_MAX_BOUNCES; k++) tab[FT_LIT + k] = L.f_lit.p + (size_t)k * spix;
+    for (int k = 0; k < FLOW_MAX_BOUNCES; k++) tab[FT_LIT + k] = L.f_lit.p + k;
     for (int k = 0; k < FLOW_QUEUES; k++) tab[FT_RING + k] = reinterpret_cast<unsigned long long *>(L.f_words.p + FLOW_HEADER_WORDS) + (size_t)k * ww;
     tab[FT_DIRS] = L.f_dirs.p;
     MRT_HIP(L.f_tab.alloc(FT_COUNT));
@@ -1378,8 +1379,6 @@ int Renderer::render(int n_frames) {                                   // Render
             FlowArgs fa{};
             if (flow_pass) {
                 if (!L.f_words.p) { if (int rc = alloc_flow(L)) return rc; }
-                const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch), spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
-                (void)qcap;
                 fa.counts = bc; fa.words = L.f_words.p;
                 fa.tab = L.f_tab.p;
                 fa.n_primary = (uint32_t)((size_t)capacity * B);
@@ -1388,7 +1387,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 fa.take = (uint32_t)std::max(1, std::min(flow_take, (int)FLOW_MAX_TAKE));
                 fa.granule = (uint32_t)std::max(64, flow_granule) / 64u * 64u;
                 fa.session_rays = (uint32_t)std::min<size_t>((size_t)std::max(64, flow_session_rays), (size_t)60 * fa.granule);
-                fa.lit_stride = (uint32_t)spix; fa.mix = flow_mix != 0 ? 1u : 0u;
+                fa.mix = flow_mix != 0 ? 1u : 0u;
                 fa.breadth_first = flow_order != 0 ? 1u : 0u;
                 if (flow_slots_for_stack != stack_bytes) {
                     int per_cu = 0, dev = 0; hipDeviceProp_t prop;
@@ -1404,15 +1403,14 @@ int Renderer::render(int n_frames) {                                   // Render
                 fa.chunk = chunk;
                 fa.exit_rays = (uint32_t)std::min<size_t>((size_t)std::max(0, flow_exit_rays) * slots + 1, 0x7FFFFFFFu);
                 MRT_HIP(hipMemsetAsync(L.f_words.p, 0, L.f_words.bytes(), st));
-                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, (size_t)max_bounces * spix, st));
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)width * height * (size_t)B, st));
             }
             float4 *const dirs = flow_pass ? L.f_dirs.p : L.rayB[1].p;
             // shadow planes: contribution per pixel and bounce + one byte per shadow ray that got through, instead of the contribution queue and the read-modify-write of the sample buffer
             const bool planes_pass = !flow_pass && shadow_planes != 0 && fp.chain && on_wide && wide_stream && !materials && !shadow_rope && max_bounces <= FLOW_MAX_BOUNCES && !ablate;
-            const size_t plane_stride = (size_t)width * height * (size_t)std::max(1, alloc_batch);
             if (planes_pass) {
                 if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
-                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, (size_t)max_bounces * plane_stride, st));
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)width * height * (size_t)B, st));
             }
             used_planes = planes_pass;
             if (!planes_pass && !flow_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
@@ -1440,7 +1438,7 @@ int Renderer::render(int n_frames) {                                   // Render
                                               : planes_pass ? (fp.htab ? k_shade<false, true, true, true> : k_shade<false, false, true, true>)
                                               : fp.chain ? (fp.htab ? k_shade<false, true, true> : k_shade<false, false, true>) : (fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>);
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
-                uint8_t *const lit_b = planes_pass ? L.f_lit.p + (size_t)b * plane_stride : nullptr;
+                uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
@@ -1506,7 +1504,7 @@ int Renderer::render(int n_frames) {                                   // Render
             EvPair *ev = nullptr;
             if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
             if (used_planes) launch_timed(ev, k_accumulate_planes, dim3(grid), dim3(64), 0, st, fp, (const float4 *)L.sample.p, (const float4 *)L.f_con[0].p, (const float4 *)L.f_con[1].p, (const uint8_t *)L.f_lit.p,
-                                          (uint32_t)((size_t)width * height * (size_t)std::max(1, alloc_batch)), (const float4 *)accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
+                                          (const float4 *)accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
             else launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
         }
         MRT_HIP(hipEventRecord(L.accumulated, st));
