@@ -73,3 +73,27 @@ def test_flow_falls_back_where_it_does_not_apply(mrt, gpu_ctx):
     ref, _ = render(mrt, gpu_ctx, sc, (160, 100), 4, materials=1)
     img, _ = render(mrt, gpu_ctx, sc, (160, 100), 4, materials=1, flow=1)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_shadow_planes_are_the_contribution_queue(mrt, gpu_ctx):
+    """shadow_planes (default): contribution planes + one byte per shadow ray that got through; = 0: the contribution queue and the read-modify-write of the
+    sample buffer.  Same additions in the same order: same image, same ray counts — flattened, two-level, sharded, one- and four-frame passes."""
+    for scene, sopts, size in ((mrt.DragonScene((640, 360)), None, (640, 360)), (mrt.InstancedDragonScene((320, 200)), {"instancing": 1}, (320, 200))):
+        imgs = []
+        for planes in (1, 0):
+            r = mrt.Renderer(size, scene, ctx=gpu_ctx, scene_options=sopts)
+            r.set_option("shadow_planes", planes)
+            r.draw(5, wait=True); r.set_option("frame_batch", 1); r.draw(2, wait=True)
+            st = r.stats
+            imgs.append((r.accumulation().copy(), (st.closest_rays, st.shadow_rays)))
+            r.close()
+        assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32)) and imgs[0][1] == imgs[1][1]
+    sc = mrt.DragonScene((333, 211))
+    parts = []
+    for planes in (1, 0):
+        acc = np.zeros((211, 333, 4), np.float32)
+        for rank in range(3):
+            r = mrt.Renderer((333, 211), sc, ctx=gpu_ctx); r.set_option("shadow_planes", planes); r.set_shard(rank, 3); r.draw(3, wait=True)
+            acc += r.accumulation(); r.close()
+        parts.append(acc)
+    assert np.array_equal(parts[0].view(np.uint32), parts[1].view(np.uint32))
