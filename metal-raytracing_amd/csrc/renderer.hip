@@ -627,7 +627,7 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool TAB, bool CHAIN, bool PLANES = false>      // PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
+template <bool MATERIALS, bool TAB, bool CHAIN, bool PLANES = false, bool TRACE0 = false>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (k_trace_primary's body) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
 __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
@@ -635,7 +635,8 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
                                               float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon,
                                               unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */,
                                               float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */,
-                                              float4 *__restrict__ sample /* MATERIALS: emitted radiance is added here */) {
+                                              float4 *__restrict__ sample /* MATERIALS: emitted radiance is added here */,
+                                              uint32_t *__restrict__ hint /* TRACE0: per pixel, the packet its primary ray hit last (or nullptr) */) {
     __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES];
     __shared__ unsigned long long blk_base;
     // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
@@ -660,7 +661,32 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         spix = sub * fp.npix + (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
         if (active && !PLANES) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
     }
-    float4 H = active ? qload(&hits[i]) : make_float4(-1, 0, 0, 0);
+    float4 H = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)), Bprim = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (TRACE0) {
+        if (active) {                        // k_trace_primary<false>, statement by statement
+            f3 org, dir;
+            primary_ray(fp, seeds, sub, px_x, px_y, org, dir);
+            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
+            TravHit h;
+            bool hit;
+            if (hint != nullptr) {
+                const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+                const uint32_t guess = hint[pixel];
+                h.t = __builtin_inff(); h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = 0xFFFFFFFFu;
+                if (guess < s.num_tris) {
+                    const float4 *__restrict__ pk = s.packets + 3 * (size_t)guess;
+                    const float4 q0 = pk[0];
+                    float t, U, V, ad;
+                    if (tri_test(q0, pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = __float_as_uint(q0.w); h.pk = guess; }
+                }
+                hit = traverse<false, false, false, true>(s, org, dir, 0.0f, h.t, h);
+                if (h.pk != guess) hint[pixel] = h.pk;
+            }
+            else hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
+            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
+        }
+    }
+    else if (active) H = qload(&hits[i]);
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
     bool want_shadow = false, want_next = false;
@@ -672,7 +698,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         float4 A, B, C;
         if (sample_primary) {
             A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
-            B = qload(&rayB[i]);                                         // direction | sample index, written by the primary trace
+            B = TRACE0 ? Bprim : qload(&rayB[i]);                        // direction | sample index, written by the primary trace
             C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
         } else if (CHAIN) {
             A = qload(&rayA[i]); B = qload(&rayB[i]);
@@ -1413,8 +1439,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)width * height * (size_t)B, st));
             }
             used_planes = planes_pass;
+            // the primary trace inside shade(0): flattened scenes on the rope layout (the primary rays' kernel), planes passes
+            // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
+            // fuse_primary = 2 fuses always)
+            const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && !(primary_wide && sv.num_wnodes) && (fuse_primary == 2 || F > 1 || B > 1);
             if (!planes_pass && !flow_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
-            if (ablate & 1) {}
+            if ((ablate & 1) || trace0_pass) {}
             else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
             else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
@@ -1435,12 +1465,13 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(MRT_SHADE_XCD_BANDS ? (grid_shade + 7u) / 8u * 8u : grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
                 auto shade_kernel = materials ? (fp.htab ? k_shade<true, true, false> : k_shade<true, false, false>)
+                                              : (planes_pass && trace0_pass && b == 0) ? (fp.htab ? k_shade<false, true, true, true, true> : k_shade<false, false, true, true, true>)
                                               : planes_pass ? (fp.htab ? k_shade<false, true, true, true> : k_shade<false, false, true, true>)
                                               : fp.chain ? (fp.htab ? k_shade<false, true, true> : k_shade<false, false, true>) : (fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>);
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p);
+                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && primary_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 const bool pull = persistent == 1 || (persistent == 2 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 1024);
@@ -1492,7 +1523,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
                 hipLaunchKernelGGL((fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>), dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
-                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p);
+                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p, (uint32_t *)nullptr);
                 if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 q = 1 - q;
