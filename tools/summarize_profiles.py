@@ -5,12 +5,17 @@ out, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 os.makedirs(P, exist_ok=True)
-KERNELS = ("k_trace_primary", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_shade", "k_accumulate", "k_accumulate_planes")
+KERNELS = ("k_trace_primary", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_shade", "k_shade_primary", "k_accumulate", "k_accumulate_planes")
 
 
 def kname(n):
-    m = re.search(r"(k_[a-z0-9_]+)", n)
-    return m.group(1) if m else n.split("(")[0]
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", n)
+    if not m:
+        return n.split("(")[0]
+    targs = [t.strip() for t in (m.group(2) or "<>")[1:-1].split(",")]
+    if m.group(1) == "k_shade" and len(targs) == 5 and targs[4] == "true":
+        return "k_shade_primary"          # k_shade<..., TRACE0 = true>: the primary rays generated, traced and shaded in one launch (fuse_primary)
+    return m.group(1)
 
 
 sys.path.insert(0, ROOT)
@@ -59,7 +64,7 @@ res["valu_busy_pct"] = {k: d.get("VALUBusy") for k, d in pm.items()}
 res["valu_lane_utilization_pct"] = {k: d.get("VALUUtilization") for k, d in pm.items()}
 # VALU wave-instructions per FRAME: per 4-frame pass there is 1 primary, max_bounces shade, max_bounces trace and 1 accumulate dispatch
 B, BOUNCES = 4, 3
-per_pass = {"k_trace_primary": 1, "k_shade": BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1, "k_accumulate_planes": 1}
+per_pass = {"k_trace_primary": 1, "k_shade_primary": 1, "k_shade": BOUNCES - 1 if "k_shade_primary" in pm else BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1, "k_accumulate_planes": 1}
 insts = sum(pm[k].get("SQ_INSTS_VALU", 0.0) * n for k, n in per_pass.items() if k in pm)
 if insts:
     res["valu_wave_insts_per_frame"] = insts / B
