@@ -249,7 +249,8 @@ int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
  * materials extension: emission, specular lobe, refraction; max_bounces <= 16), "megakernel" (one launch per frame: lowest latency of a
  * single frame), "sample_offset", "throughput_chain" (bounce rays carry the resource slots of their path instead of a throughput record),
  * "shadow_planes" (a contribution plane per bounce and one byte per shadow ray that got through instead of a contribution queue), "fuse_primary"
- * (primary rays generated, traced and shaded in one launch: 0 never, 1 except for one frame alone, 2 always), "halton_table",
+ * (primary rays generated, traced and shaded in one launch: 0 never, 1 except for one frame alone, 2 always), "tail_accumulate" (the last passes of a
+ * draw accumulated in one launch), "halton_table",
  * "flow" (experiment: one launch per pass after the primary trace, csrc/flow.h; with "flow_chunk", "flow_granule", "flow_take", "flow_session_rays",
  * "flow_exit_rays", "flow_idle_polls", "flow_slots", "flow_order", "flow_mix"), and the A/B switches "fused", "wide_bounce", "wide_stream",
  * "primary_wide", "shadow_rope", "wide"; read-only through mrt_renderer_get_option: "lanes_used", "lane_bytes".  Every setting renders the same

@@ -456,6 +456,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
     else if (k == "primary_wide") r->r.primary_wide = value != 0;
     else if (k == "shadow_planes") r->r.shadow_planes = value != 0 ? 1 : 0;
+    else if (k == "tail_accumulate") r->r.tail_accumulate = value != 0;
     else if (k == "fuse_primary") { REQUIRE(value == 0 || value == 1 || value == 2, "fuse_primary must be 0, 1 (not for one frame alone) or 2 (always)"); r->r.fuse_primary = (int)value; }
     else if (k == "flow") { REQUIRE(value == 0 || value == 1, "flow must be 0 or 1"); r->r.flow = (int)value; }
     else if (k == "flow_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "flow_chunk must be a multiple of 64 in [64, 65536]"); r->r.flow_chunk = (int)value; }
@@ -496,6 +497,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;
     else if (k == "primary_wide") *value = r->r.primary_wide ? 1 : 0;
     else if (k == "shadow_planes") *value = r->r.shadow_planes;
+    else if (k == "tail_accumulate") *value = r->r.tail_accumulate ? 1 : 0;
     else if (k == "fuse_primary") *value = r->r.fuse_primary;
     else if (k == "flow") *value = r->r.flow;
     else if (k == "flow_chunk") *value = r->r.flow_chunk;

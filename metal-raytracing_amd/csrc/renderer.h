@@ -85,6 +85,7 @@ struct Renderer {
     int flow_slots_auto = 0; size_t flow_slots_for_stack = ~(size_t)0;
     int alloc_flow(FrameLane &L);
     int alloc_planes(FrameLane &L);
+    bool tail_accumulate = true;         // the last passes of a draw (one per lane) are accumulated in one launch after the join instead of one after the other
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)

@@ -960,6 +960,51 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
     q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
+// The last passes of a draw, accumulated in ONE launch on the main stream (Renderer::tail_accumulate): their accumulate launches would otherwise run one after the other at the very
+// end of the call — each reads the previous one's output — when nothing else is left to overlap them with (rocprofv3, the driver's 20 steps: five launches of 60-90 us plus their
+// gaps, 0.6 of 12.8 ms).  Same folds in the same order (pass by pass, frame by frame); the accumulation target is read once and written once.
+struct AccPass { const float4 *con0, *con1, *con2; const uint8_t *lit; unsigned long long *counts; uint32_t frameIndex; int32_t batch; uint32_t primary; uint32_t pad; };
+struct AccGroup { AccPass p[MAX_FRAMES_IN_FLIGHT]; int32_t n; };
+__global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, AccGroup g, const float4 *__restrict__ prev, float4 *__restrict__ dst, unsigned long long *__restrict__ totals) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long closest = 0, shadow = 0, primary = 0;
+#pragma unroll
+        for (int p = 0; p < MAX_FRAMES_IN_FLIGHT; p++) {
+            if (p >= g.n) break;
+            closest += g.p[p].primary; primary += g.p[p].primary;
+            for (int b = 0; b < fp.max_bounces; b++) {
+                const unsigned long long c = g.p[p].counts[b];
+                if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
+                shadow += c >> 32;
+                g.p[p].counts[b] = 0; g.p[p].counts[32 + b] = 0;
+            }
+        }
+        totals[0] += closest; totals[1] += shadow; totals[2] += primary;
+    }
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    int x, y;
+    if (!slot_to_pixel(fp, slot, x, y)) return;
+    const uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool first = true;
+#pragma unroll
+    for (int p = 0; p < MAX_FRAMES_IN_FLIGHT; p++) {
+        if (p >= g.n) break;
+        const float4 *const con[3] = {g.p[p].con0, g.p[p].con1, g.p[p].con2};
+        for (int sub = 0; sub < g.p[p].batch; sub++) {
+            const float4 sm = planes_sample(con, g.p[p].lit, fp.max_bounces, (size_t)sub * fp.npix + pix);
+            const uint32_t frame = g.p[p].frameIndex + (uint32_t)sub;
+            if (frame > 0) {
+                const float4 q = first ? q2load(&prev[pix]) : c;
+                const float fi = (float)frame, den = (float)(frame + 1);
+                c.x = (sm.x + q.x * fi) / den; c.y = (sm.y + q.y * fi) / den; c.z = (sm.z + q.z * fi) / den;
+            } else c = sm;
+            first = false;
+        }
+    }
+    q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
+}
+
 #include "flow.h"
 
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
@@ -1334,6 +1379,9 @@ int Renderer::render(int n_frames) {                                   // Render
     }
     hipEvent_t last_acc = nullptr;
     int pass = 0;
+    const int n_passes = (n_frames + batch_max - 1) / batch_max;
+    const int tail_from = tail_accumulate ? n_passes - std::min(F, n_passes) : n_passes;      // passes from here on (each on a lane of its own) are accumulated together after the join
+    AccGroup tail{}; tail.n = 0;
     for (int f = 0; f < n_frames; pass++) {
         int B = std::min(batch_max, n_frames - f);
         f += B;
@@ -1530,6 +1578,14 @@ int Renderer::render(int n_frames) {                                   // Render
             }
         }
         // accumulation is the only frame-to-frame dependency (prev target = the previous frame's output)
+        const bool deferred = used_planes && pass >= tail_from && tail.n < MAX_FRAMES_IN_FLIGHT;
+        if (deferred) {
+            AccPass &P = tail.p[tail.n++];
+            P.con0 = L.sample.p; P.con1 = L.f_con[0].p; P.con2 = L.f_con[1].p; P.lit = L.f_lit.p; P.counts = bc; P.frameIndex = fp.frameIndex; P.batch = B; P.primary = (uint32_t)(owned_pixels * (uint64_t)B); P.pad = 0;
+            MRT_HIP(hipEventRecord(L.accumulated, st));       // (here: traced — the join below waits for it, the accumulation follows on the main stream)
+            frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
+            continue;
+        }
         if (last_acc && !flow_pass) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
         if (!flow_pass) {
             EvPair *ev = nullptr;
@@ -1546,6 +1602,13 @@ int Renderer::render(int n_frames) {                                   // Render
     }
     // join: the main stream continues after every lane has drained
     for (int k = 0; k < std::min(F, pass); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
+    if (tail.n > 0) {
+        EvPair *ev = nullptr;
+        if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
+        launch_timed(ev, k_accumulate_planes_group, dim3(grid), dim3(64), 0, stream, fp, tail, (const float4 *)accum[cur].p, accum[1 - cur].p, totals.p);
+        cur = 1 - cur;
+        if (int rc = note_pass(stream)) return rc;
+    }
     MRT_HIP(hipEventRecord(ev_end, stream));
     MRT_HIP(hipGetLastError());
     pending_timing = true;
