@@ -97,3 +97,22 @@ def test_shadow_planes_are_the_contribution_queue(mrt, gpu_ctx):
             acc += r.accumulation(); r.close()
         parts.append(acc)
     assert np.array_equal(parts[0].view(np.uint32), parts[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("opts", [dict(tail_accumulate=0), dict(fuse_primary=0), dict(fuse_primary=2, frames_in_flight=1, frame_batch=1), dict(fuse_primary=0, shadow_planes=0, tail_accumulate=0),
+                                  dict(frames_in_flight=2, frame_batch=3), dict(primary_hint=0)], ids=str)
+def test_pipeline_switches_do_not_change_the_image(mrt, gpu_ctx, opts):
+    """fuse_primary (primary rays traced inside shade(0)), tail_accumulate (the last passes folded in one launch), shadow_planes: scheduling and storage, never the image —
+    over draws of several shapes (a draw shorter than the lanes, one that wraps around them, a single frame)."""
+    sc = mrt.DragonScene((400, 240))
+    imgs = []
+    for o in (dict(), opts):
+        r = mrt.Renderer((400, 240), sc, ctx=gpu_ctx)
+        for k, v in o.items():
+            r.set_option(k, v)
+        for n in (3, 1, 17, 52):
+            r.draw(n, wait=True)
+        st = r.stats
+        imgs.append((r.accumulation().copy(), (st.closest_rays, st.shadow_rays, st.primary_rays, st.frames)))
+        r.close()
+    assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32)) and imgs[0][1] == imgs[1][1]
