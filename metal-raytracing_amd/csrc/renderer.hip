@@ -968,7 +968,6 @@ struct AccGroup { AccPass p[MAX_FRAMES_IN_FLIGHT]; int32_t n; };
 __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, AccGroup g, const float4 *__restrict__ prev, float4 *__restrict__ dst, unsigned long long *__restrict__ totals) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long closest = 0, shadow = 0, primary = 0;
-#pragma unroll
         for (int p = 0; p < MAX_FRAMES_IN_FLIGHT; p++) {
             if (p >= g.n) break;
             closest += g.p[p].primary; primary += g.p[p].primary;
@@ -987,7 +986,6 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
     const uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     bool first = true;
-#pragma unroll
     for (int p = 0; p < MAX_FRAMES_IN_FLIGHT; p++) {
         if (p >= g.n) break;
         const float4 *const con[3] = {g.p[p].con0, g.p[p].con1, g.p[p].con2};
