@@ -39,6 +39,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef MRT_WIDE_SPEC
 #define MRT_WIDE_SPEC 1     // flattened scenes: a lane that still has triangles to test visits its next node anyway and keeps that node's triangles in a second group (below)
 #endif
+#ifndef MRT_WIDE_DUAL_TRI_TWO_LEVEL
+#define MRT_WIDE_DUAL_TRI_TWO_LEVEL 0     // two-level scenes: two pending triangles per iteration (a two-triangle wall or floor instance then costs one iteration instead of two)
+#endif
 #ifndef MRT_WIDE_SPEC_TWO_LEVEL
 #define MRT_WIDE_SPEC_TWO_LEVEL 0     // the same inside the BLASes of two-level scenes: measured twice, no gain
 #endif
@@ -421,11 +424,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             if (n_busy != 0u && n_want < (uint32_t)MRT_WIDE_NODE_MIN) want_node = false;
         }
 #endif
-#if MRT_WIDE_DUAL_TRI
-        const bool has_tri2 = live && t_rest != 0u;             // two or more pending: test two this iteration (the node registers carry the second packet)
-#else
-        const bool has_tri2 = false;
-#endif
+        constexpr bool DUAL = (TWO_LEVEL ? MRT_WIDE_DUAL_TRI_TWO_LEVEL : MRT_WIDE_DUAL_TRI) != 0;
+        bool has_tri2 = DUAL && has_tri && t_rest != 0u && !want_node;      // two or more pending: test two this iteration (the node registers carry the second packet)
         uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
         bool last_step = false;         // flattened scenes: nothing but this iteration's triangle is left of the ray — it is finished when the test is done
         if (TWO_LEVEL && has_inst) {
@@ -448,7 +448,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             t_base = 0; t_mask = 0;
             insts = (insts & 0xFFFF0000u) | id;
             if (I.ntri <= 8u) {          // a BLAS of a few triangles (a wall, a floor): no node to test, its packets are the pending set, the first one is tested now
-                t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true;
+                t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true; has_tri2 = DUAL && t_rest != 0u;
             } else { pending = I.wroot; want_node = true; }
         }
         else if (want_node) {
