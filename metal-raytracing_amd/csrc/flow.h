@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(64) k_accumulate_flow(FrameParams fp, FlowArgs
     const uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
-        const size_t sp = (size_t)sub * fp.npix + pix;
+        const size_t sp = (size_t)sub * fp.capacity + slot;
         float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int b = 0; b < fp.max_bounces; b++)
             if (static_cast<const uint8_t *>(fa.tab[FT_LIT])[4 * sp + b]) { const float4 cc = qload(&static_cast<const float4 *>(fa.tab[FT_CON + b])[sp]); sm = make_float4(sm.x + cc.x, sm.y + cc.y, sm.z + cc.z, 0.0f); }

@@ -40,7 +40,8 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     int32_t bounce, max_bounces;
     // frame batching: one pass of the pipeline carries `batch` consecutive frames.  Sub-frame s uses Halton index
     // sampleIndex + s (the offset is baked into its copy of the seed table), slots [s * capacity, (s + 1) * capacity)
-    // of the primary queue and sample buffer entries [s * npix, (s + 1) * npix); k_accumulate applies the sub-frames in order.
+    // of the primary queue, of the seed table and of the sample buffer / contribution planes (a SAMPLE INDEX = s * capacity + slot: per-pixel state of a pass is laid
+    // out by the shard's own slots, so a rank of N holds 1/N of it and a wave's 8x8 tile is 64 consecutive entries); k_accumulate applies the sub-frames in order.
     uint32_t npix, capacity;
     int32_t batch;
     // Halton table (renderer option halton_table): row i = every value a path of up to HTAB_BOUNCES bounces draws for Halton index i, or nullptr
@@ -95,11 +96,18 @@ __global__ void k_seed(uint32_t *__restrict__ seeds, uint32_t n, uint32_t seed) 
     if (i < n) seeds[(size_t)blockIdx.y * n + i] = seed_hash_dev(seed, i) + blockIdx.y;
 }
 
+// the renderer's seed table: by sample index (sub-frame * capacity + slot of this shard), seeds[...] = hash(seed, pixel of the slot) + sub-frame
+__global__ void k_seed_slots(uint32_t *__restrict__ seeds, FrameParams fp, uint32_t seed) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= fp.capacity) return;
+    int x, y;
+    seeds[(size_t)blockIdx.y * fp.capacity + slot] = slot_to_pixel(fp, slot, x, y) ? seed_hash_dev(seed, (uint32_t)y * (uint32_t)fp.width + (uint32_t)x) + blockIdx.y : 0u;
+}
+
 // ------------------------------------------------------------------ primary rays
 // Raytracing.metal:175, :202-221
-MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, uint32_t sub, int x, int y, f3 &org, f3 &dir) {
-    uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
-    uint32_t offset = q2load(&seeds[sub * fp.npix + pix]);               // :175 (+ sub-frame index)
+MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, uint32_t sample_index, int x, int y, f3 &org, f3 &dir) {
+    uint32_t offset = q2load(&seeds[sample_index]);                      // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
     float r0, r1;                                                        // :202-203
     if (fp.htab) { const float4 q = fp.htab[(size_t)HTAB_ROW * (uint32_t)idx]; r0 = q.x; r1 = q.y; }
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *_
         if ((int)(slot >> 6) < fp.tiles_local) rayB[slot] = make_float4(0, 0, 0, __uint_as_float(DEAD_PIXEL));
         return;
     }
-    uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+    const uint32_t pix = slot;                                           // sample index (one frame per pass here)
     uint32_t offset = seeds[pix];                                        // Raytracing.metal:175
     int idx = (int)(offset + fp.sampleIndex);
     float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
@@ -167,10 +175,10 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
         return;
     }
     f3 org, dir;
-    primary_ray(fp, seeds, sub, x, y, org, dir);
+    primary_ray(fp, seeds, sub * fp.capacity + slot, x, y, org, dir);
     // the direction goes to HBM (16 B per pixel: the memory system has headroom, the vector ALUs do not — k_shade reads it back
     // instead of repeating two Halton values, two divisions and a normalisation per pixel)
-    qstore(&dirs[(size_t)sub * fp.capacity + slot], make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x)));
+    qstore(&dirs[(size_t)sub * fp.capacity + slot], make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.capacity + slot)));
     TravHit h;
     bool hit;
     if (!TWO_LEVEL && hint != nullptr) {
@@ -384,11 +392,11 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
     const uint32_t n_slots = fp.capacity;
     // prefetched pixels: slot batch_base + lane -> primary direction + pixel index (0xFFFFFFFF: slot outside the image)
     f3 pd = mk3(0, 0, 1); uint32_t ppix = 0xFFFFFFFFu;
-    uint32_t batch_n = 0, batch_used = 0;
+    uint32_t batch_n = 0, batch_used = 0, batch_base = 0;
     bool more = true;
     // path state of the lane
     bool has_path = false, live = false, is_shadow = false, pending = false;
-    uint32_t pix = 0; int bounce = 0;
+    uint32_t pix = 0, pslot = 0; int bounce = 0;      // pixel (accumulation targets) and slot (seed table) of the lane's path
     f3 thr = mk3(1, 1, 1), rad = mk3(0, 0, 0), con = mk3(0, 0, 0), ndir = mk3(0, 1, 0);
     uint32_t n_closest = 0, n_shadow = 0;
     // ray + traversal state (traverse_wide_stream)
@@ -433,7 +441,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
                                        (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);        // :267
                     const f3 nrm = normalize3(n_w);                                                // :268
                     const f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);          // :262-269
-                    const int idx = (int)(seeds[pix] + fp.sampleIndex);
+                    const int idx = (int)(seeds[pslot] + fp.sampleIndex);
                     const int dim0 = 2 + bounce * 5;
                     const float ls = halton_dev(idx, dim0 + 0);                                    // :272
                     const int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);       // :273
@@ -501,10 +509,10 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= n_slots) { more = false; batch_n = batch_used = 0; }
                 else {
-                    batch_n = min(64u, n_slots - base); batch_used = 0;
+                    batch_n = min(64u, n_slots - base); batch_used = 0; batch_base = base;
                     int x, y; ppix = 0xFFFFFFFFu;
                     if (lane < batch_n && slot_to_pixel(fp, base + lane, x, y)) {
-                        f3 org; primary_ray(fp, seeds, 0u, x, y, org, pd);
+                        f3 org; primary_ray(fp, seeds, base + lane, x, y, org, pd);
                         ppix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
                     }
                 }
@@ -518,7 +526,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
                 const float dx_ = __shfl(pd.x, sl), dy_ = __shfl(pd.y, sl), dz_ = __shfl(pd.z, sl);
                 const uint32_t px_ = (uint32_t)__shfl((int)ppix, sl);
                 if (take && px_ != 0xFFFFFFFFu) {
-                    has_path = true; is_shadow = false; pending = false; pix = px_; bounce = 0;
+                    has_path = true; is_shadow = false; pending = false; pix = px_; pslot = batch_base + (uint32_t)sl; bounce = 0;
                     thr = mk3(1.0f, 1.0f, 1.0f); rad = mk3(0.0f, 0.0f, 0.0f);                     // :226-227
                     n_closest++;
                     start_ray(mk3(fp.cam_pos), mk3(dx_, dy_, dz_), __builtin_inff());              // :214-221
@@ -600,9 +608,9 @@ __global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s
         [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             int x, y; is_any = 0u; tag = slot;
             if (slot_to_pixel(fp, slot, x, y)) {
-                f3 org, dir; primary_ray(fp, seeds, sub, x, y, org, dir);
+                f3 org, dir; primary_ray(fp, seeds, sub * fp.capacity + slot, x, y, org, dir);
                 A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
-                dirs[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.npix + (uint32_t)y * (uint32_t)fp.width + (uint32_t)x));   // read back by k_shade
+                dirs[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.capacity + slot));   // read back by k_shade
             } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
         },
         [&](uint32_t slot, bool, bool hit, const TravHit &h) {
@@ -655,17 +663,17 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
     bool active = slot < n;
     int px_x = 0, px_y = 0;
-    uint32_t spix = 0;                   // sample-buffer index = sub * npix + pixel
+    uint32_t spix = 0;                   // sample index (seed table, sample buffer, contribution planes)
     if (sample_primary) {
         active = active && slot_to_pixel(fp, slot, px_x, px_y);
-        spix = sub * fp.npix + (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+        spix = i;                        // sample index = sub * capacity + slot
         if (active && !PLANES) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
     }
     float4 H = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)), Bprim = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
     if (TRACE0) {
         if (active) {                        // k_trace_primary<false>, statement by statement
             f3 org, dir;
-            primary_ray(fp, seeds, sub, px_x, px_y, org, dir);
+            primary_ray(fp, seeds, spix, px_x, px_y, org, dir);
             Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
             TravHit h;
             bool hit;
@@ -905,7 +913,7 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
     uint32_t pix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
-        const float4 sm = qload(&sample[(size_t)sub * fp.npix + pix]);
+        const float4 sm = qload(&sample[(size_t)sub * fp.capacity + slot]);
         const uint32_t frame = fp.frameIndex + (uint32_t)sub;
         if (frame > 0) {
             const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
@@ -949,7 +957,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
     const float4 *const con[3] = {con0, con1, con2};
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sub = 0; sub < fp.batch; sub++) {                           // the batch's frames, in frame order
-        const float4 sm = planes_sample(con, lit, fp.max_bounces, (size_t)sub * fp.npix + pix);
+        const float4 sm = planes_sample(con, lit, fp.max_bounces, (size_t)sub * fp.capacity + slot);
         const uint32_t frame = fp.frameIndex + (uint32_t)sub;
         if (frame > 0) {
             const float4 p = sub == 0 ? q2load(&prev[pix]) : c;
@@ -990,7 +998,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
         if (p >= g.n) break;
         const float4 *const con[3] = {g.p[p].con0, g.p[p].con1, g.p[p].con2};
         for (int sub = 0; sub < g.p[p].batch; sub++) {
-            const float4 sm = planes_sample(con, g.p[p].lit, fp.max_bounces, (size_t)sub * fp.npix + pix);
+            const float4 sm = planes_sample(con, g.p[p].lit, fp.max_bounces, (size_t)sub * fp.capacity + slot);
             const uint32_t frame = g.p[p].frameIndex + (uint32_t)sub;
             if (frame > 0) {
                 const float4 q = first ? q2load(&prev[pix]) : c;
@@ -1180,13 +1188,11 @@ int Renderer::resize(int w, int h) {                                   // Render
     const size_t npix = (size_t)w * h;
     const int B = std::max(1, std::min(frame_batch, MAX_FRAME_BATCH));
     alloc_batch = B;
-    MRT_HIP(seeds.alloc(npix * B));
     MRT_HIP(hint.alloc(npix));
     MRT_HIP(hipMemsetAsync(hint.p, 0xFF, hint.bytes(), stream));
     MRT_HIP(accum[0].alloc(npix)); MRT_HIP(accum[1].alloc(npix));
     MRT_HIP(hipMemsetAsync(accum[0].p, 0, accum[0].bytes(), stream));
     MRT_HIP(hipMemsetAsync(accum[1].p, 0, accum[1].bytes(), stream));
-    hipLaunchKernelGGL(k_seed, dim3(cdiv(npix, 256), B), dim3(256), 0, stream, seeds.p, (uint32_t)npix, seed);
     default_camera(w, h, &camera);
     frame_index = 0; cur = 0;
     MRT_HIP(hipMemsetAsync(totals.p, 0, totals.bytes(), stream));
@@ -1226,6 +1232,12 @@ int Renderer::alloc_queues() {
     tiles_local = (tiles - shard_rank + shard_world - 1) / shard_world;
     if (tiles_local < 0) tiles_local = 0;
     capacity = (uint32_t)tiles_local * 64u;
+    {   // the seed table, by sample index (sub-frame * capacity + slot): this shard's pixels only
+        const int B = std::max(1, alloc_batch);
+        MRT_HIP(seeds.alloc((size_t)std::max<uint32_t>(capacity, 1u) * B));
+        FrameParams sp{}; sp.width = width; sp.height = height; sp.shard_rank = shard_rank; sp.shard_world = shard_world; sp.tiles_x = tiles_x; sp.tiles_local = tiles_local; sp.capacity = capacity;
+        if (capacity) hipLaunchKernelGGL(k_seed_slots, dim3(cdiv(capacity, 256), B), dim3(256), 0, stream, seeds.p, sp, seed);
+    }
     // lanes get their buffers when first used (alloc_lane): 16 lanes x 4-frame queues would pin 23 GB at 1080p, 94 GB at 4K
     lanes_ready = 0;
     for (auto &L : lanes) release_lane(L);
@@ -1245,7 +1257,7 @@ static inline size_t flow_written_words(size_t qcap) { return 2 * (qcap >> 6) + 
 size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
     const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
-    const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
     const size_t planes_bytes = (flow || shadow_planes) ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const size_t flow_bytes = planes_bytes + (flow ? 7 * qcap * sizeof(float4) + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0);
     const bool need_scon = need_thr || !shadow_planes;
@@ -1258,7 +1270,7 @@ void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.f_sA[k].release(); L.f_sB[k].release(); L.f_hits[k].release(); L.f_con[k].release(); }
 }
 int Renderer::alloc_planes(FrameLane &L) {
-    const size_t spix = (size_t)width * height * (size_t)std::max(1, alloc_batch);
+    const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
     for (int k = 0; k < 2; k++) MRT_HIP(L.f_con[k].alloc(spix));
     MRT_HIP(L.f_lit.alloc(spix * 4));          // [sub-frame][pixel][bounce]: one 32-bit word per pixel and frame
     return MRT_OK;
@@ -1289,7 +1301,7 @@ int Renderer::alloc_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); if (need_thr) MRT_HIP(L.thr[k].alloc(qcap, qf)); }
     MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf));
     if (need_thr || !shadow_planes) MRT_HIP(L.scon.alloc(qcap, qf));          // the contribution queue: with shadow planes only the passes they do not cover need it (allocated then, render())
-    MRT_HIP(L.sample.alloc((size_t)width * height * (size_t)std::max(1, alloc_batch)));
+    MRT_HIP(L.sample.alloc((size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     if (shadow_planes && !need_thr) { if (int rc = alloc_planes(L)) return rc; }
     return MRT_OK;
@@ -1475,14 +1487,14 @@ int Renderer::render(int n_frames) {                                   // Render
                 fa.chunk = chunk;
                 fa.exit_rays = (uint32_t)std::min<size_t>((size_t)std::max(0, flow_exit_rays) * slots + 1, 0x7FFFFFFFu);
                 MRT_HIP(hipMemsetAsync(L.f_words.p, 0, L.f_words.bytes(), st));
-                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)width * height * (size_t)B, st));
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)capacity * (size_t)B, st));
             }
             float4 *const dirs = flow_pass ? L.f_dirs.p : L.rayB[1].p;
             // shadow planes: contribution per pixel and bounce + one byte per shadow ray that got through, instead of the contribution queue and the read-modify-write of the sample buffer
             const bool planes_pass = !flow_pass && shadow_planes != 0 && fp.chain && on_wide && wide_stream && !materials && !shadow_rope && max_bounces <= FLOW_MAX_BOUNCES && !ablate;
             if (planes_pass) {
                 if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
-                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)width * height * (size_t)B, st));
+                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)capacity * (size_t)B, st));
             }
             used_planes = planes_pass;
             // the primary trace inside shade(0): flattened scenes on the rope layout (the primary rays' kernel), planes passes
