@@ -116,3 +116,18 @@ def test_pipeline_switches_do_not_change_the_image(mrt, gpu_ctx, opts):
         imgs.append((r.accumulation().copy(), (st.closest_rays, st.shadow_rays, st.primary_rays, st.frames)))
         r.close()
     assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32)) and imgs[0][1] == imgs[1][1]
+
+
+@pytest.mark.parametrize("bounces,size", [(1, (96, 96)), (2, (96, 96)), (3, (9, 7)), (3, (1, 1)), (2, (65, 3))])
+def test_default_path_matches_oracle_at_few_bounces_and_tiny_sizes(mrt, orc, gpu_ctx, bounces, size):
+    """the default path (primary rays traced inside shade(0), shadow planes, tail accumulate) against the oracle where its special cases live:
+    one and two bounces (no bounce queue at the last one), images smaller than a tile, a single pixel"""
+    from test_gpu_parity import assert_parity, oracle_render
+    sc = mrt.CornellScene(size)
+    ref, cnt = oracle_render(orc, mrt, sc, size[0], size[1], 6, bounces=bounces)
+    r = mrt.Renderer(size, sc, ctx=gpu_ctx, max_bounces=bounces)
+    r.draw(5, wait=True); r.draw(1, wait=True)
+    assert_parity(r.accumulation(), ref, exact_frac=1.0)
+    st = r.stats
+    assert (st.closest_rays, st.shadow_rays) == tuple(cnt)
+    r.close()
