@@ -12,6 +12,14 @@
 //   k_shadow      any hit; unoccluded contributions are added to the pixel's sample        (:360-374)
 //   k_accumulate  running average with the previous target                                  (:394-403)
 //
+// That is the plain sequence (renderer option fused = 0).  The DEFAULT pass carries four frames and runs
+//   k_shade<.., TRACE0>          primary rays generated, traced (rope walk + last frame's hit as a hint) and shaded in one launch
+//   k_trace_mixed_wide_persist   per bounce: its bounce rays (closest hit) and shadow rays (any hit) in ONE launch of persistent waves on the
+//                                8-wide layout (traverse_wide.h); a shadow ray that gets through sets one byte
+//   k_shade                      bounces 1, 2: the light's contribution goes to a per-bounce plane, the throughput is rebuilt from resource slots
+//   k_accumulate_planes          contributions whose byte is set, summed in bounce order; running average (the last passes of a draw: one launch)
+// on up to twelve streams; instanced scenes walk both levels with the same kernels (<TWO_LEVEL>); flow.h is the one-launch-per-pass experiment.
+//
 // Record layout (all 16-byte lanes, one dwordx4 per lane per access, fully coalesced):
 //   rayA = {origin.xyz, tmax}   rayB = {direction.xyz, pixel}   thr = {throughput.rgb, -}   (path rays)
 //   hit  = {t, U/|det|, V/|det|, gid}                                                        (16 B)
