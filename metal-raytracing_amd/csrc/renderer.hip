@@ -302,10 +302,10 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
     const size_t batches = slots / 64 / 10240;                             // 64-ray batches per wave if the launch had ~10 K waves
     return 64u * (uint32_t)std::min<size_t>(16, std::max<size_t>(6, batches));
 }
-#ifndef MRT_WIDE_STREAM_WAVES
 #ifndef MRT_TWO_LEVEL_WAVES
 #define MRT_TWO_LEVEL_WAVES 6
 #endif
+#ifndef MRT_WIDE_STREAM_WAVES
 #define MRT_WIDE_STREAM_WAVES (MRT_WIDE_SPEC ? 6 : 7)      // the second triangle group costs two registers: 80 instead of 72 (no spills); the frame rate does not depend on 6 or 7 waves per SIMD
 #endif
 template <bool TWO_LEVEL>
