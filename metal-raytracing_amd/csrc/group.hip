@@ -175,7 +175,7 @@ int mrt_group_renderer_create(MRTGroup g, MRTScene scene, int32_t width, int32_t
         raw->r.push_back(r);
         rc = mrt_renderer_set_shard(r, rank, n); if (rc) return rc;
         // a shard's launches are 1/n of a frame: carry proportionally more frames per pass so that they stay large
-        rc = mrt_renderer_set_option(r, "frame_batch", (double)std::min(mrt::MAX_FRAME_BATCH, 4 * n)); if (rc) return rc;
+        rc = mrt_renderer_set_option(r, "frame_batch", (double)std::min(mrt::MAX_FRAME_BATCH, mrt::DEFAULT_FRAME_BATCH * n)); if (rc) return rc;
         MRT_HIP(hipSetDevice(g->devices[(size_t)rank]));
         hipEvent_t e = nullptr; MRT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         raw->done.push_back(e);

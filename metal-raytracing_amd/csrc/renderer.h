@@ -29,6 +29,7 @@ struct FrameLane {
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 constexpr int MAX_FRAME_BATCH = 32;
+constexpr int DEFAULT_FRAME_BATCH = 8;
 
 struct Renderer {
     hipStream_t stream = nullptr;
@@ -55,8 +56,8 @@ struct Renderer {
     int halton_table = 0;                // 0 = digit loops (default: measured fastest), 1 = full table, 2 = table for dimension 1 only
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
-    int frames_in_flight = 12;           // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 8-12 lanes measured best on MI355X (16 HW queues)
-    int frame_batch = 4;                 // frames carried through the pipeline per pass (fused pipeline); 1 = one frame per pass
+    int frames_in_flight = 6;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 6 lanes x 8-frame passes measured best on MI355X (12 x 4 until then)
+    int frame_batch = DEFAULT_FRAME_BATCH;                 // frames carried through the pipeline per pass at most (a draw's frames go in passes of equal size); 1 = one frame per pass
     int lanes_used = 0;                  // lanes the last draw ran on (<= frames_in_flight when device memory is short)
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for

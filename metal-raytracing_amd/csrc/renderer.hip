@@ -1401,7 +1401,8 @@ int Renderer::render(int n_frames) {                                   // Render
     const int tail_from = tail_accumulate ? n_passes - std::min(F, n_passes) : n_passes;      // passes from here on (each on a lane of its own) are accumulated together after the join
     AccGroup tail{}; tail.n = 0;
     for (int f = 0; f < n_frames; pass++) {
-        int B = std::min(batch_max, n_frames - f);
+        // the draw's frames in passes of equal size (20 frames at frame_batch 8: 7 + 7 + 6, not 8 + 8 + 4 — the passes of a short draw run side by side and end together)
+        int B = std::min(batch_max, (n_frames - f + (n_passes - pass) - 1) / std::max(1, n_passes - pass));
         f += B;
         fp.batch = B;
         FrameLane &L = lanes[pass % F];

@@ -55,9 +55,10 @@ class ShardedRenderer:
                 # 1/world of the pixels per frame: carry proportionally more frames per pass so that the launches stay large — but a short run
                 # still needs about three passes to overlap (tools/tile_scaling_probe.py, rank 0 of N on one GPU, 20 frames: N = 8 at 32 frames
                 # per pass 4.98, at 8 frames per pass 5.42 Grays/s per rank; 240 frames: 9.73 at 32, 8.66 at 8)
-                fb = min(32, 4 * world)
+                base = int(self.renderer.get_option("frame_batch"))          # the library's default (8)
+                fb = min(32, base * world)
                 if frames_total is not None:
-                    fb = min(fb, max(4, int(frames_total) // 3))
+                    fb = min(fb, max(base, int(frames_total) // 3))
                 self.renderer.set_option("frame_batch", fb)
             else:
                 if frames_total is None:

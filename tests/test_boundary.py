@@ -101,7 +101,7 @@ def test_frames_completed_never_blocks_and_ends_at_the_total(mrt, gpu_ctx):
         seen.append(r.framesCompleted)
     assert seen[-1] == 3 + n
     assert all(b >= a for a, b in zip(seen, seen[1:]))                      # monotonic
-    assert all((s - 3) % 4 == 0 or s == 3 + n for s in seen if s > 3)       # reported per pass of frame_batch = 4 frames
+    assert all((s - 3) % 8 == 0 or s == 3 + n for s in seen if s > 3)       # reported per pass of frame_batch = 8 frames (400 = 50 x 8)
     assert seen[0] < 3 + n, f"the first poll, {t_poll * 1e3:.1f} ms after the call returned, already saw every frame: render() blocked?"
     r.wait()
     assert r.framesCompleted == 3 + n

@@ -28,11 +28,11 @@ def small_dragon(mrt, gpu_ctx):
     r.close()
 
 
-DEFAULTS = dict(flow_chunk=512, flow_take=8, flow_granule=128, flow_session_rays=2048, flow_mix=1, flow_order=1, flow_slots=0, flow_idle_polls=4096, flow_exit_rays=512, frame_batch=4, frames_in_flight=12)
+DEFAULTS = dict(flow_chunk=512, flow_take=8, flow_granule=128, flow_session_rays=2048, flow_mix=1, flow_order=1, flow_slots=0, flow_idle_polls=4096, flow_exit_rays=512, frame_batch=8, frames_in_flight=6)
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(flow_chunk=64, flow_take=1, flow_granule=64, flow_session_rays=64), dict(flow_chunk=4096, flow_take=16, flow_granule=512, flow_session_rays=65536), dict(flow_order=0), dict(flow_mix=0), dict(flow_take=2, flow_session_rays=64), dict(flow_slots=64), dict(flow_slots=1),
-                                  dict(flow_idle_polls=0), dict(flow_exit_rays=0), dict(flow_exit_rays=65536), dict(frame_batch=1), dict(frame_batch=8, frames_in_flight=2)], ids=str)
+                                  dict(flow_idle_polls=0), dict(flow_exit_rays=0), dict(flow_exit_rays=65536), dict(frame_batch=1), dict(frame_batch=4, frames_in_flight=12), dict(frame_batch=3, frames_in_flight=2)], ids=str)
 def test_flow_image_is_the_pipelines(small_dragon, opts):
     r, ref, st0 = small_dragon
     for k, v in {**DEFAULTS, **opts}.items():

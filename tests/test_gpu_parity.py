@@ -380,7 +380,7 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
-    if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 4: 5 frames = 4 + 1
+    if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 8: 5 frames = one pass; three: 3 + 2
     r.draw(5, wait=True)
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
     assert_parity(r.accumulation(), ref)
@@ -401,7 +401,7 @@ def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
     w, h = 200, 120
     sc = mrt.CornellScene((w, h))
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
-    assert r.get_option("frame_batch") == 4
+    assert r.get_option("frame_batch") == 8
     r.draw(3, wait=True)                       # one pass of 3
     r.set_option("frame_batch", 2); r.draw(5, wait=True)    # 2 + 2 + 1
     r.set_option("frame_batch", 8); r.draw(3, wait=True)    # one pass of 3

@@ -25,7 +25,7 @@ def test_group_image_is_bit_identical_to_one_device(mrt, orc, gpu_ctx, n):
         assert g.world == n
         mode, note = g.reduce_mode
         assert mode == 1 and (("one device" in note) if n == 1 else ("more than once" in note))
-        assert g.rank_option(0, "frame_batch") == min(32, 4 * n)
+        assert g.rank_option(0, "frame_batch") == (8 if n == 1 else min(32, 8 * n))
         g.draw(frames)
         img = g.gather()
         assert g.framesCompleted == frames
