@@ -45,6 +45,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PASS_FRAMES = 8                # the library's default frame_batch: the serialised-pass leg and the committed counters use launches of this many frames
 BYTES_PER_CLOSEST_RAY = 96     # ray 2x32 B + hit 2x16 B
 BYTES_PER_SHADOW_RAY = 72
 
@@ -139,16 +140,16 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames,
            "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU",
            "kernel_ms_serialised": {k: round(statistics.median(v), 4) for k, v in per_kernel.items()}}
-    # the default pass size alone on the GPU: one stream, 4-frame passes (the regime in which the dominant kernel's standalone duration is
-    # consistent with ms_per_step; profiles/r03_kernel_stats_serial4.csv is rocprofv3's view of the same regime)
-    q.set_option("frame_batch", 4); q.draw(8, wait=True)
+    # the default pass size alone on the GPU: one stream, passes of PASS_FRAMES frames (the regime in which the dominant kernel's standalone duration is
+    # consistent with ms_per_step; profiles/r03_kernel_stats_serial_pass.csv is rocprofv3's view of the same regime)
+    q.set_option("frame_batch", PASS_FRAMES); q.draw(2 * PASS_FRAMES, wait=True)
     four = {}
     for _ in range(4):
-        q.draw(8, wait=True)             # two passes per call: the grid policy of a long call (half the wave slots per traversal launch), as in the default run and in the rocprofv3 trace
+        q.draw(2 * PASS_FRAMES, wait=True)   # two passes per call: the grid policy of a long call (half the wave slots per traversal launch), as in the default run and in the rocprofv3 trace
         for k, (ms, n) in q.kernel_times.items():
             if n:
                 four.setdefault(k, []).append(ms / n)
-    out["kernel_ms_serialised_four_frame_pass"] = {k: round(statistics.median(v), 4) for k, v in four.items()}
+    out["kernel_ms_serialised_pass"] = {k: round(statistics.median(v), 4) for k, v in four.items()}; out["frames_per_serialised_pass"] = PASS_FRAMES
     q.set_option("frame_batch", 1); q.draw(2, wait=True)
     # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
     q.set_option("megakernel", 1); q.draw(3, wait=True)
@@ -311,6 +312,7 @@ def main():
             pers = int(r.get_option("persistent"))
             pulls = pers == 1 or (pers == 2 and 2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 1024)
             kernel_label = ("k_trace_mixed_wide_persist" if pulls else "k_trace_mixed_wide_stream") + ("<two-level>" if two_level else "") + " (bounce + shadow traversal)"
+        traffic_p = (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected") if prof else None
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -328,15 +330,17 @@ def main():
                        "device": r.ctx.device_name},
             "roofline": {"bound": "hbm", "kernel": kernel_label,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected") if prof_applies else None,
+                         # the counters were collected on launches of full passes (PASS_FRAMES frames, tools/collect_profiles.sh); this run's launches carry steps / passes frames: scaled by the ratio
+                         "traffic": (round(traffic_p * (a.steps / passes) / prof.get("pmc_frames_per_dispatch", PASS_FRAMES)) if traffic_p else None) if prof_applies else None,
+                         "traffic_measured": {"bytes_per_launch": traffic_p, "frames_per_launch": prof.get("pmc_frames_per_dispatch", PASS_FRAMES), "frames_per_launch_here": round(a.steps / passes, 3)} if prof_applies else None,
                          "traffic_source": prof.get("_source") if prof_applies else None, "traffic_note": prof_note,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
                          "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY,
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n,
-                         # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 12 streams x 4-frame passes) and of the serialised frame
+                         # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 6 streams, passes of 7 + 7 + 6 frames) and of the serialised frame
                          "avg_launch_ms_rocprof_driver_command": (round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
                          "avg_launch_ms_rocprof_serialised_one_frame": (round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None) if prof_applies else None,
-                         "avg_launch_ms_rocprof_serialised_four_frames": (round((prof.get("kernel_avg_us_serial4") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
+                         "avg_launch_ms_rocprof_serialised_pass": (round((prof.get("kernel_avg_us_serial_pass") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
                          "avg_launch_ms_note": "kernel start/stop events of the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is the duration under overlap (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone; the serialised duration is latency.kernel_ms_serialised.trace",
                          "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
                          "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
@@ -370,13 +374,13 @@ def main():
         if world == 1 and not a.no_latency:
             out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
             out["ms_per_frame"] = out["latency"]["ms_per_frame"]      # SURVEY §8(d)'s ms/frame (one frame alone on the GPU), next to ms_per_step (inverse throughput)
-            t4 = out["latency"]["kernel_ms_serialised_four_frame_pass"].get("trace")
+            t4 = out["latency"]["kernel_ms_serialised_pass"].get("trace")
             if t4 and fused:
-                b4 = (BYTES_PER_CLOSEST_RAY * (closest - primary) + BYTES_PER_SHADOW_RAY * shadow) / steps_total * 4 / a.bounces
-                out["roofline"]["serialised_four_frame_launch"] = {"avg_launch_ms": t4, "algorithmic_bytes_per_launch": round(b4), "achieved": round(b4 / (t4 * 1e-3) / 1e9, 2),
+                b4 = (BYTES_PER_CLOSEST_RAY * (closest - primary) + BYTES_PER_SHADOW_RAY * shadow) / steps_total * PASS_FRAMES / a.bounces
+                out["roofline"]["serialised_pass_launch"] = {"avg_launch_ms": t4, "frames_per_launch": PASS_FRAMES, "algorithmic_bytes_per_launch": round(b4), "achieved": round(b4 / (t4 * 1e-3) / 1e9, 2),
                                                                    "frac": round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s",
-                                                                   "kernel_time_per_frame_ms": round(t4 * a.bounces / 4, 4),
-                                                                   "note": "one stream, 4-frame passes: the dominant kernel alone at the default pass size; kernel_time_per_frame_ms <= ms_per_step is the consistency check"}
+                                                                   "kernel_time_per_frame_ms": round(t4 * a.bounces / PASS_FRAMES, 4),
+                                                                   "note": "one stream, 8-frame passes: the dominant kernel alone at the default pass size; kernel_time_per_frame_ms <= ms_per_step is the consistency check"}
             # the dominant kernel ALONE: one-frame launches on one stream (the latency leg's own start/stop events), algorithmic bytes of one frame's
             # bounce + shadow rays spread over its max_bounces launches — the kernel-level figure that profiles/r02_kernel_stats_serial.csv reproduces
             t_ser = out["latency"]["kernel_ms_serialised"].get("trace")

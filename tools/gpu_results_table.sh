@@ -9,8 +9,10 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name:', d['valu
 b "C1 cornell 256" --scene cornell --width 256 --height 256 --steps 240 --warmup 24
 b "C2 driver 20" --steps 20 --warmup 5
 b "C2 default 240" --steps 240 --warmup 24
-b "C2 3 lanes x 4" --steps 240 --warmup 24 --frames-in-flight 3
-b "C2 6 lanes x 4" --steps 240 --warmup 24 --frames-in-flight 6
+b "C2 3 lanes x 8" --steps 240 --warmup 24 --frames-in-flight 3
+b "C2 12 lanes x 4 (the default until §6.57)" --steps 240 --warmup 24 --frames-in-flight 12 --opt frame_batch=4
+b "C2 12 lanes x 4, 20 steps" --steps 20 --warmup 5 --frames-in-flight 12 --opt frame_batch=4
+b "C2 3 lanes x 4" --steps 240 --warmup 24 --frames-in-flight 3 --opt frame_batch=4
 b "C2 irregular 20" --scene dragon_irregular --steps 20 --warmup 5
 b "C2 irregular 240" --scene dragon_irregular --steps 240 --warmup 24
 b "C2 hostile 20" --scene dragon_hostile --steps 20 --warmup 5

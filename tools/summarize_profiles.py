@@ -21,7 +21,7 @@ def kname(n):
 sys.path.insert(0, ROOT)
 import bench
 res = {"tag": tag, "csrc_sha256": bench.csrc_hash()}      # bench.py shows these counters only for the source tree they were collected on
-for mode in ("driver", "serial", "serial4"):
+for mode in ("driver", "serial", "serial_pass"):
     ks = glob.glob(out + f"/trace_{mode}/**/*kernel_stats.csv", recursive=True)
     if not ks:
         continue
@@ -39,7 +39,7 @@ for mode in ("driver", "serial", "serial4"):
 
 
 def pmc_all():
-    """{kernel: {counter: mean per dispatch}} over every pmc_* directory; the runs use 4-frame passes with warm-up = one pass, so every dispatch is full size"""
+    """{kernel: {counter: mean per dispatch}} over every pmc_* directory; the runs use full passes (bench.PASS_FRAMES frames) with warm-up = one pass, so every dispatch is full size"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     newest = {}
     for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):      # one (the newest) file per pass directory
@@ -54,7 +54,8 @@ def pmc_all():
 
 
 pm, pn = pmc_all()
-res["pmc_mean_per_dispatch_of_4_frames"] = pm
+res["pmc_mean_per_dispatch"] = pm
+res["pmc_frames_per_dispatch"] = bench.PASS_FRAMES
 res["pmc_dispatches"] = {k: max(v.values()) for k, v in pn.items()}
 # HBM traffic per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2
 # (units: KB = 1024 B); other access widths are uncalibrated, so this is an upper estimate for gathers.
@@ -62,8 +63,8 @@ res["hbm_traffic_bytes_per_launch"] = {k: {"fetch_raw_KB": d.get("FETCH_SIZE"), 
                                            "bytes_corrected": (2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 if "FETCH_SIZE" in d else None} for k, d in pm.items()}
 res["valu_busy_pct"] = {k: d.get("VALUBusy") for k, d in pm.items()}
 res["valu_lane_utilization_pct"] = {k: d.get("VALUUtilization") for k, d in pm.items()}
-# VALU wave-instructions per FRAME: per 4-frame pass there is 1 primary, max_bounces shade, max_bounces trace and 1 accumulate dispatch
-B, BOUNCES = 4, 3
+# VALU wave-instructions per FRAME: per pass of B frames there is 1 primary, max_bounces shade, max_bounces trace and 1 accumulate dispatch
+B, BOUNCES = bench.PASS_FRAMES, 3
 per_pass = {"k_trace_primary": 1, "k_shade_primary": 1, "k_shade": BOUNCES - 1 if "k_shade_primary" in pm else BOUNCES, "k_trace_mixed_wide_persist": BOUNCES, "k_trace_mixed_wide_stream": BOUNCES, "k_accumulate": 1, "k_accumulate_planes": 1}
 insts = sum(pm[k].get("SQ_INSTS_VALU", 0.0) * n for k, n in per_pass.items() if k in pm)
 if insts:
@@ -87,4 +88,4 @@ for name in ("valu_rates", "calibrate"):
     except Exception as e:
         res[name] = str(e)
 json.dump(res, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if not k.startswith("bench_") and k not in ("valu_rates", "pmc_mean_per_dispatch_of_4_frames")}, indent=1)[:6000])
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("bench_") and k not in ("valu_rates", "pmc_mean_per_dispatch")}, indent=1)[:6000])
