@@ -468,10 +468,21 @@ __global__ void k_assign(TreeArrays t, uint32_t nnodes, uint32_t *__restrict__ n
     }
     new_index[nd] = dropped ? NONE : pre;
     leaf_offset[nd] = lrank;
+    if (depth == 0) stat[2] = nd;                   // the root (the one node without a parent)
     if (!dropped) {
         atomicMax(&stat[0], depth);
         if (t.collapsed[nd]) atomicAdd(&stat[1], 1u);
     }
+}
+
+// what the host wants to know about the finished tree, in one 48-byte read-back: {root, size, cost, depth, leaves, -, lo.xyz, hi.xyz}
+__global__ void k_build_summary(TreeArrays t, const uint32_t *__restrict__ stat, uint32_t *__restrict__ out) {
+    const uint32_t root = stat[2];
+    if (root == NONE) { out[0] = NONE; return; }
+    out[0] = root; out[1] = t.size[root]; out[2] = __float_as_uint(t.cost[root]); out[3] = stat[0]; out[4] = stat[1]; out[5] = 0;
+    const float4 lo = t.lo[root], hi = t.hi[root];
+    out[6] = __float_as_uint(lo.x); out[7] = __float_as_uint(lo.y); out[8] = __float_as_uint(lo.z);
+    out[9] = __float_as_uint(hi.x); out[10] = __float_as_uint(hi.y); out[11] = __float_as_uint(hi.z);
 }
 
 __global__ void k_emit_nodes(TreeArrays t, uint32_t nnodes, const uint32_t *__restrict__ new_index, const uint32_t *__restrict__ leaf_offset, float4 *__restrict__ out) {
@@ -965,15 +976,17 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     }
 
     const uint32_t T32 = (uint32_t)T;
+    ScratchArena arena;                                          // before the buffers that borrow from it
+    arena.chunk_bytes = ((size_t)T * 576 + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle): one allocation, more if pre-splitting adds references
     DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
     DevBuf<float4> tri_world, tri_lo, tri_hi, ref_lo, ref_hi, node_lo, node_hi;
     DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat, ref_tri;
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<float> cost;
     DevBuf<uint8_t> collapsed, mask;
-    MRT_HIP(d_pos.alloc(h_pos.size())); MRT_HIP(d_idx.alloc(h_idx.size())); MRT_HIP(d_recs.alloc(recs.size()));
-    MRT_HIP(tri_world.alloc(3 * (size_t)T32)); MRT_HIP(tri_lo.alloc(T32)); MRT_HIP(tri_hi.alloc(T32));
-    MRT_HIP(cbounds.alloc(6)); MRT_HIP(stat.alloc(4));
+    MRT_HIP(d_pos.alloc_in(arena, h_pos.size())); MRT_HIP(d_idx.alloc_in(arena, h_idx.size())); MRT_HIP(d_recs.alloc_in(arena, recs.size()));
+    MRT_HIP(tri_world.alloc_in(arena, 3 * (size_t)T32)); MRT_HIP(tri_lo.alloc_in(arena, T32)); MRT_HIP(tri_hi.alloc_in(arena, T32));
+    MRT_HIP(cbounds.alloc_in(arena, 6)); MRT_HIP(stat.alloc_in(arena, 4));
 
     struct EventPair {           // destroyed on every return path
         hipEvent_t a = nullptr, b = nullptr;
@@ -989,7 +1002,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
         MRT_HIP(hipMemcpyAsync(cbounds.p, init, sizeof init, hipMemcpyHostToDevice, stream));
     }
-    MRT_HIP(hipMemsetAsync(stat.p, 0, stat.bytes(), stream));
+    MRT_HIP(hipMemsetAsync(stat.p, 0xFF, stat.bytes(), stream));       // [0] depth and [1] leaves are cleared below; [2] = root stays NONE until k_assign finds it
+    MRT_HIP(hipMemsetAsync(stat.p, 0, 8, stream));
     const int B = 256;
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, B)), dim3(B), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
@@ -999,14 +1013,14 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const uint32_t *ref_tri_p = nullptr;
     if (opt.presplit > 0.0f && T32 >= 64) {
         DevBuf<unsigned long long> esum; DevBuf<uint32_t> cnt, off;
-        MRT_HIP(esum.alloc(1)); MRT_HIP(cnt.alloc((size_t)T32 + 1)); MRT_HIP(off.alloc((size_t)T32 + 1));
+        MRT_HIP(esum.alloc_in(arena, 1)); MRT_HIP(cnt.alloc_in(arena, (size_t)T32 + 1)); MRT_HIP(off.alloc_in(arena, (size_t)T32 + 1));
         MRT_HIP(hipMemsetAsync(esum.p, 0, 8, stream));
         MRT_HIP(hipMemsetAsync(cnt.p + T32, 0, 4, stream));
         hipLaunchKernelGGL(k_extent_sum, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p);
         hipLaunchKernelGGL(k_split_count, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p, opt.presplit, 32u, cnt.p);
         {   // exclusive scan of the counts: per-block scan, scan of the block sums, add; tot.p = number of references
             const uint32_t nb = cdiv(T32, 1024);
-            DevBuf<uint32_t> bsum, tot; MRT_HIP(bsum.alloc(nb + 1)); MRT_HIP(tot.alloc(1));
+            DevBuf<uint32_t> bsum, tot; MRT_HIP(bsum.alloc_in(arena, nb + 1)); MRT_HIP(tot.alloc_in(arena, 1));
             hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, cnt.p, off.p, bsum.p, T32);
             hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb);
             hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, off.p, bsum.p, T32, tot.p, cnt.p);
@@ -1018,7 +1032,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(hipStreamSynchronize(stream));
         if (total > T32 && (uint64_t)total <= 2ull * T32) {           // (more than twice the triangles: the criterion is wrong for this mesh; build unsplit)
             n = total;
-            MRT_HIP(ref_lo.alloc(n)); MRT_HIP(ref_hi.alloc(n)); MRT_HIP(ref_tri.alloc(n));
+            MRT_HIP(ref_lo.alloc_in(arena, n)); MRT_HIP(ref_hi.alloc_in(arena, n)); MRT_HIP(ref_tri.alloc_in(arena, n));
             hipLaunchKernelGGL(k_split_emit, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cnt.p, off.p, T32, ref_lo.p, ref_hi.p, ref_tri.p);
             MRT_HIP(hipStreamSynchronize(stream));                    // cnt / off die at scope exit
             leaf_lo_p = ref_lo.p; leaf_hi_p = ref_hi.p; ref_tri_p = ref_tri.p;
@@ -1028,13 +1042,13 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     if (int rc = layout_limits(n, 0)) return rc;
     const uint32_t nnodes = 2 * n - 1;
     const uint32_t leaf_base = n - 1;
-    MRT_HIP(node_lo.alloc(nnodes)); MRT_HIP(node_hi.alloc(nnodes));
-    MRT_HIP(keys_a.alloc(n)); MRT_HIP(keys_b.alloc(n)); MRT_HIP(vals_a.alloc(n)); MRT_HIP(vals_b.alloc(n));
+    MRT_HIP(node_lo.alloc_in(arena, nnodes)); MRT_HIP(node_hi.alloc_in(arena, nnodes));
+    MRT_HIP(keys_a.alloc_in(arena, n)); MRT_HIP(keys_b.alloc_in(arena, n)); MRT_HIP(vals_a.alloc_in(arena, n)); MRT_HIP(vals_b.alloc_in(arena, n));
     const uint32_t sort_blocks = cdiv(n, SORT_TILE);
-    MRT_HIP(ghist.alloc(256 * (size_t)sort_blocks));
-    MRT_HIP(parent.alloc(nnodes)); MRT_HIP(left.alloc(n)); MRT_HIP(right.alloc(n)); MRT_HIP(flags.alloc(nnodes));
-    MRT_HIP(ntri.alloc(nnodes)); MRT_HIP(size.alloc(nnodes)); MRT_HIP(cost.alloc(nnodes)); MRT_HIP(collapsed.alloc(nnodes)); MRT_HIP(mask.alloc(nnodes));
-    MRT_HIP(new_index.alloc(nnodes)); MRT_HIP(leaf_offset.alloc(nnodes));
+    MRT_HIP(ghist.alloc_in(arena, 256 * (size_t)sort_blocks));
+    MRT_HIP(parent.alloc_in(arena, nnodes)); MRT_HIP(left.alloc_in(arena, n)); MRT_HIP(right.alloc_in(arena, n)); MRT_HIP(flags.alloc_in(arena, nnodes));
+    MRT_HIP(ntri.alloc_in(arena, nnodes)); MRT_HIP(size.alloc_in(arena, nnodes)); MRT_HIP(cost.alloc_in(arena, nnodes)); MRT_HIP(collapsed.alloc_in(arena, nnodes)); MRT_HIP(mask.alloc_in(arena, nnodes));
+    MRT_HIP(new_index.alloc_in(arena, nnodes)); MRT_HIP(leaf_offset.alloc_in(arena, nnodes));
     MRT_HIP(hipMemsetAsync(flags.p, 0, flags.bytes(), stream));
     hipLaunchKernelGGL(k_morton, dim3(cdiv(n, B)), dim3(B), 0, stream, leaf_lo_p, leaf_hi_p, cbounds.p, n, keys_a.p, vals_a.p);
     // 8 passes of 8 bits over 64-bit keys; after the 8 swaps the sorted data is back in the first pair
@@ -1072,9 +1086,9 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         // PLOC rounds; cluster arrays double as scratch
         DevBuf<uint32_t> cid, ncid, nn, keep, pos, bsum, counter;
         DevBuf<float4> clo, chi, nlo, nhi;
-        MRT_HIP(cid.alloc(n)); MRT_HIP(ncid.alloc(n)); MRT_HIP(nn.alloc(n)); MRT_HIP(keep.alloc(n)); MRT_HIP(pos.alloc(n));
-        MRT_HIP(bsum.alloc(cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc(2));
-        MRT_HIP(clo.alloc(n)); MRT_HIP(chi.alloc(n)); MRT_HIP(nlo.alloc(n)); MRT_HIP(nhi.alloc(n));
+        MRT_HIP(cid.alloc_in(arena, n)); MRT_HIP(ncid.alloc_in(arena, n)); MRT_HIP(nn.alloc_in(arena, n)); MRT_HIP(keep.alloc_in(arena, n)); MRT_HIP(pos.alloc_in(arena, n));
+        MRT_HIP(bsum.alloc_in(arena, cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc_in(arena, 2));
+        MRT_HIP(clo.alloc_in(arena, n)); MRT_HIP(chi.alloc_in(arena, n)); MRT_HIP(nlo.alloc_in(arena, n)); MRT_HIP(nhi.alloc_in(arena, n));
         MRT_HIP(hipMemsetAsync(counter.p, 0, 8, stream));
         hipLaunchKernelGGL(k_ploc_init, dim3(cdiv(n, B)), dim3(B), 0, stream, n, leaf_base, vin, leaf_lo_p, leaf_hi_p, cid.p, clo.p, chi.p);
         uint32_t m = n;
@@ -1104,11 +1118,11 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     DevBuf<float> dpC; DevBuf<uint8_t> dpD;
     WideDP dp{nullptr, nullptr};
     if (opt.wide && opt.max_leaf <= 4 && opt.wide_collapse) {
-        MRT_HIP(dpC.alloc(8 * (size_t)nnodes)); MRT_HIP(dpD.alloc(8 * (size_t)nnodes));
+        MRT_HIP(dpC.alloc_in(arena, 8 * (size_t)nnodes)); MRT_HIP(dpD.alloc_in(arena, 8 * (size_t)nnodes));
         dp.C = dpC.p; dp.dec = dpD.p;
     }
     DevBuf<float4> refit_aux;
-    MRT_HIP(refit_aux.alloc(nnodes));
+    MRT_HIP(refit_aux.alloc_in(arena, nnodes));
     hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
                        dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
@@ -1120,23 +1134,20 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.packets_offset = 4 * (size_t)nnodes;
     hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, out.nodes.p);
     hipLaunchKernelGGL(k_emit_packets, dim3(cdiv(n, B)), dim3(B), 0, stream, vin, leaf_offset.p, leaf_base, n, tri_world.p, ref_tri_p, packets_p);
+    // ---- stats: the root (k_assign found it), its size, cost and box, depth and leaf count in one small read-back
+    DevBuf<uint32_t> summary; MRT_HIP(summary.alloc_in(arena, 12));
+    hipLaunchKernelGGL(k_build_summary, dim3(1), dim3(1), 0, stream, t, stat.p, summary.p);
     MRT_HIP(hipEventRecord(ev1, stream));
+    uint32_t h_sum[12];
+    MRT_HIP(hipMemcpyAsync(h_sum, summary.p, sizeof h_sum, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-
-    // ---- stats: find the root (new_index == 0) on the host side from a small readback
-    std::vector<uint32_t> h_new(nnodes);
-    MRT_HIP(hipMemcpy(h_new.data(), new_index.p, nnodes * 4, hipMemcpyDeviceToHost));
-    uint32_t root = NONE;
-    for (uint32_t i = 0; i < nnodes; i++) if (h_new[i] == 0) { root = i; break; }
-    if (root == NONE) { set_error("BVH build produced no root"); return MRT_ERR_HIP; }
-    uint32_t h_size = 0; float h_cost = 0; float4 rlo, rhi; uint32_t h_stat[4];
-    MRT_HIP(hipMemcpy(&h_size, size.p + root, 4, hipMemcpyDeviceToHost));
-    MRT_HIP(hipMemcpy(&h_cost, cost.p + root, 4, hipMemcpyDeviceToHost));
-    MRT_HIP(hipMemcpy(&rlo, node_lo.p + root, 16, hipMemcpyDeviceToHost));
-    MRT_HIP(hipMemcpy(&rhi, node_hi.p + root, 16, hipMemcpyDeviceToHost));
-    MRT_HIP(hipMemcpy(h_stat, stat.p, 16, hipMemcpyDeviceToHost));
+    const uint32_t root = h_sum[0];
+    if (root >= nnodes) { set_error("BVH build produced no root"); return MRT_ERR_HIP; }
+    const uint32_t h_size = h_sum[1]; const uint32_t h_stat[2] = {h_sum[3], h_sum[4]};
+    float h_cost; memcpy(&h_cost, &h_sum[2], 4);
+    float4 rlo, rhi; memcpy(&rlo.x, &h_sum[6], 12); memcpy(&rhi.x, &h_sum[9], 12);
     if (int rc = layout_limits(T, h_size)) return rc;           // the surviving node count must fit the 24-bit child index
     float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
     float area = 2.0f * (dx * dy + dy * dz + dz * dx);
@@ -1155,7 +1166,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         // at least two children and every leaf child at least one triangle, so there are fewer wide nodes than triangles.  The array is trimmed below.
         const size_t max_w = opt.wide_collapse ? (size_t)n + 2 : (size_t)h_size / 2 + 2;
         DevBuf<uint32_t> fa, fb, wc;
-        MRT_HIP(fa.alloc(max_w)); MRT_HIP(fb.alloc(max_w)); MRT_HIP(wc.alloc(2));
+        MRT_HIP(fa.alloc_in(arena, max_w)); MRT_HIP(fb.alloc_in(arena, max_w)); MRT_HIP(wc.alloc_in(arena, 2));
         MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(WPK * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
         MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));

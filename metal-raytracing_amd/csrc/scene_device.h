@@ -107,17 +107,45 @@ struct SceneView {           // passed by value to kernels
     int32_t max_sub;
 };
 
+// Scratch memory of one build: a few large allocations handed out in 256-byte-aligned pieces and freed together (a build used to make ~60 hipMalloc / hipFree
+// pairs, each a few tens of microseconds and the frees device-synchronising).  Declare it before the buffers that borrow from it.
+struct ScratchArena {
+    std::vector<void *> chunks; uint8_t *cur = nullptr; size_t left = 0, chunk_bytes = (size_t)1 << 20;
+    ScratchArena() = default;
+    ScratchArena(const ScratchArena &) = delete; ScratchArena &operator=(const ScratchArena &) = delete;
+    ~ScratchArena() { for (void *c : chunks) (void)hipFree(c); }
+    hipError_t take(void **out, size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) {
+            const size_t c = bytes > chunk_bytes ? bytes : chunk_bytes;
+            void *m = nullptr;
+            hipError_t e = hipMalloc(&m, c);
+            if (e != hipSuccess) return e;
+            chunks.push_back(m); cur = (uint8_t *)m; left = c;
+        }
+        *out = cur; cur += bytes; left -= bytes;
+        return hipSuccess;
+    }
+};
+
 template <class T> struct DevBuf {
-    T *p = nullptr; size_t n = 0;
+    T *p = nullptr; size_t n = 0; bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
     hipError_t alloc(size_t count, unsigned flags = 0 /* hipDeviceMallocDefault; hipDeviceMallocUncached for streamed buffers (experiment) */) {
         release();
         if (count == 0) count = 1;
         hipError_t e = flags ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), flags) : hipMalloc((void **)&p, count * sizeof(T));
         if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    hipError_t alloc_in(ScratchArena &a, size_t count) {       // a piece of the arena: not freed here, gone with the arena
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = a.take((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) { n = count; owned = false; } else p = nullptr;
         return e;
     }
     size_t bytes() const { return n * sizeof(T); }

@@ -5,6 +5,7 @@ targets, buffers, acceleration structures); `draw()` is `draw(in:)` — one fram
 dispatch, ping-pong swap.  There is no MTKView: the tonemap pass writes RGBA8 to host memory
 instead of a drawable (`tonemapped()`).
 """
+import time
 import ctypes as C
 
 import numpy as np
@@ -59,7 +60,9 @@ class DeviceScene:
                 idx = np.ascontiguousarray(idx, np.uint32)
                 check(lib.mrt_mesh_add_submesh(self.handle, mid.value, ptr(idx), idx.shape[0], C.byref(mat), None))
         self.set_lights(scene.lights)
+        t0 = time.perf_counter()
         check(lib.mrt_scene_commit(self.handle))
+        self.commit_wall_ms = (time.perf_counter() - t0) * 1e3      # host wall time of the commit (uploads, build, validation); stats.build_ms is the device time of the build alone
 
     def set_instance_transform(self, mesh_id, transform):
         """Animated transforms: new object->world matrix for one instance; call commit() afterwards."""

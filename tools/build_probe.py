@@ -10,10 +10,11 @@ S = mrt.SCENES
 for name, scene, opts in (("cornell", S["cornell"]((256, 256)), {}), ("dragon", S["dragon"]((1920, 1080)), {}), ("dragon builder 0 (Karras)", S["dragon"]((1920, 1080)), {"builder": 0}),
                           ("dragon hostile", S["dragon_hostile"]((1920, 1080)), {}), ("garden", S["garden"]((3840, 2160)), {}),
                           ("dragon4 flat", S["dragon4"]((1920, 1080)), {}), ("dragon4 two-level", S["dragon4"]((1920, 1080)), {"instancing": 1})):
-    best, st = None, None
+    best, st, wall = None, None, None
     for _ in range(a.reps):
         d = mrt.DeviceScene(ctx, scene, opts)
         st = d.stats
         best = st.build_ms if best is None else min(best, st.build_ms)
+        wall = d.commit_wall_ms if wall is None else min(wall, d.commit_wall_ms)
         d.close()
-    print(f"{name:26s} triangles {st.triangles:8d} build {best:7.3f} ms = {st.triangles / best / 1e3:6.1f} Mtris/s  nodes {st.bvh_nodes} leaves {st.bvh_leaves} depth {st.max_depth} sah {st.sah_cost:.4f}", flush=True)
+    print(f"{name:26s} triangles {st.triangles:8d} build {best:7.3f} ms = {st.triangles / best / 1e3:6.1f} Mtris/s  commit wall {wall:7.2f} ms  nodes {st.bvh_nodes} leaves {st.bvh_leaves} depth {st.max_depth} sah {st.sah_cost:.4f}", flush=True)
