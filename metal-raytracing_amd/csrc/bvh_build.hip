@@ -86,11 +86,22 @@ __global__ void k_flatten(const SubRec *__restrict__ recs, int nrec, const float
         leaf_lo[gid] = make_float4(blo[0], blo[1], blo[2], 0.0f);
         leaf_hi[gid] = make_float4(bhi[0], bhi[1], bhi[2], 0.0f);
     }
+    // bounds of the centres: wave, then workgroup (LDS), then one set of atomics per workgroup — the six words take ~90 atomics per microsecond, and one set per
+    // wave (14 K waves for 885 K triangles) was the whole duration of this kernel (0.95 ms)
     const float BIG = 3.0e38f;
+    __shared__ float smn[3][16], smx[3][16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float mn = wave_min(valid ? c[k] : BIG), mx = wave_max(valid ? c[k] : -BIG);
-        if ((threadIdx.x & 63) == 0 && mn <= mx) { atomicMin(&cbounds[k], f2ord(mn)); atomicMax(&cbounds[3 + k], f2ord(mx)); }
+        if (lane == 0) { smn[k][wv] = mn; smx[k][wv] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = (int)threadIdx.x;
+        float mn = BIG, mx = -BIG;
+        for (uint32_t i = 0; i < nw; i++) { mn = fminf(mn, smn[k][i]); mx = fmaxf(mx, smx[k][i]); }
+        if (mn <= mx) { atomicMin(&cbounds[k], f2ord(mn)); atomicMax(&cbounds[3 + k], f2ord(mx)); }
     }
 }
 
@@ -114,7 +125,14 @@ __global__ void k_extent_sum(const float4 *__restrict__ leaf_lo, const float4 *_
         v = (unsigned long long)(r * 1073741824.0f);
     }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+    __shared__ unsigned long long sv[16];                        // one atomic per workgroup (see k_flatten)
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (uint32_t i = 0; i < ((blockDim.x + 63) >> 6); i++) tot += sv[i];
+        if (tot) atomicAdd(sum, tot);
+    }
 }
 MRT_DEV uint32_t split_pieces(float4 lo, float4 hi, float scene, unsigned long long sum, uint32_t T, float factor, uint32_t max_pieces, int &ax, float &ext) {
     const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
@@ -457,21 +475,31 @@ __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const f
 // ------------------------------------------------------------------ numbering + emit
 __global__ void k_assign(TreeArrays t, uint32_t nnodes, uint32_t *__restrict__ new_index, uint32_t *__restrict__ leaf_offset, uint32_t *__restrict__ stat /*[0]=max depth,[1]=leaves*/) {
     uint32_t nd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nd >= nnodes) return;
-    bool dropped = false;
-    uint32_t pre = 0, lrank = 0, depth = 0, c = nd, p;
-    while ((p = t.parent[c]) != NONE) {
-        if (t.collapsed[p]) dropped = true;
-        uint32_t l = t.left[p];
-        if (l != c) { pre += t.size[l]; lrank += t.ntri[l]; }
-        pre += 1; depth++; c = p;
+    uint32_t my_depth = 0, my_leaf = 0;
+    if (nd < nnodes) {
+        bool dropped = false;
+        uint32_t pre = 0, lrank = 0, depth = 0, c = nd, p;
+        while ((p = t.parent[c]) != NONE) {
+            if (t.collapsed[p]) dropped = true;
+            uint32_t l = t.left[p];
+            if (l != c) { pre += t.size[l]; lrank += t.ntri[l]; }
+            pre += 1; depth++; c = p;
+        }
+        new_index[nd] = dropped ? NONE : pre;
+        leaf_offset[nd] = lrank;
+        if (depth == 0) stat[2] = nd;               // the root (the one node without a parent)
+        if (!dropped) { my_depth = depth; my_leaf = t.collapsed[nd] ? 1u : 0u; }
     }
-    new_index[nd] = dropped ? NONE : pre;
-    leaf_offset[nd] = lrank;
-    if (depth == 0) stat[2] = nd;                   // the root (the one node without a parent)
-    if (!dropped) {
-        atomicMax(&stat[0], depth);
-        if (t.collapsed[nd]) atomicAdd(&stat[1], 1u);
+    // depth and leaf count: one pair of atomics per workgroup (one per wave was this kernel's whole duration)
+    __shared__ uint32_t sd[16], sl[16];
+    for (int o = 32; o > 0; o >>= 1) { my_depth = max(my_depth, (uint32_t)__shfl_xor((int)my_depth, o)); my_leaf += (uint32_t)__shfl_xor((int)my_leaf, o); }
+    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = my_depth; sl[threadIdx.x >> 6] = my_leaf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t d = 0, l = 0;
+        for (uint32_t i = 0; i < ((blockDim.x + 63) >> 6); i++) { d = max(d, sd[i]); l += sl[i]; }
+        atomicMax(&stat[0], d);
+        if (l) atomicAdd(&stat[1], l);
     }
 }
 
@@ -560,11 +588,24 @@ __global__ void k_ploc_merge(uint32_t m, const uint32_t *__restrict__ nn, const 
                              uint32_t *__restrict__ node_counter, uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
                              float4 *__restrict__ node_lo, float4 *__restrict__ node_hi) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = i < m ? nn[i] : NONE;
+    const bool mutual = (j != NONE) && (nn[j] == i);
+    // node ids: one atomic per workgroup (one per wave — 14 K in the first round — was this kernel's duration), then rank within the workgroup
+    __shared__ uint32_t wcnt[16], wbase[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long creators = __ballot(mutual && i < j);
+    if (lane == 0) wcnt[wv] = (uint32_t)__popcll(creators);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < ((blockDim.x + 63) >> 6); k++) { wbase[k] = tot; tot += wcnt[k]; }
+        const uint32_t base = tot ? atomicAdd(node_counter, tot) : 0u;
+        for (uint32_t k = 0; k < ((blockDim.x + 63) >> 6); k++) wbase[k] += base;
+    }
+    __syncthreads();
     if (i >= m) return;
-    uint32_t j = nn[i];
-    bool mutual = (j != NONE) && (nn[j] == i);
     if (mutual && i < j) {
-        uint32_t id = atomicAdd(node_counter, 1u);
+        uint32_t id = wbase[wv] + (uint32_t)__popcll(creators & ((1ull << lane) - 1ull));
         uint32_t a = cid[i], b = cid[j];
         left[id] = a; right[id] = b; parent[a] = id; parent[b] = id;
         float4 lo = make_float4(fminf(clo[i].x, clo[j].x), fminf(clo[i].y, clo[j].y), fminf(clo[i].z, clo[j].z), 0.0f);
@@ -1005,7 +1046,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(hipMemsetAsync(stat.p, 0xFF, stat.bytes(), stream));       // [0] depth and [1] leaves are cleared below; [2] = root stays NONE until k_assign finds it
     MRT_HIP(hipMemsetAsync(stat.p, 0, 8, stream));
     const int B = 256;
-    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, B)), dim3(B), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, T32,
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
     uint32_t n = T32;
@@ -1016,7 +1057,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(esum.alloc_in(arena, 1)); MRT_HIP(cnt.alloc_in(arena, (size_t)T32 + 1)); MRT_HIP(off.alloc_in(arena, (size_t)T32 + 1));
         MRT_HIP(hipMemsetAsync(esum.p, 0, 8, stream));
         MRT_HIP(hipMemsetAsync(cnt.p + T32, 0, 4, stream));
-        hipLaunchKernelGGL(k_extent_sum, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p);
+        hipLaunchKernelGGL(k_extent_sum, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p);
         hipLaunchKernelGGL(k_split_count, dim3(cdiv(T32, B)), dim3(B), 0, stream, tri_world.p, tri_lo.p, tri_hi.p, cbounds.p, T32, esum.p, opt.presplit, 32u, cnt.p);
         {   // exclusive scan of the counts: per-block scan, scan of the block sums, add; tot.p = number of references
             const uint32_t nb = cdiv(T32, 1024);
@@ -1096,7 +1137,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         while (m > PLOC_TAIL) {
             if (++guard > 4096) { set_error("PLOC did not converge"); return MRT_ERR_HIP; }
             hipLaunchKernelGGL(k_ploc_nn, dim3(cdiv(m, B)), dim3(B), 0, stream, m, opt.ploc_radius, clo.p, chi.p, nn.p);
-            hipLaunchKernelGGL(k_ploc_merge, dim3(cdiv(m, B)), dim3(B), 0, stream, m, nn.p, cid.p, clo.p, chi.p, keep.p, ncid.p, nlo.p, nhi.p,
+            hipLaunchKernelGGL(k_ploc_merge, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, nn.p, cid.p, clo.p, chi.p, keep.p, ncid.p, nlo.p, nhi.p,
                                counter.p, left.p, right.p, parent.p, node_lo.p, node_hi.p);
             uint32_t nb = cdiv(m, 1024);
             hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, keep.p, pos.p, bsum.p, m);
@@ -1125,7 +1166,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(refit_aux.alloc_in(arena, nnodes));
     hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
                        dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
-    hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
+    hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, 1024)), dim3(1024), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
     // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
     // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
     // one allocation: [nodes (worst case 2n-1) | packets], so the traversal addresses both from one base
