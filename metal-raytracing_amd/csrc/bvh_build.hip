@@ -251,24 +251,28 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_hist(const uint64_t *__re
     ghist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of `count` uint32 in place, single workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) k_scan_exclusive(uint32_t *__restrict__ data, uint32_t count) {
+// exclusive scan of `count` uint32 in place, single workgroup of 1024 threads, four entries per thread and step
+__global__ void __launch_bounds__(1024) k_scan_exclusive(uint32_t *__restrict__ data, uint32_t count, const uint32_t *__restrict__ items_dev /* count = ceil(*items_dev / 1024) */) {
+    if (items_dev) count = (*items_dev + 1023u) >> 10;
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < count; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < count ? data[i] : 0;
-        uint32_t x = v;
+    for (uint32_t base = 0; base < count; base += 4096) {
+        const uint32_t i = base + 4 * threadIdx.x;
+        uint32_t v[4];
+        for (int k = 0; k < 4; k++) v[k] = i + k < count ? data[i + k] : 0;
+        const uint32_t s4 = v[0] + v[1] + v[2] + v[3];
+        uint32_t x = s4;
         for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
         if (lane == 63) wsum[w] = x;
         __syncthreads();
         uint32_t woff = 0;
         for (uint32_t k = 0; k < w; k++) woff += wsum[k];
-        uint32_t carry = carry_s;
-        if (i < count) data[i] = carry + woff + x - v;
+        const uint32_t carry = carry_s;
+        uint32_t e = carry + woff + x - s4;
+        for (int k = 0; k < 4; k++) { if (i + k < count) data[i + k] = e; e += v[k]; }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + woff + x;
         __syncthreads();
@@ -566,7 +570,10 @@ __global__ void k_ploc_init(uint32_t n, uint32_t leaf_base, const uint32_t *__re
     cid[j] = leaf_base + j; clo[j] = leaf_lo[gid]; chi[j] = leaf_hi[gid];
 }
 
-__global__ void k_ploc_nn(uint32_t m, int radius, const float4 *__restrict__ clo, const float4 *__restrict__ chi, uint32_t *__restrict__ nn) {
+// (m_dev, here and below: the cluster count of this round as the previous round left it on the device — the host launches a few rounds on its last known count,
+// an upper bound, and reads the count back once per batch instead of once per round)
+__global__ void k_ploc_nn(uint32_t m, int radius, const float4 *__restrict__ clo, const float4 *__restrict__ chi, uint32_t *__restrict__ nn, const uint32_t *__restrict__ m_dev) {
+    if (m_dev) m = *m_dev;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     float4 lo = clo[i], hi = chi[i];
@@ -586,7 +593,8 @@ __global__ void k_ploc_nn(uint32_t m, int radius, const float4 *__restrict__ clo
 __global__ void k_ploc_merge(uint32_t m, const uint32_t *__restrict__ nn, const uint32_t *__restrict__ cid, const float4 *__restrict__ clo, const float4 *__restrict__ chi,
                              uint32_t *__restrict__ keep /* 1 = survives (possibly as merged) */, uint32_t *__restrict__ new_cid, float4 *__restrict__ nlo, float4 *__restrict__ nhi,
                              uint32_t *__restrict__ node_counter, uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
-                             float4 *__restrict__ node_lo, float4 *__restrict__ node_hi) {
+                             float4 *__restrict__ node_lo, float4 *__restrict__ node_hi, const uint32_t *__restrict__ m_dev) {
+    if (m_dev) m = *m_dev;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = i < m ? nn[i] : NONE;
     const bool mutual = (j != NONE) && (nn[j] == i);
@@ -621,14 +629,16 @@ __global__ void k_ploc_merge(uint32_t m, const uint32_t *__restrict__ nn, const 
 
 __global__ void k_ploc_compact(uint32_t m, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos /* exclusive scan of keep */,
                                const uint32_t *__restrict__ new_cid, const float4 *__restrict__ nlo, const float4 *__restrict__ nhi,
-                               uint32_t *__restrict__ cid, float4 *__restrict__ clo, float4 *__restrict__ chi) {
+                               uint32_t *__restrict__ cid, float4 *__restrict__ clo, float4 *__restrict__ chi, const uint32_t *__restrict__ m_dev) {
+    if (m_dev) m = *m_dev;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     if (keep[i]) { uint32_t p = pos[i]; cid[p] = new_cid[i]; clo[p] = nlo[i]; chi[p] = nhi[i]; }
 }
 
 // multi-block exclusive scan: per-block sums -> scan -> add
-__global__ void __launch_bounds__(1024) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ bsum, uint32_t count) {
+__global__ void __launch_bounds__(1024) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ bsum, uint32_t count, const uint32_t *__restrict__ count_dev) {
+    if (count_dev) count = *count_dev;
     __shared__ uint32_t wsum[16];
     uint32_t i = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -641,7 +651,8 @@ __global__ void __launch_bounds__(1024) k_scan_block(const uint32_t *__restrict_
     if (i < count) out[i] = woff + x - v;
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ bsum_scanned, uint32_t count, uint32_t *__restrict__ total, const uint32_t *__restrict__ last_in) {
+__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ bsum_scanned, uint32_t count, uint32_t *__restrict__ total, const uint32_t *__restrict__ last_in, const uint32_t *__restrict__ count_dev) {
+    if (count_dev) count = *count_dev;
     uint32_t i = blockIdx.x * 1024 + threadIdx.x;
     if (i < count) {
         uint32_t v = out[i] + bsum_scanned[blockIdx.x];
@@ -654,6 +665,7 @@ __global__ void k_set_root_parent(const uint32_t *__restrict__ cid, uint32_t *__
 // host read-back each) the clusters fit in LDS and the rounds need a barrier, not a launch.  Same rounds, same pairs, same order as the kernels above (node ids are
 // handed out in a different order; the numbering of the emitted tree does not depend on them).
 constexpr uint32_t PLOC_TAIL = 1024;
+constexpr int PLOC_ROUNDS_PER_READBACK = 4;     // a round removes at most half the clusters: more than 1024 / 16 are left when a batch ends
 __global__ void __launch_bounds__(1024) k_ploc_tail(uint32_t m, int radius, const uint32_t *__restrict__ cid, const float4 *__restrict__ clo, const float4 *__restrict__ chi,
                                                     uint32_t *__restrict__ node_counter, uint32_t *__restrict__ left, uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
                                                     float4 *__restrict__ node_lo, float4 *__restrict__ node_hi) {
@@ -1062,9 +1074,9 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         {   // exclusive scan of the counts: per-block scan, scan of the block sums, add; tot.p = number of references
             const uint32_t nb = cdiv(T32, 1024);
             DevBuf<uint32_t> bsum, tot; MRT_HIP(bsum.alloc_in(arena, nb + 1)); MRT_HIP(tot.alloc_in(arena, 1));
-            hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, cnt.p, off.p, bsum.p, T32);
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb);
-            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, off.p, bsum.p, T32, tot.p, cnt.p);
+            hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, cnt.p, off.p, bsum.p, T32, nullptr);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb, nullptr);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, off.p, bsum.p, T32, tot.p, cnt.p, nullptr);
             MRT_HIP(hipMemcpyAsync(off.p + T32, tot.p, 4, hipMemcpyDeviceToDevice, stream));
             MRT_HIP(hipStreamSynchronize(stream));
         }
@@ -1098,7 +1110,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         for (int pass = 0; pass < 8; pass++) {
             int shift = pass * 8;
             hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SORT_THREADS), 0, stream, ka, count, shift, nb, hist);
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, hist, 256 * nb);
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, hist, 256 * nb, nullptr);
             hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SORT_THREADS), 0, stream, ka, va, kb, vb, hist, count, shift, nb);
             std::swap(ka, kb); std::swap(va, vb);
         }
@@ -1128,24 +1140,29 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         DevBuf<uint32_t> cid, ncid, nn, keep, pos, bsum, counter;
         DevBuf<float4> clo, chi, nlo, nhi;
         MRT_HIP(cid.alloc_in(arena, n)); MRT_HIP(ncid.alloc_in(arena, n)); MRT_HIP(nn.alloc_in(arena, n)); MRT_HIP(keep.alloc_in(arena, n)); MRT_HIP(pos.alloc_in(arena, n));
-        MRT_HIP(bsum.alloc_in(arena, cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc_in(arena, 2));
+        MRT_HIP(bsum.alloc_in(arena, cdiv(n, 1024) + 1)); MRT_HIP(counter.alloc_in(arena, 4));
         MRT_HIP(clo.alloc_in(arena, n)); MRT_HIP(chi.alloc_in(arena, n)); MRT_HIP(nlo.alloc_in(arena, n)); MRT_HIP(nhi.alloc_in(arena, n));
-        MRT_HIP(hipMemsetAsync(counter.p, 0, 8, stream));
+        MRT_HIP(hipMemsetAsync(counter.p, 0, 16, stream));
         hipLaunchKernelGGL(k_ploc_init, dim3(cdiv(n, B)), dim3(B), 0, stream, n, leaf_base, vin, leaf_lo_p, leaf_hi_p, cid.p, clo.p, chi.p);
         uint32_t m = n;
-        int guard = 0;
+        int guard = 0, round = 0;
+        MRT_HIP(hipMemsetD32Async((hipDeviceptr_t)(counter.p + 1), (int)n, 1, stream));       // the count round 0 reads; rounds alternate between counter[1] and counter[2]
         while (m > PLOC_TAIL) {
             if (++guard > 4096) { set_error("PLOC did not converge"); return MRT_ERR_HIP; }
-            hipLaunchKernelGGL(k_ploc_nn, dim3(cdiv(m, B)), dim3(B), 0, stream, m, opt.ploc_radius, clo.p, chi.p, nn.p);
-            hipLaunchKernelGGL(k_ploc_merge, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, nn.p, cid.p, clo.p, chi.p, keep.p, ncid.p, nlo.p, nhi.p,
-                               counter.p, left.p, right.p, parent.p, node_lo.p, node_hi.p);
-            uint32_t nb = cdiv(m, 1024);
-            hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, keep.p, pos.p, bsum.p, m);
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb);
-            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, pos.p, bsum.p, m, counter.p + 1, keep.p);
-            hipLaunchKernelGGL(k_ploc_compact, dim3(cdiv(m, B)), dim3(B), 0, stream, m, keep.p, pos.p, ncid.p, nlo.p, nhi.p, cid.p, clo.p, chi.p);
+            // a batch of rounds on grids sized for the last count the host has seen; every kernel takes the round's count from the device
+            for (int k = 0; k < PLOC_ROUNDS_PER_READBACK; k++, round++) {
+                const uint32_t *m_in = counter.p + 1 + (round & 1); uint32_t *m_out = counter.p + 1 + ((round + 1) & 1);
+                hipLaunchKernelGGL(k_ploc_nn, dim3(cdiv(m, B)), dim3(B), 0, stream, m, opt.ploc_radius, clo.p, chi.p, nn.p, m_in);
+                hipLaunchKernelGGL(k_ploc_merge, dim3(cdiv(m, 1024)), dim3(1024), 0, stream, m, nn.p, cid.p, clo.p, chi.p, keep.p, ncid.p, nlo.p, nhi.p,
+                                   counter.p, left.p, right.p, parent.p, node_lo.p, node_hi.p, m_in);
+                uint32_t nb = cdiv(m, 1024);
+                hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, stream, keep.p, pos.p, bsum.p, m, m_in);
+                hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, bsum.p, nb, m_in);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, pos.p, bsum.p, m, m_out, keep.p, m_in);
+                hipLaunchKernelGGL(k_ploc_compact, dim3(cdiv(m, B)), dim3(B), 0, stream, m, keep.p, pos.p, ncid.p, nlo.p, nhi.p, cid.p, clo.p, chi.p, m_in);
+            }
             uint32_t new_m = 0;
-            MRT_HIP(hipMemcpyAsync(&new_m, counter.p + 1, 4, hipMemcpyDeviceToHost, stream));
+            MRT_HIP(hipMemcpyAsync(&new_m, counter.p + 1 + (round & 1), 4, hipMemcpyDeviceToHost, stream));
             MRT_HIP(hipStreamSynchronize(stream));
             if (new_m >= m || new_m == 0) { set_error("PLOC made no progress"); return MRT_ERR_HIP; }
             m = new_m;
