@@ -250,7 +250,8 @@ int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
  * single frame), "sample_offset", "throughput_chain" (bounce rays carry the resource slots of their path instead of a throughput record),
  * "shadow_planes" (a contribution plane per bounce and one byte per shadow ray that got through instead of a contribution queue), "fuse_primary"
  * (primary rays generated, traced and shaded in one launch: 0 never, 1 except for one frame alone, 2 always), "tail_accumulate" (the last passes of a
- * draw accumulated in one launch), "halton_table",
+ * draw accumulated in one launch), "stream_even" (traversal launches too small for chunk pulling: percent of the wave slots launched as waves, the rays
+ * split evenly among them; default 200, 0 = fixed ranges), "halton_table",
  * "flow" (experiment: one launch per pass after the primary trace, csrc/flow.h; with "flow_chunk", "flow_granule", "flow_take", "flow_session_rays",
  * "flow_exit_rays", "flow_idle_polls", "flow_slots", "flow_order", "flow_mix"), and the A/B switches "fused", "wide_bounce", "wide_stream",
  * "primary_wide", "shadow_rope", "wide"; read-only through mrt_renderer_get_option: "lanes_used", "lane_bytes".  Every setting renders the same

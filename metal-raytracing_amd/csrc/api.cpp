@@ -440,6 +440,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= (r->r.materials ? 16 : 19), "max_bounces must be in [1,19] ([1,16] with materials = 1)"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
+    else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
     else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
     else if (k == "megakernel") r->r.megakernel = value != 0;
     else if (k == "fused") r->r.fused = value != 0;
@@ -480,6 +481,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     std::string k(key);
     if (k == "max_bounces") *value = r->r.max_bounces;
     else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
+    else if (k == "stream_even") *value = r->r.stream_even;
     else if (k == "frame_batch") *value = r->r.frame_batch;
     else if (k == "lanes_used") *value = r->r.lanes_used;
     else if (k == "lane_bytes") *value = (double)r->r.lane_bytes();

@@ -89,6 +89,7 @@ struct Renderer {
     bool tail_accumulate = true;         // the last passes of a draw (one per lane) are accumulated in one launch after the join instead of one after the other
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
+    int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
     bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)
     bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
     bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)

@@ -29,5 +29,6 @@ for world in [int(x) for x in a.worlds.split(",")]:
             rate = (st.closest_rays + st.shadow_rays) / dt / 1e6
             best = max(best or 0.0, rate)
         if world == 1: base = max(base or 0.0, best)
+        if base is None: base = float('nan')
         print(f"world {world} frame_batch {fb:2d}: rank rate {best:8.1f} Mrays/s  x{world} = {best * world:8.1f}  efficiency vs best 1-GPU {best * world / base:5.2f}", flush=True)
         r.close()
