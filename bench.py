@@ -310,7 +310,7 @@ def main():
             kernel_label = "k_trace_mixed_wide (8-wide layout, one ray per lane)"
         else:
             pers = int(r.get_option("persistent"))
-            pulls = pers == 1 or (pers == 2 and (2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 1024 or min(int(r.get_option("lanes_used")), passes) >= 5))      # renderer.hip render(): the same rule
+            pulls = pers == 1 or (pers == 2 and (2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 1024 or (min(int(r.get_option("lanes_used")), passes) >= 5 and 2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 256)))      # renderer.hip render(): the same rule
             kernel_label = ("k_trace_mixed_wide_persist" if pulls else "k_trace_mixed_wide_stream") + ("<two-level>" if two_level else "") + " (bounce + shadow traversal)"
         traffic_p = (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected") if prof else None
         out = {

@@ -1547,7 +1547,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 // [r3] smaller launches pull as well when five or more passes are in flight (6 lanes x one-frame passes: 9.33 against 8.76 Grays/s; a rank of eight over 240 frames
                 // in 8-frame passes: 9.43 against 8.56); with one to three passes in flight they do better on the even static split (one frame alone 1.51 against 1.76 ms, 3 x 1 frame
                 // 7.63 against 7.20 Grays/s, a rank of eight over the driver's 20 frames 6.65 against 5.73): stream_even below
-                const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || std::min(F, n_passes) >= 5));
+                const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || (std::min(F, n_passes) >= 5 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 256)));      // (below 256 slots per wave slot — Cornell 256^2 in 8-frame passes — the even split: 6.46 against 5.40 Grays/s)
                 if (ablate & 2) {}
                 else if (on_wide && wide_stream && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
