@@ -609,24 +609,61 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
 
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
-template <bool TWO_LEVEL>
-__global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave) {
+template <bool TWO_LEVEL, bool SEED>
+__global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t capacity, uint32_t rays_per_wave,
+                                                                     uint32_t *__restrict__ hint /* SEED: per pixel, the (packet | instance << 24) its primary ray hit last */) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t begin = blockIdx.x * rays_per_wave, sub = blockIdx.y;
     if (begin >= capacity) return;
     hits += (size_t)sub * capacity; dirs += (size_t)sub * capacity;
-    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
-        [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
-            int x, y; is_any = 0u; tag = slot;
-            if (slot_to_pixel(fp, slot, x, y)) {
-                f3 org, dir; primary_ray(fp, seeds, sub * fp.capacity + slot, x, y, org, dir);
-                A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
-                dirs[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.capacity + slot));   // read back by k_shade
-            } else { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); }     // partial-tile slot: tmax < 0 -> miss
-        },
-        [&](uint32_t slot, bool, bool hit, const TravHit &h) {
-            hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        });
+    auto make_ray = [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, f3 &org, f3 &dir, int &x, int &y) -> bool {
+        is_any = 0u; tag = slot;
+        if (slot_to_pixel(fp, slot, x, y)) {
+            primary_ray(fp, seeds, sub * fp.capacity + slot, x, y, org, dir);
+            A = make_float4(org.x, org.y, org.z, __builtin_inff()); B = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            dirs[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.capacity + slot));   // read back by k_shade
+            return true;
+        }
+        A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f);                // partial-tile slot: tmax < 0 -> miss
+        return false;
+    };
+    if constexpr (SEED) {
+        // the triangle this pixel hit in an earlier frame is tested first (in its instance's object space: the arithmetic of the walk itself): the jittered ray most
+        // often hits it again and the walk starts with the right distance bound.  A guess is legal when its packet belongs to its instance's BLAS (a stale one —
+        // another scene, moved instances — is then one wasted test or none); the result is the minimum over (t, id) either way.
+        traverse_wide_stream<TWO_LEVEL, true>(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
+            [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, uint32_t &seed) {
+                f3 org, dir; int x, y;
+                seed = 0xFFFFFFFFu;
+                if (!make_ray(slot, A, B, tag, is_any, org, dir, x, y)) return;
+                const uint32_t guess = hint[(uint32_t)y * (uint32_t)fp.width + (uint32_t)x];
+                const uint32_t pk = TWO_LEVEL ? (guess & 0xFFFFFFu) : guess, in = TWO_LEVEL ? guess >> 24 : 0u;
+                if (guess == 0xFFFFFFFFu) return;
+                float t, U, V, ad;
+                if (TWO_LEVEL) {
+                    if (in >= s.num_inst) return;
+                    const InstanceDev &I = s.inst[in];
+                    if (pk - I.packet_base >= I.ntri) return;
+                    const float4 *__restrict__ q = s.wpackets + WPK * (size_t)pk;
+                    if (tri_test(q[0], q[1], q[2], to_object_point(I, org), to_object_dir(I, dir), 0.0f, __builtin_inff(), t, U, V, ad)) { A.w = t; seed = guess; }
+                } else {
+                    if (pk >= s.num_tris) return;
+                    const float4 *__restrict__ q = s.wpackets + WPK * (size_t)pk;
+                    if (tri_test(q[0], q[1], q[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { A.w = t; seed = guess; }
+                }
+            },
+            [&](uint32_t slot, bool, bool hit, const TravHit &h) {
+                hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                int x, y;
+                if (hit && slot_to_pixel(fp, slot, x, y)) hint[(uint32_t)y * (uint32_t)fp.width + (uint32_t)x] = h.pk;
+            });
+    } else {
+        traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(capacity, begin + rays_per_wave)}, stk_dyn,
+            [&](uint32_t slot, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) { f3 org, dir; int x, y; (void)make_ray(slot, A, B, tag, is_any, org, dir, x, y); },
+            [&](uint32_t slot, bool, bool hit, const TravHit &h) {
+                hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+            });
+    }
 }
 
 // Queue compaction.  Lanes ballot, waves post their two counts to LDS, and ONE packed 64-bit atomic per
@@ -1515,8 +1552,16 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && !(primary_wide && sv.num_wnodes) && (fuse_primary == 2 || F > 1 || B > 1);
             if (!planes_pass && !flow_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
-            else if (two_level && on_wide) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
-            else if (primary_wide && sv.num_wnodes && !two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p);
+            else if (two_level && on_wide) {
+                // the hint of two-level scenes is (packet | instance << 24): scenes of at most 255 instances and 2^24 packets
+                const bool seeded = primary_hint && sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24);
+                if (seeded) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
+                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
+            }
+            else if (primary_wide && sv.num_wnodes && !two_level) {
+                if (primary_hint) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
+                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
+            }
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
             else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
             if (flow_pass) {

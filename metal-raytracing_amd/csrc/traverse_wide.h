@@ -269,7 +269,9 @@ struct SharedCounter {
 // (direction not renormalised: t stays the world-space distance) and enters the BLAS root; when nothing of the BLAS is left — stack depth back
 // at the entry depth — it restores the world ray from LDS and pops the parked group.  g_mask carries the entry depth in bits 24..28 (0 = at the
 // TLAS level), the stack depth in bits 16..20.  `stack` then starts with WIDE_WORLD_RAY_BYTES of parked world rays.
-template <bool TWO_LEVEL = false, class Chunks, class RayFetch, class Emit>
+// SEED (primary rays with a hint, k_trace_primary_wide_stream): `fetch` also returns a candidate hit — a packet (| instance << 24) whose distance it has already put
+// into the ray's limit word — and the walk starts with it as its closest hit so far; TravHit::pk at emit time is the final hit in the same encoding.
+template <bool TWO_LEVEL = false, bool SEED = false, class Chunks, class RayFetch, class Emit>
 MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     float *const wray = reinterpret_cast<float *>(stack);      // [6][64]: o.xyz, d.xyz of the lane's ray in world space (TWO_LEVEL)
@@ -279,6 +281,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     const unsigned long long lt = (1ull << lane) - 1ull;
     // prefetched batch: rays batch_base .. batch_base + batch_n - 1, one per lane; pB.w = tag | any-hit flag << 31
     float4 pA = make_float4(0, 0, 0, 0), pB = pA;
+    uint32_t pS = 0xFFFFFFFFu;                        // SEED: the prefetched ray's candidate
     uint32_t batch_n = 0, batch_used = 0;             // wave-uniform; used == n -> nothing prefetched
     uint32_t cur = 0, end = 0;                        // unfetched part of the current chunk
     bool more = true;                                 // the chunk source may have more
@@ -320,6 +323,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                         h.gid = __float_as_uint(q0.w);
                     }
                 }
+                if (SEED) h.pk = was_hit ? (best_pk | (TWO_LEVEL ? (insts >> 16) << 24 : 0u)) : 0xFFFFFFFFu;
                 emit(tagw & 0x7FFFFFFFu, was_any, was_hit, h); unreported = false;
             }
             if (batch_used >= batch_n) {                        // prefetch the next (up to) 64 rays (coalesced), all lanes
@@ -327,7 +331,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 batch_n = cur < end ? min(64u, end - cur) : 0u; batch_used = 0;
                 if (lane < batch_n) {
                     uint32_t tag = 0, is_any = 0;
-                    fetch(cur + lane, pA, pB, tag, is_any);
+                    if constexpr (SEED) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any);
                     pB.w = __uint_as_float((tag & 0x7FFFFFFFu) | (is_any << 31));
                 }
                 cur += batch_n;
@@ -341,6 +345,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 const int sl = (int)(take ? batch_used + rank : lane);
                 const float ax_ = __shfl(pA.x, sl), ay_ = __shfl(pA.y, sl), az_ = __shfl(pA.z, sl), aw_ = __shfl(pA.w, sl);
                 const float bx_ = __shfl(pB.x, sl), by_ = __shfl(pB.y, sl), bz_ = __shfl(pB.z, sl), bw_ = __shfl(pB.w, sl);
+                const uint32_t seed_ = SEED ? (uint32_t)__shfl((int)pS, sl) : 0xFFFFFFFFu;
                 if (take) {
                     o = mk3(ax_, ay_, az_); d = mk3(bx_, by_, bz_); ix = box_inv(bx_); iy = box_inv(by_); iz = box_inv(bz_);
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
@@ -354,6 +359,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                         wray[lane] = ax_; wray[64 + lane] = ay_; wray[128 + lane] = az_; wray[192 + lane] = bx_; wray[256 + lane] = by_; wray[320 + lane] = bz_;
                         insts = 0; tl_pack = 0;
                     }
+                    if (SEED && seed_ != 0xFFFFFFFFu) { best_pk = TWO_LEVEL ? (seed_ & 0xFFFFFFu) : seed_; if (TWO_LEVEL) insts = (seed_ >> 24) << 16; }
                 }
                 batch_used += min(avail, n_idle);
 #ifndef MRT_STATS_BOTH

@@ -276,3 +276,29 @@ def test_commit_validates_every_index_of_the_layout(mrt, gpu_ctx, instancing):
         assert rc == 5 and "validation failed" in msg and what in msg, (rc, msg)
     assert lib.mrt_debug_validate(ds.handle) == 0
     ds.close()
+
+
+@pytest.mark.gpu
+def test_primary_hint_on_two_level_scenes(mrt, orc, gpu_ctx):
+    """The hint of two-level scenes — (packet | instance << 24) of the pixel's last primary hit, tested first in that instance's object space — changes no pixel:
+    with it and without it, over frames that reuse it, after the instances have moved (stale hints: legal guesses or rejected), and against the oracle."""
+    w, h = 160, 96
+    sc = _scene(mrt, (w, h))
+    opts = {"instancing": 1}
+    imgs = {}
+    for hint in (1, 0):
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=opts)
+        r.set_option("primary_hint", hint)
+        r.draw(5, wait=True)
+        xf = np.eye(4, dtype=np.float32); xf[:3, 3] = [1.0, 0.3, -0.8]; xf = np.ascontiguousarray(xf.T)
+        r.device_scene.set_instance_transform(2, xf); r.device_scene.commit()
+        r.draw(4, wait=True)
+        imgs[hint] = (r.accumulation().copy(), r.stats.closest_rays, r.stats.shadow_rays)
+        r.close()
+    assert np.array_equal(imgs[1][0].view(np.uint32), imgs[0][0].view(np.uint32)) and imgs[1][1:] == imgs[0][1:]
+    # and both are the oracle's image of the same sequence
+    two = orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True)
+    ref = orc.OracleRenderer(two, w, h, camera=sc.camera); ref.render(5)
+    two.set_transform(2, xf.reshape(16)); ref.render(4)
+    assert_parity(imgs[1][0], ref.accumulation(), exact_frac=1.0)
+    assert imgs[1][1:] == ref.counters()
