@@ -282,6 +282,8 @@ def main():
         value = (closest + shadow) / dt / 1e6
         fused = r.get_option("fused") != 0 and r.get_option("wide") == 0
         frame_batch = int(r.get_option("frame_batch")) if fused else 1
+        if frame_batch > PASS_FRAMES:                                    # renderer.hip render(): passes larger than the default take at most a third of a draw
+            frame_batch = min(frame_batch, max(PASS_FRAMES, (a.steps + 2) // 3))
         passes = (a.steps + frame_batch - 1) // frame_batch              # one pass of the pipeline = frame_batch frames
         # dominant kernel: the bounce + shadow traversal (k_trace_mixed_wide_persist): max_bounces launches per pass, each over
         # [bounce rays of that bounce (closest hit, 96 B) | shadow rays of that bounce (any hit, 72 B)]; the primary rays (96 B each)
