@@ -1,46 +1,38 @@
-"""Diagnostics: how much faster do incoherent (diffuse bounce) rays traverse when the queue is ordered by
-direction octant and origin cell?  Uses the per-wave timestamps of the stats query kernel."""
-import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+"""Would sorting the bounce rays by direction octant pay?  Bounce-like rays (primary hit points of the dragon scene, cosine-like directions about the view-facing normal) walked by the
+stream traversal in queue order, sorted by octant inside blocks of 256 (what k_shade's compaction could do locally), and sorted globally: wave iterations per 64 rays."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import metal_raytracing_amd as m
-from trav_stats import primary_rays
-
-def timing(st):
-    t0 = st[:, 4].astype(np.int64).reshape(-1, 64)[:, 0]; t1 = st[:, 5].astype(np.int64).reshape(-1, 64).max(1)
-    base = t0.min(); end = np.sort(t1 - base) / 100.0
-    wi = st[:, 6].astype(np.int64).reshape(-1, 64).sum(1)
-    return end[int(0.95 * len(end))], end[-1], wi.sum()
-
-def morton3(q):
-    def spread(x):
-        x = x.astype(np.uint64) & 0x3ff
-        x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249
-        return x
-    return (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
-
+import metal_raytracing_amd as mrt
 w, h = 1920, 1080
-sc = m.DragonScene((w, h)); ctx = m.Context(0)
-for wide in (1, 0):
-    ds = m.DeviceScene(ctx, sc, {"wide": wide})
-    rays = primary_rays(w, h)
-    hit = ds.intersect_closest(rays); ok = hit["type"] == 1
-    P = rays[ok, 0:3] + rays[ok, 4:7] * hit["distance"][ok, None]
-    rng = np.random.default_rng(0)
-    d = rng.normal(size=P.shape).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True); d[:, 1] = np.abs(d[:, 1])
-    n = (len(P) // 64) * 64
-    r2 = np.zeros((n, 8), np.float32); r2[:, 0:3] = P[:n] + np.array([0, 2e-3, 0], np.float32); r2[:, 4:7] = d[:n]; r2[:, 7] = np.inf
-    octant = (r2[:, 4] < 0).astype(np.uint64) | ((r2[:, 5] < 0).astype(np.uint64) << 1) | ((r2[:, 6] < 0).astype(np.uint64) << 2)
-    lo, hi = r2[:, 0:3].min(0), r2[:, 0:3].max(0)
-    for bits in (0, 3, 5, 8):
-        if bits == 0:
-            order = np.arange(n); name = "queue order"
-        else:
-            q = np.clip(((r2[:, 0:3] - lo) / (hi - lo) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
-            key = (octant << np.uint64(32)) | morton3(q)
-            order = np.argsort(key, kind="stable"); name = f"octant + {bits}-bit/axis origin cell"
-        st = ds.traversal_stats(r2[order])
-        b, t, wi = timing(st)
-        print(f"wide={wide} {name:34s}: 95% waves done {b:7.1f} us, kernel {t:7.1f} us, wave-iterations {wi}", flush=True)
-    ds.close()
+sc = mrt.DragonScene((w, h))
+ctx = mrt.Context(0)
+cam = sc.camera
+# pixels in 8x8 tile order, as the renderer's slots are
+ty, tx = np.mgrid[0:h // 8, 0:w // 8]
+oy, ox = np.mgrid[0:8, 0:8]
+ys = (ty.ravel()[:, None] * 8 + oy.ravel()[None, :]).ravel(); xs = (tx.ravel()[:, None] * 8 + ox.ravel()[None, :]).ravel()
+px = (xs + 0.5) / w * 2 - 1; py = 1 - (ys + 0.5) / h * 2
+pos = np.array(cam.position.tolist()); right = np.array(cam.right.tolist()); up = np.array(cam.up.tolist()); fwd = np.array(cam.forward.tolist())
+d = px[:, None] * right * (w / h) * 0.41 + py[:, None] * up * 0.41 + fwd; d /= np.linalg.norm(d, axis=1, keepdims=True)
+rays = np.zeros((len(d), 8), np.float32); rays[:, 0:3] = pos; rays[:, 4:7] = d; rays[:, 7] = np.inf
+ds = mrt.DeviceScene(ctx, sc, {})
+hit = ds.intersect_closest(rays); ok = hit["type"] == 1
+print("primary hits", ok.mean())
+P = pos + d[ok] * hit["distance"][ok, None]
+rng = np.random.default_rng(3)
+u = rng.normal(size=P.shape); u /= np.linalg.norm(u, axis=1, keepdims=True)
+nd = -d[ok] + u; nd /= np.maximum(np.linalg.norm(nd, axis=1, keepdims=True), 1e-6)
+br = np.zeros((len(P), 8), np.float32); br[:, 0:3] = P - d[ok] * 1e-3; br[:, 4:7] = nd; br[:, 7] = np.inf
+octant = (nd[:, 0] < 0) * 1 + (nd[:, 1] < 0) * 2 + (nd[:, 2] < 0) * 4
+def run(name, order):
+    st = ds.stream_stats(np.ascontiguousarray(br[order]), any_hit=False, per_wave=256).astype(np.int64)
+    it, live, n = st[:, 0].sum(), st[:, 1].sum(), st[:, 7].sum()
+    print(f"{name:34s}: {n} rays  wave iterations per 64 rays {64 * it / n:6.2f}  live lanes {live / it:5.1f}", flush=True)
+n = len(br)
+run("queue order", np.arange(n))
+blk = np.arange(n) // 256
+run("octant-sorted inside blocks of 256", np.lexsort((octant, blk)))
+blk = np.arange(n) // 2048
+run("octant-sorted inside blocks of 2048", np.lexsort((octant, blk)))
+run("octant-sorted globally (stable)", np.argsort(octant, kind="stable"))
