@@ -100,9 +100,11 @@ def test_shadow_planes_are_the_contribution_queue(mrt, gpu_ctx):
 
 
 @pytest.mark.parametrize("opts", [dict(tail_accumulate=0), dict(fuse_primary=0), dict(fuse_primary=2, frames_in_flight=1, frame_batch=1), dict(fuse_primary=0, shadow_planes=0, tail_accumulate=0),
-                                  dict(frames_in_flight=2, frame_batch=3), dict(primary_hint=0)], ids=str)
+                                  dict(frames_in_flight=2, frame_batch=3), dict(primary_hint=0),
+                                  dict(stream_even=0), dict(stream_even=100, frame_batch=1), dict(stream_even=1600, frames_in_flight=2, frame_batch=2), dict(persistent=0), dict(persistent=1, persist_chunk=64)], ids=str)
 def test_pipeline_switches_do_not_change_the_image(mrt, gpu_ctx, opts):
-    """fuse_primary (primary rays traced inside shade(0)), tail_accumulate (the last passes folded in one launch), shadow_planes: scheduling and storage, never the image —
+    """fuse_primary (primary rays traced inside shade(0)), tail_accumulate (the last passes folded in one launch), shadow_planes, stream_even / persistent (how a traversal launch
+    hands its rays to its waves): scheduling and storage, never the image —
     over draws of several shapes (a draw shorter than the lanes, one that wraps around them, a single frame)."""
     sc = mrt.DragonScene((400, 240))
     imgs = []
