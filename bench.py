@@ -102,7 +102,7 @@ def committed_profile():
         return {}
 
 
-def cpu_baseline(mrt, scene, w, h, bounces, threads):
+def cpu_baseline(mrt, scene, w, h, bounces, threads, two_level=False):
     """The oracle (CPU restatement, kind 'port') on the GPU box's host cores: one full frame of the
     same workload, same seeds.  Reported, never the thing shipped.  SURVEY §8(d): built here, on this box, with -O3 -march=native
     (oracle/Makefile target `native`; no fast-math, no contraction: the same bits as the portable build the tests use) and run on
@@ -111,7 +111,8 @@ def cpu_baseline(mrt, scene, w, h, bounces, threads):
     import oracle as O
     O.build_oracle(force=True)                     # always rebuilt HERE: -march=native is only valid on the machine that compiled it
     threads = threads or (os.cpu_count() or 1)     # all host cores of the box
-    osc = O.OracleScene(mrt.flatten_scene(scene), scene.lights)
+    # a two-level scene (--sopt instancing=1) is checked against the oracle's two-level restatement: triangle tests in object space round differently from the flattened scene's
+    osc = O.OracleScene(mrt.flatten_scene(scene, share=True), scene.lights, instancing=True) if two_level else O.OracleScene(mrt.flatten_scene(scene), scene.lights)
     r = O.OracleRenderer(osc, w, h, seed=1, max_bounces=bounces, camera=scene.camera)
     t0 = time.perf_counter()
     r.render(1, threads=threads)
@@ -400,7 +401,7 @@ def main():
                                                  "rays_per_frame": {"primary": s1.closest_rays / a.steps, "shadow": s1.shadow_rays / a.steps}, "max_bounces": 1}
             r.set_option("max_bounces", a.bounces)
         if world == 1 and not a.no_cpu_baseline:
-            cb, ref = cpu_baseline(mrt, scene, w, h, a.bounces, a.cpu_threads)
+            cb, ref = cpu_baseline(mrt, scene, w, h, a.bounces, a.cpu_threads, two_level=any(kv.startswith("instancing=1") for kv in a.sopt))
             out["cpu_baseline"] = cb
             # parity of frame 0 against the oracle, same seeds (informational; the gates are tests/ -m gpu)
             r0 = mrt.Renderer((w, h), scene, ctx=r.ctx, seed=1, max_bounces=a.bounces, scene_options=opts)
