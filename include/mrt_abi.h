@@ -112,6 +112,11 @@ typedef struct {
     int32_t  max_submeshes;    /* resource-table stride (Renderer.swift:128-139)               */
     int32_t  max_leaf_tris;
     int32_t  max_depth;
+    int32_t  wide_layout;      /* 1: the scene has the 8-wide layout and every ray walks it; 0: it could not be built (tree deeper than the
+                                  traversal stack can be made, node index beyond 24 bits, scene option wide = 0) and every ray falls back to
+                                  the binary rope walk — about a third of the rate                                                        */
+    int32_t  wide_depth;       /* levels of the 8-wide tree (two-level scenes: TLAS levels + 1 + the deepest BLAS); the traversal kernels'
+                                  LDS stack is sized from it at every launch: 320 B per wave and level                                     */
 } MRTSceneStats;
 
 typedef struct {
@@ -242,20 +247,13 @@ int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
  * frame will be drawn with.                                                                                                 */
 int mrt_renderer_set_uniforms(MRTRenderer r, const MRTUniforms *uniforms);
 int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
-/* Tuning knobs of this implementation (no counterpart in the reference beyond maxFramesInFlight, Renderer.swift:33):
- * "max_bounces", "frames_in_flight" (HIP streams carrying frame batches concurrently), "frame_batch" (frames carried through
- * the pipeline per pass, <= 32), "persistent" (bounce / shadow traversal as persistent waves pulling chunks: 0 never, 1 always, 2 by launch
- * size), "persist_chunk", "wave_slots", "primary_hint" (primary rays test the triangle their pixel hit last first), "materials" (the
- * materials extension: emission, specular lobe, refraction; max_bounces <= 16), "megakernel" (one launch per frame: lowest latency of a
- * single frame), "sample_offset", "throughput_chain" (bounce rays carry the resource slots of their path instead of a throughput record),
- * "shadow_planes" (a contribution plane per bounce and one byte per shadow ray that got through instead of a contribution queue), "fuse_primary"
- * (primary rays generated, traced and shaded in one launch: 0 never, 1 except for one frame alone, 2 always), "tail_accumulate" (the last passes of a
- * draw accumulated in one launch), "stream_even" (traversal launches too small for chunk pulling: percent of the wave slots launched as waves, the rays
- * split evenly among them; default 200, 0 = fixed ranges), "halton_table",
- * "flow" (experiment: one launch per pass after the primary trace, csrc/flow.h; with "flow_chunk", "flow_granule", "flow_take", "flow_session_rays",
- * "flow_exit_rays", "flow_idle_polls", "flow_slots", "flow_order", "flow_mix"), and the A/B switches "fused", "wide_bounce", "wide_stream",
- * "primary_wide", "shadow_rope", "wide"; read-only through mrt_renderer_get_option: "lanes_used", "lane_bytes".  Every setting renders the same
- * image bit for bit (except "materials", which changes the shading model).                                                         */
+/* The renderer's knobs.  The reference's own: "max_bounces" (the literal 3 of Raytracing.metal:237; 1..19), "frames_in_flight"
+ * (Renderer.maxFramesInFlight, Renderer.swift:33: here passes in flight on separate HIP streams, default 6), "sample_offset" (added to
+ * frameIndex for the Halton index only: sample-index sharding).  This implementation's: "frame_batch" (frames carried through the pipeline
+ * per pass, default 8, <= 32: larger launches against more queue memory — "lane_bytes" per pass in flight), "megakernel" (1: one launch
+ * per frame, the lowest latency of a single frame; the default pipeline has the higher throughput), "materials" (1: the materials
+ * extension — emission, specular lobe, refraction; max_bounces <= 16; the only key that changes the image).  Read-only through
+ * mrt_renderer_get_option: "lanes_used", "lane_bytes".                                                                              */
 int mrt_renderer_set_option(MRTRenderer r, const char *key, double value);
 int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value);
 /* Screen-tile shard for multi-GPU: this renderer owns 8x8 tiles with (tile_id % world) == rank;
@@ -269,8 +267,9 @@ int mrt_renderer_render(MRTRenderer r, int32_t n_frames);
 /* commandBuffer completion (Renderer.swift:285-287).                                           */
 int mrt_renderer_wait(MRTRenderer r);
 /* The same completion as a poll (the reference's handler is told per command buffer, Renderer.swift:285-287): frames, counted
- * as MRTRenderStats.frames is, whose accumulation has finished on the device.  Never blocks; completion is reported per pass
- * of `frame_batch` frames.                                                                                                   */
+ * as MRTRenderStats.frames is, whose accumulation has finished on the device.  Never blocks.  Granularity: a pass of `frame_batch`
+ * frames; the LAST passes of a draw call (one per pass in flight, i.e. every pass of a short call such as 20 frames) are accumulated
+ * together when the call's last traversal launch has finished, so their frames are reported together at the end of the call.          */
 int mrt_renderer_frames_completed(MRTRenderer r, uint64_t *frames);
 /* accumulationTargets[0] after the swap (Renderer.swift:332-334): w*h RGBA32F, row 0 = bottom of
  * the image as the kernel writes it (Raytracing.metal:206-207; the blit flips, Shaders.metal:35). */
@@ -313,6 +312,13 @@ int mrt_group_frames_completed(MRTGroupRenderer gr, uint64_t *frames);          
 int mrt_group_gather(MRTGroupRenderer gr, float *rgba, size_t nbytes);
 int mrt_group_gathered_device_ptr(MRTGroupRenderer gr, void **device_ptr);         /* the assembled image on the root device            */
 int mrt_group_stats(MRTGroupRenderer gr, MRTRenderStats *out);                     /* ray counters summed over the devices              */
+
+/* ---------------------------------------------------------------- library-internal A/B switches (tests, tools/, bench.py --opt)
+ * Not part of the host contract: keys come and go with the experiments that need them; every setting renders the same image bit for bit.
+ * Today: "persistent" / "persist_chunk" / "wave_slots" / "stream_even" (how a traversal launch splits its rays over waves), "primary_hint",
+ * "primary_wide", "fuse_primary", "wide_bounce", "throughput_chain", "shadow_planes", "tail_accumulate" (DESIGN.md §6).  Public keys are accepted too. */
+int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value);
+int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value);
 
 /* ---------------------------------------------------------------- device-function probes
  * Evaluate the kernel's helper functions on the device for known-answer tests

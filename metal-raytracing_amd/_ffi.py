@@ -96,7 +96,7 @@ class Intersection(C.Structure):
 class SceneStats(C.Structure):
     _fields_ = [("triangles", C.c_uint64), ("vertices", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_leaves", C.c_uint64),
                 ("scene_bytes", C.c_uint64), ("build_ms", C.c_float), ("sah_cost", C.c_float), ("instances", C.c_int32),
-                ("max_submeshes", C.c_int32), ("max_leaf_tris", C.c_int32), ("max_depth", C.c_int32)]
+                ("max_submeshes", C.c_int32), ("max_leaf_tris", C.c_int32), ("max_depth", C.c_int32), ("wide_layout", C.c_int32), ("wide_depth", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -158,6 +158,8 @@ SIGNATURES = {
     "mrt_renderer_frames_completed": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "mrt_renderer_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "mrt_renderer_get_option": (C.c_int, [_P, C.c_char_p, _P]),
+    "mrt_debug_renderer_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "mrt_debug_renderer_get_option": (C.c_int, [_P, C.c_char_p, _P]),
     "mrt_renderer_set_shard": (C.c_int, [_P, _I32, _I32]),
     "mrt_renderer_set_frame_index": (C.c_int, [_P, _U32]),
     "mrt_renderer_frame_index": (C.c_int, [_P, _PU32]),

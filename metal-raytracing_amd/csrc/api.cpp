@@ -217,6 +217,7 @@ int mrt_scene_stats(MRTScene scene, MRTSceneStats *out) {
     REQUIRE(scene && out, "mrt_scene_stats: bad argument");
     if (!scene->committed) { mrt::set_error("mrt_scene_stats: scene not committed"); return MRT_ERR_STATE; }
     *out = scene->dev.stats;
+    out->wide_layout = scene->dev.num_wnodes > 0 ? 1 : 0; out->wide_depth = scene->dev.wide_depth;
     return MRT_OK;
 }
 int mrt_scene_instance_transform(MRTScene scene, int32_t mesh_id, float out[12]) {
@@ -434,44 +435,18 @@ int mrt_renderer_frames_completed(MRTRenderer r, uint64_t *frames) {
     return r->r.poll_completed(frames);
     MRT_CATCH
 }
+// The host's knobs: the reference's own (the bounce count, Raytracing.metal:237; maxFramesInFlight, Renderer.swift:33; the shard's sample offset) + three of this implementation.
 int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     MRT_TRY
     REQUIRE(r && key, "mrt_renderer_set_option: bad argument");
     std::string k(key);
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= (r->r.materials ? 16 : 19), "max_bounces must be in [1,19] ([1,16] with materials = 1)"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
-    else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
+    else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
     else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
     else if (k == "megakernel") r->r.megakernel = value != 0;
-    else if (k == "fused") r->r.fused = value != 0;
     else if (k == "materials") { REQUIRE(value == 0 || (value == 1 && r->r.max_bounces <= 16), "materials must be 0 or 1 (and max_bounces <= 16: the lobe choice uses Halton dimension 2 + 5 * max_bounces + bounce < 100)"); r->r.materials = value != 0; }
-    else if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
-    else if (k == "primary_hint") r->r.primary_hint = value != 0;
-    else if (k == "throughput_chain") r->r.throughput_chain = value != 0;
-    else if (k == "queue_uncached") { REQUIRE(r->r.lanes_ready == 0, "queue_uncached must be set before the first draw"); r->r.queue_uncached = value != 0; }
-    else if (k == "halton_table") { REQUIRE(value == 0 || value == 1 || value == 2, "halton_table must be 0 (digit loops), 1 (table) or 2 (table for dimension 1 only)"); r->r.halton_table = (int)value; }
-    else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
-    else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
-    else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
-    else if (k == "wide_stream") r->r.wide_stream = value != 0;
-    else if (k == "shadow_rope") r->r.shadow_rope = value != 0;
-    else if (k == "primary_wide") r->r.primary_wide = value != 0;
-    else if (k == "shadow_planes") r->r.shadow_planes = value != 0 ? 1 : 0;
-    else if (k == "tail_accumulate") r->r.tail_accumulate = value != 0;
-    else if (k == "fuse_primary") { REQUIRE(value == 0 || value == 1 || value == 2, "fuse_primary must be 0, 1 (not for one frame alone) or 2 (always)"); r->r.fuse_primary = (int)value; }
-    else if (k == "flow") { REQUIRE(value == 0 || value == 1, "flow must be 0 or 1"); r->r.flow = (int)value; }
-    else if (k == "flow_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "flow_chunk must be a multiple of 64 in [64, 65536]"); r->r.flow_chunk = (int)value; }
-    else if (k == "flow_take") { REQUIRE(value >= 1 && value <= 16, "flow_take must be in [1, 16]"); r->r.flow_take = (int)value; }
-    else if (k == "flow_session_rays") { REQUIRE(value >= 64 && value <= (1 << 20), "flow_session_rays must be in [64, 2^20]"); r->r.flow_session_rays = (int)value; }
-    else if (k == "flow_granule") { REQUIRE(value >= 64 && value <= 4096 && ((int)value % 64) == 0, "flow_granule must be a multiple of 64 in [64, 4096]"); r->r.flow_granule = (int)value; }
-    else if (k == "flow_mix") r->r.flow_mix = value != 0;
-    else if (k == "flow_order") { REQUIRE(value == 0 || value == 1, "flow_order must be 0 or 1"); r->r.flow_order = (int)value; }
-    else if (k == "flow_exit_rays") { REQUIRE(value >= 0 && value <= 65536, "flow_exit_rays must be in [0, 65536]"); r->r.flow_exit_rays = (int)value; }
-    else if (k == "flow_idle_polls") { REQUIRE(value >= 0 && value <= 65536, "flow_idle_polls must be in [0, 65536]"); r->r.flow_idle_polls = (int)value; }
-    else if (k == "flow_slots") { REQUIRE(value >= 0 && value <= (1 << 20), "flow_slots must be in [0, 2^20]"); r->r.flow_slots = (int)value; }
-    else if (k == "wide") r->r.use_wide = value != 0;
-    else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
-    else { mrt::set_error("mrt_renderer_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    else { mrt::set_error("mrt_renderer_set_option: unknown key " + k + " (keys: max_bounces, frames_in_flight, sample_offset, frame_batch, megakernel, materials; the library's A/B switches are behind mrt_debug_renderer_set_option)"); return MRT_ERR_INVALID_ARGUMENT; }
     return MRT_OK;
     MRT_CATCH
 }
@@ -481,39 +456,53 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     std::string k(key);
     if (k == "max_bounces") *value = r->r.max_bounces;
     else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
-    else if (k == "stream_even") *value = r->r.stream_even;
+    else if (k == "sample_offset") *value = r->r.sample_offset;
     else if (k == "frame_batch") *value = r->r.frame_batch;
+    else if (k == "megakernel") *value = r->r.megakernel ? 1 : 0;
+    else if (k == "materials") *value = r->r.materials ? 1 : 0;
     else if (k == "lanes_used") *value = r->r.lanes_used;
     else if (k == "lane_bytes") *value = (double)r->r.lane_bytes();
-    else if (k == "megakernel") *value = r->r.megakernel ? 1 : 0;
-    else if (k == "fused") *value = r->r.fused ? 1 : 0;
-    else if (k == "materials") *value = r->r.materials ? 1 : 0;
-    else if (k == "persistent") *value = r->r.persistent;
-    else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;
-    else if (k == "halton_table") *value = r->r.halton_table;
-    else if (k == "throughput_chain") *value = r->r.throughput_chain ? 1 : 0;
+    else { mrt::set_error("mrt_renderer_get_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    return MRT_OK;
+    MRT_CATCH
+}
+// The library's A/B switches and launch-shape parameters (tests, tools/, bench.py --opt): every setting renders the same image bit for bit.  Not part of the host contract:
+// keys come and go with the experiments that need them.  Also accepts the public keys.
+int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) {
+    MRT_TRY
+    REQUIRE(r && key, "mrt_debug_renderer_set_option: bad argument");
+    std::string k(key);
+    if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
+    else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
+    else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
+    else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
+    else if (k == "primary_hint") r->r.primary_hint = value != 0;
+    else if (k == "throughput_chain") r->r.throughput_chain = value != 0;
+    else if (k == "shadow_planes") r->r.shadow_planes = value != 0 ? 1 : 0;
+    else if (k == "tail_accumulate") r->r.tail_accumulate = value != 0;
+    else if (k == "fuse_primary") { REQUIRE(value == 0 || value == 1 || value == 2, "fuse_primary must be 0, 1 (not for one frame alone) or 2 (always)"); r->r.fuse_primary = (int)value; }
+    else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
+    else if (k == "primary_wide") { REQUIRE(value == 0 || value == 1 || value == 2, "primary_wide must be 0 (rope walk inside shade(0)), 1 (own launch of the 8-wide stream kernel) or 2 (8-wide walk inside shade(0))"); r->r.primary_wide = (int)value; }
+    else return mrt_renderer_set_option(r, key, value);
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value) {
+    MRT_TRY
+    REQUIRE(r && key && value, "mrt_debug_renderer_get_option: bad argument");
+    std::string k(key);
+    if (k == "persistent") *value = r->r.persistent;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
     else if (k == "wave_slots") *value = r->r.wave_slots;
-    else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
-    else if (k == "wide_stream") *value = r->r.wide_stream ? 1 : 0;
-    else if (k == "shadow_rope") *value = r->r.shadow_rope ? 1 : 0;
-    else if (k == "primary_wide") *value = r->r.primary_wide ? 1 : 0;
+    else if (k == "stream_even") *value = r->r.stream_even;
+    else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;
+    else if (k == "throughput_chain") *value = r->r.throughput_chain ? 1 : 0;
     else if (k == "shadow_planes") *value = r->r.shadow_planes;
     else if (k == "tail_accumulate") *value = r->r.tail_accumulate ? 1 : 0;
     else if (k == "fuse_primary") *value = r->r.fuse_primary;
-    else if (k == "flow") *value = r->r.flow;
-    else if (k == "flow_chunk") *value = r->r.flow_chunk;
-    else if (k == "flow_take") *value = r->r.flow_take;
-    else if (k == "flow_session_rays") *value = r->r.flow_session_rays;
-    else if (k == "flow_granule") *value = r->r.flow_granule;
-    else if (k == "flow_mix") *value = r->r.flow_mix;
-    else if (k == "flow_order") *value = r->r.flow_order;
-    else if (k == "flow_exit_rays") *value = r->r.flow_exit_rays;
-    else if (k == "flow_idle_polls") *value = r->r.flow_idle_polls;
-    else if (k == "flow_slots") *value = r->r.flow_slots > 0 ? r->r.flow_slots : r->r.flow_slots_auto;
-    else if (k == "wide") *value = r->r.use_wide ? 1 : 0;
-    else if (k == "sample_offset") *value = r->r.sample_offset;
-    else { mrt::set_error("mrt_renderer_get_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
+    else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
+    else if (k == "primary_wide") *value = r->r.primary_wide;
+    else return mrt_renderer_get_option(r, key, value);
     return MRT_OK;
     MRT_CATCH
 }

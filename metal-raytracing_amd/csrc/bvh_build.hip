@@ -735,10 +735,20 @@ __global__ void __launch_bounds__(1024) k_ploc_tail(uint32_t m, int radius, cons
 // One thread per wide node of the current level.  Greedy collapse (largest surface area first) of the
 // refitted binary tree; children that are binary inner nodes form the next level (BFS numbering, so a
 // node's children are contiguous and the top of the tree sits at the lowest indices).
+// Levels are launched in batches without a host round trip in between (the 13 levels of DragonScene used to cost 13 read-backs, 0.9 of the build's 3.9 ms): level L takes its
+// node count from lv[L] — lv[0] = 1, level L - 1 has counted its internal children into lv[L] — and its first node index from the counts before it; the grid is sized for
+// the most a level can hold (min(8^L, max_w)), surplus threads leave.  lv[WIDE_LV_PACKETS] counts packets, lv[WIDE_LV_ERROR] is set when the node array would overflow.
+constexpr uint32_t WIDE_LV_MAX = 4096, WIDE_LV_PACKETS = WIDE_LV_MAX + 1, WIDE_LV_ERROR = WIDE_LV_MAX + 2, WIDE_LV_WORDS = WIDE_LV_MAX + 3;
 template <bool DP>
-__global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict__ leaf_offset, const uint32_t *__restrict__ fin, uint32_t n_in,
-                             uint32_t base_in, uint32_t next_base, uint32_t *__restrict__ fout, uint32_t *__restrict__ counters /* [0] next-level nodes, [1] packets */,
+__global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict__ leaf_offset, const uint32_t *__restrict__ fin, uint32_t level, uint32_t max_w,
+                             uint32_t *__restrict__ fout, uint32_t *__restrict__ lv,
                              float4 *__restrict__ wnodes, const float4 *__restrict__ packets, float4 *__restrict__ wpackets) {
+    const uint32_t n_in = lv[level];
+    if (blockIdx.x * blockDim.x >= n_in) return;
+    uint32_t base_in = 0;
+    for (uint32_t l = 0; l < level; l++) base_in += lv[l];
+    const uint32_t next_base = base_in + n_in;
+    uint32_t *const counters = lv + level + 1;            // [0]: the next level's nodes
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n_in;
     uint32_t ch[8]; bool isleaf[8]; int nch = 0;
@@ -796,9 +806,10 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
     uint32_t xi = ninner, xt = ntris;
     for (int o = 1; o < 64; o <<= 1) { uint32_t a = __shfl_up(xi, o), b = __shfl_up(xt, o); if (lane >= (uint32_t)o) { xi += a; xt += b; } }
     uint32_t tot_i = __shfl(xi, 63), tot_t = __shfl(xt, 63), base_i = 0, base_t = 0;
-    if (lane == 63) { if (tot_i) base_i = atomicAdd(&counters[0], tot_i); if (tot_t) base_t = atomicAdd(&counters[1], tot_t); }
+    if (lane == 63) { if (tot_i) base_i = atomicAdd(&counters[0], tot_i); if (tot_t) base_t = atomicAdd(&lv[WIDE_LV_PACKETS], tot_t); }
     base_i = __shfl(base_i, 63); base_t = __shfl(base_t, 63);
     if (!active) return;
+    if ((uint64_t)next_base + base_i + tot_i > (uint64_t)max_w) { lv[WIDE_LV_ERROR] = 1u; return; }      // (wave-uniform) the node array would overflow: the host reports it
     const uint32_t my_i = base_i + xi - ninner, my_t = base_t + xt - ntris;
     // slot assignment: preferred slot = side of the node centre per axis; greedy nearest free slot (Hamming)
     int slot_of[8]; bool used[8] = {false, false, false, false, false, false, false, false};
@@ -964,7 +975,7 @@ int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt,
 }
 
 // One world-space BVH over the given (geometry, transform) pairs: the whole flattened scene, or one BLAS (a single mesh under the identity).
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage) {
     struct MeshView { const std::vector<float> &positions, &normals; const float *xf; const std::vector<std::vector<uint32_t>> &sub_indices; const std::vector<MRTMaterial> &sub_materials; };
     std::vector<MeshView> meshes;
     for (auto &r : refs) meshes.push_back(MeshView{r.g->positions, r.g->normals, r.xf, r.g->sub_indices, r.g->sub_materials});
@@ -978,15 +989,25 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const size_t I = meshes.size();
     if (V >= 0xFFFFFFF0ull || I >= 65536 || max_sub >= 65536) { set_error("scene too large (limits: 2^32 - 16 vertices, 65535 instances / submeshes)"); return MRT_ERR_UNSUPPORTED; }
     if (int rc = layout_limits(T, 0)) return rc;                // before any device work: what no tree of T triangles can satisfy
-    std::vector<float> h_pos(std::max<size_t>(V * 3, 3));
-    std::vector<float4> h_nrm(std::max<size_t>(V, 1));
-    std::vector<uint32_t> h_idx(std::max<size_t>(NI, 3));
-    std::vector<SubRec> recs;
-    std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
-    std::vector<float4> h_base(std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
-    std::vector<float4> h_mat(3 * std::max<size_t>(I * max_sub, 1), make_float4(0, 0, 0, 0));
-    std::vector<uint32_t> h_gbase(std::max<size_t>(I * max_sub, 1), 0);
-    size_t vb = 0, tb = 0, ib = 0;
+    // one pinned staging area for everything that goes up (positions, normals as float4, indices, the small tables): filled in ONE pass straight from the caller's
+    // arrays (no zero-filled intermediate vectors), copied to the device by DMA from pinned pages.  DragonScene: 24 MB; the pageable path took 4 of the commit's 8.4 ms.
+    const size_t slots = std::max<size_t>(I * max_sub, 1);
+    size_t nrec = 0;
+    for (auto &m : meshes) for (auto &sx : m.sub_indices) if (!sx.empty()) nrec++;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_pos = 0, o_nrm = o_pos + up(std::max<size_t>(V * 3, 3) * 4), o_idx = o_nrm + up(std::max<size_t>(V, 1) * 16), o_rec = o_idx + up(std::max<size_t>(NI, 3) * 4),
+                 o_cols = o_rec + up(std::max<size_t>(nrec, 1) * sizeof(SubRec)), o_base = o_cols + up(std::max<size_t>(I * 4, 4) * 16), o_mat = o_base + up(slots * 16), o_gb = o_mat + up(3 * slots * 16), o_end = o_gb + up(slots * 4);
+    PinnedBuf &stg = stage ? *stage : out.stage;
+    MRT_HIP(stg.reserve(o_end));
+    uint8_t *const S = (uint8_t *)stg.p;
+    float *const h_pos = (float *)(S + o_pos); float4 *const h_nrm = (float4 *)(S + o_nrm); uint32_t *const h_idx = (uint32_t *)(S + o_idx); SubRec *const recs = (SubRec *)(S + o_rec);
+    float4 *const h_cols = (float4 *)(S + o_cols), *const h_base = (float4 *)(S + o_base), *const h_mat = (float4 *)(S + o_mat); uint32_t *const h_gbase = (uint32_t *)(S + o_gb);
+    const size_t n_pos = std::max<size_t>(V * 3, 3), n_nrm = std::max<size_t>(V, 1), n_idx = std::max<size_t>(NI, 3), n_cols = std::max<size_t>(I * 4, 4);
+    memset(h_base, 0, slots * 16); memset(h_mat, 0, 3 * slots * 16); memset(h_gbase, 0, slots * 4);
+    if (V == 0) { h_pos[0] = h_pos[1] = h_pos[2] = 0.0f; h_nrm[0] = make_float4(0, 0, 0, 0); }
+    if (NI == 0) { h_idx[0] = h_idx[1] = h_idx[2] = 0u; }
+    if (I == 0) for (int c = 0; c < 4; c++) h_cols[c] = make_float4(0, 0, 0, 0);
+    size_t vb = 0, tb = 0, ib = 0, nr = 0;
     for (size_t mi = 0; mi < I; mi++) {
         const MeshView &m = meshes[mi];
         size_t nv = m.positions.size() / 3;
@@ -1000,7 +1021,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
             h_gbase[mi * max_sub + g] = (uint32_t)tb;
             if (ix.empty()) continue;
             memcpy(&h_idx[ib], ix.data(), ix.size() * 4);
-            recs.push_back(SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)ib, (uint32_t)vb, (uint32_t)mi, (uint32_t)g});
+            recs[nr++] = SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)ib, (uint32_t)vb, (uint32_t)mi, (uint32_t)g};
             tb += ix.size() / 3; ib += ix.size();
         }
         vb += nv;
@@ -1009,16 +1030,16 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.stats.triangles = T; out.stats.vertices = V; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub;
     out.stats.max_leaf_tris = opt.max_leaf;
 
-    MRT_HIP(out.normals.alloc(h_nrm.size()));
-    MRT_HIP(out.base_color.alloc(h_base.size())); MRT_HIP(out.materials.alloc(h_mat.size()));
-    MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat.data(), h_mat.size() * 16, hipMemcpyHostToDevice, stream));
-    MRT_HIP(out.geom_base.alloc(h_gbase.size()));
-    MRT_HIP(out.inst_cols.alloc(h_cols.size()));
+    MRT_HIP(out.normals.alloc(n_nrm));
+    MRT_HIP(out.base_color.alloc(slots)); MRT_HIP(out.materials.alloc(3 * slots));
+    MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat, 3 * slots * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(out.geom_base.alloc(slots));
+    MRT_HIP(out.inst_cols.alloc(n_cols));
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(T, 1)));
-    MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm.data(), h_nrm.size() * 16, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base.data(), h_base.size() * 16, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase.data(), h_gbase.size() * 4, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols.data(), h_cols.size() * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base, slots * 16, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase, slots * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols, n_cols * 16, hipMemcpyHostToDevice, stream));
 
     if (T == 0) {       // empty scene: every ray misses
         MRT_HIP(out.nodes.alloc(8)); out.packets_offset = 4;
@@ -1030,14 +1051,14 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
 
     const uint32_t T32 = (uint32_t)T;
     ScratchArena arena;                                          // before the buffers that borrow from it
-    arena.chunk_bytes = ((size_t)T * 576 + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle): one allocation, more if pre-splitting adds references
+    arena.chunk_bytes = ((size_t)T * (576 + (opt.wide && opt.max_leaf <= 4 ? 16 * WNODE_STRIDE : 0)) + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle + the 8-wide nodes' scratch): one allocation, more if pre-splitting adds references
     DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
     DevBuf<float4> tri_world, tri_lo, tri_hi, ref_lo, ref_hi, node_lo, node_hi;
     DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat, ref_tri;
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<float> cost;
     DevBuf<uint8_t> collapsed, mask;
-    MRT_HIP(d_pos.alloc_in(arena, h_pos.size())); MRT_HIP(d_idx.alloc_in(arena, h_idx.size())); MRT_HIP(d_recs.alloc_in(arena, recs.size()));
+    MRT_HIP(d_pos.alloc_in(arena, n_pos)); MRT_HIP(d_idx.alloc_in(arena, n_idx)); MRT_HIP(d_recs.alloc_in(arena, std::max<size_t>(nrec, 1)));
     MRT_HIP(tri_world.alloc_in(arena, 3 * (size_t)T32)); MRT_HIP(tri_lo.alloc_in(arena, T32)); MRT_HIP(tri_hi.alloc_in(arena, T32));
     MRT_HIP(cbounds.alloc_in(arena, 6)); MRT_HIP(stat.alloc_in(arena, 4));
 
@@ -1047,9 +1068,9 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     } evs;
     MRT_HIP(hipEventCreate(&evs.a)); MRT_HIP(hipEventCreate(&evs.b));
     const hipEvent_t ev0 = evs.a, ev1 = evs.b;
-    MRT_HIP(hipMemcpyAsync(d_pos.p, h_pos.data(), h_pos.size() * 4, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(d_idx.p, h_idx.data(), h_idx.size() * 4, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(SubRec), hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_pos.p, h_pos, n_pos * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_idx.p, h_idx, n_idx * 4, hipMemcpyHostToDevice, stream));
+    if (nrec) MRT_HIP(hipMemcpyAsync(d_recs.p, recs, nrec * sizeof(SubRec), hipMemcpyHostToDevice, stream));
     MRT_HIP(hipEventRecord(ev0, stream));
     {
         uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
@@ -1058,7 +1079,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(hipMemsetAsync(stat.p, 0xFF, stat.bytes(), stream));       // [0] depth and [1] leaves are cleared below; [2] = root stays NONE until k_assign finds it
     MRT_HIP(hipMemsetAsync(stat.p, 0, 8, stream));
     const int B = 256;
-    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs.p, (int)recs.size(), d_pos.p, d_idx.p, out.inst_cols.p, T32,
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs.p, (int)nrec, d_pos.p, d_idx.p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
     uint32_t n = T32;
@@ -1223,43 +1244,42 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         // greedy: every wide node is an inner node of the collapsed binary tree and swallows at least one more; optimal: every wide node has
         // at least two children and every leaf child at least one triangle, so there are fewer wide nodes than triangles.  The array is trimmed below.
         const size_t max_w = opt.wide_collapse ? (size_t)n + 2 : (size_t)h_size / 2 + 2;
-        DevBuf<uint32_t> fa, fb, wc;
-        MRT_HIP(fa.alloc_in(arena, max_w)); MRT_HIP(fb.alloc_in(arena, max_w)); MRT_HIP(wc.alloc_in(arena, 2));
-        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * max_w)); MRT_HIP(out.wpackets.alloc(WPK * (size_t)n));
+        DevBuf<uint32_t> fa, fb, lv; DevBuf<float4> wtmp;
+        MRT_HIP(fa.alloc_in(arena, max_w)); MRT_HIP(fb.alloc_in(arena, max_w)); MRT_HIP(lv.alloc_in(arena, WIDE_LV_WORDS));
+        MRT_HIP(wtmp.alloc_in(arena, WNODE_STRIDE * max_w));          // built in scratch (worst case: one node per reference), copied into an array of the size the tree has
+        MRT_HIP(out.wpackets.alloc(WPK * (size_t)n));
         MRT_HIP(hipEventRecord(ev0, stream));
-        MRT_HIP(hipMemsetAsync(wc.p, 0, 8, stream));
+        MRT_HIP(hipMemsetAsync(lv.p, 0, lv.bytes(), stream));
+        { const uint32_t one = 1; MRT_HIP(hipMemcpyAsync(lv.p, &one, 4, hipMemcpyHostToDevice, stream)); }
         MRT_HIP(hipMemcpyAsync(fa.p, &root, 4, hipMemcpyHostToDevice, stream));
-        uint32_t n_in = 1, base_in = 0, total = 0; int depth = 0;
-        uint32_t *fin = fa.p, *fo = fb.p;
-        while (n_in > 0) {
-            depth++;
-            if (total + n_in > max_w) { set_error("wide BVH build overflow"); return MRT_ERR_HIP; }
-            MRT_HIP(hipMemsetAsync(wc.p, 0, 4, stream));
-            if (opt.wide_collapse) hipLaunchKernelGGL(k_wide_level<true>, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
-                                                      out.wnodes.p, packets_p, out.wpackets.p);
-            else hipLaunchKernelGGL(k_wide_level<false>, dim3(cdiv(n_in, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, n_in, base_in, base_in + n_in, fo, wc.p,
-                                    out.wnodes.p, packets_p, out.wpackets.p);
-            uint32_t n_out = 0;
-            MRT_HIP(hipMemcpyAsync(&n_out, wc.p, 4, hipMemcpyDeviceToHost, stream));
+        std::vector<uint32_t> h_lv(WIDE_LV_WORDS, 0u);
+        uint32_t total = 0; int depth = 0;
+        constexpr int LEVELS_PER_READBACK = 16;
+        for (uint32_t L0 = 0; ; L0 += LEVELS_PER_READBACK) {
+            if (L0 + LEVELS_PER_READBACK >= WIDE_LV_MAX) { set_error("wide BVH deeper than 4096 levels"); return MRT_ERR_UNSUPPORTED; }
+            for (uint32_t L = L0; L < L0 + LEVELS_PER_READBACK; L++) {
+                const size_t ub = L >= 8 ? max_w : std::min<size_t>(max_w, (size_t)1 << (3 * L));      // a level holds at most 8^L nodes
+                uint32_t *fin = (L & 1) ? fb.p : fa.p, *fo = (L & 1) ? fa.p : fb.p;
+                if (opt.wide_collapse) hipLaunchKernelGGL(k_wide_level<true>, dim3(cdiv(ub, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, L, (uint32_t)max_w, fo, lv.p, wtmp.p, packets_p, out.wpackets.p);
+                else hipLaunchKernelGGL(k_wide_level<false>, dim3(cdiv(ub, 64)), dim3(64), 0, stream, t, dp, leaf_offset.p, fin, L, (uint32_t)max_w, fo, lv.p, wtmp.p, packets_p, out.wpackets.p);
+            }
+            MRT_HIP(hipMemcpyAsync(h_lv.data(), lv.p, WIDE_LV_WORDS * 4, hipMemcpyDeviceToHost, stream));
             MRT_HIP(hipStreamSynchronize(stream));
-            total += n_in; base_in += n_in; n_in = n_out;
-            std::swap(fin, fo);
+            if (h_lv[WIDE_LV_ERROR]) { set_error("wide BVH build overflow"); return MRT_ERR_HIP; }
+            if (h_lv[L0 + LEVELS_PER_READBACK] == 0) break;           // the last level of the batch left nothing to do
         }
+        for (uint32_t L = 0; L < WIDE_LV_MAX && h_lv[L] != 0; L++) { depth++; total += h_lv[L]; }
+        if (total > max_w) { set_error("wide BVH build overflow"); return MRT_ERR_HIP; }
+        if (h_lv[WIDE_LV_PACKETS] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
+        MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * (size_t)std::max(total, 1u)));
+        MRT_HIP(hipMemcpyAsync(out.wnodes.p, wtmp.p, WNODE_STRIDE * (size_t)total * sizeof(float4), hipMemcpyDeviceToDevice, stream));
         MRT_HIP(hipEventRecord(ev1, stream));
         MRT_HIP(hipStreamSynchronize(stream));
         MRT_HIP(hipGetLastError());
         float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
-        uint32_t h_wc[2]; MRT_HIP(hipMemcpy(h_wc, wc.p, 8, hipMemcpyDeviceToHost));
-        if (h_wc[1] != n) { set_error("wide BVH build lost triangles"); return MRT_ERR_HIP; }
         out.stats.build_ms += wms;
         out.wide_depth = depth;
-        if ((size_t)total + 1 < max_w) {            // keep what the tree uses
-            DevBuf<float4> trimmed; MRT_HIP(trimmed.alloc(WNODE_STRIDE * (size_t)std::max(total, 1u)));
-            MRT_HIP(hipMemcpyAsync(trimmed.p, out.wnodes.p, WNODE_STRIDE * (size_t)total * sizeof(float4), hipMemcpyDeviceToDevice, stream));
-            MRT_HIP(hipStreamSynchronize(stream));
-            std::swap(out.wnodes.p, trimmed.p); std::swap(out.wnodes.n, trimmed.n);
-        }
-        if (depth <= WIDE_STACK && total < (1u << 24)) out.num_wnodes = total;       // deeper than the LDS stack (or child_base beyond its 24 stack bits): keep the rope backend
+        if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;

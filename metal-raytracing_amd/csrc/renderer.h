@@ -20,12 +20,9 @@ struct FrameLane {
     DevBuf<float4> sample;               // [sub-frame][pixel] radiance of the batch's frames
     DevBuf<float4> rayA[2], rayB[2], thr[2], hits, srayA, srayB, scon;
     DevBuf<unsigned long long> bounce_counts;   // per bounce {next-queue rays (lo 32), shadow rays (hi 32)}
-    // flow passes (renderer option flow = 1, flow.h): the bounces' queues are all live at once, so every bounce has its own shadow queue, hit records and
-    // contribution plane; allocated at the first flow pass of the lane
-    DevBuf<float4> f_dirs, f_sA[2], f_sB[2], f_hits[2], f_con[2];
-    DevBuf<uint8_t> f_lit;               // [bounce][sub-frame][pixel]
-    DevBuf<uint32_t> f_words;            // FW_* header + the queues' ready rings
-    DevBuf<const void *> f_tab;          // the kernel's table of pointers to all of these (flow.h FT_*)
+    // shadow planes (default path): the light's contribution of bounces 1 and 2 per sample (bounce 0 uses `sample`) and one byte per sample and bounce "the shadow ray got through"
+    DevBuf<float4> f_con[2];
+    DevBuf<uint8_t> f_lit;               // [sub-frame][pixel][bounce]: one 32-bit word per sample
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 constexpr int MAX_FRAME_BATCH = 32;
@@ -49,11 +46,7 @@ struct Renderer {
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
     DevBuf<uint32_t> hint;               // per pixel: the packet its primary ray hit last (k_trace_primary tests it first); 0xFFFFFFFF = none
     bool primary_hint = true;
-    DevBuf<float4> htab;                 // Halton table: 128-byte rows, one per Halton index the first 65 536 frames can reach (renderer.hip k_halton_table)
-    DevBuf<float> hprim;                 // halton_table = 2: dimension 1 only
     bool throughput_chain = true;        // bounce rays carry the resource slots of their path instead of a throughput record (renderer.hip FrameParams::chain)
-    bool queue_uncached = false;         // experiment: ray / hit queues in uncached device memory (must be set before the first draw)
-    int halton_table = 0;                // 0 = digit loops (default: measured fastest), 1 = full table, 2 = table for dimension 1 only
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 6;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 6 lanes x 8-frame passes measured best on MI355X (12 x 4 until then)
@@ -64,35 +57,18 @@ struct Renderer {
     bool megakernel = false;             // one launch per frame (k_megakernel): lowest latency of a single frame; the wavefront pipeline has the higher throughput
     int mega_slots = 0; size_t mega_slots_for_stack = ~(size_t)0;
     bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
-    bool fused = true;                   // primary-ray generation fused into the first trace; shadow(b) + extend(b+1) in one launch
-    bool primary_wide = false;           // experiment: primary rays on the wide stream kernel instead of the rope kernel
-    bool shadow_rope = false;            // experiment: shadow rays on the rope kernel (own launch), bounce rays on the wide stream kernel
+    int primary_wide = 0;                // A/B switch: 1 = primary rays on the wide stream kernel (own launch) instead of inside shade(0)
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it
     size_t slots_for_stack = ~(size_t)0;
-    // one launch per pass after the primary trace: chunks of rays flow from stage to stage inside it (flow.h); diffuse path, max_bounces <= 3, flattened scenes
-    int flow = 0;
-    int flow_chunk = 512;                // primary slots per stage-0 session (multiple of 64; smaller when the pass is small)
-    int flow_take = 8;                   // K: descriptors a traversal session pulls at a time
-    int flow_session_rays = 2048;        // rays a traversal session starts before it drains and shades its hits
-    int flow_granule = 128;              // rays per descriptor
-    int flow_mix = 1;                    // a traversal session that traces bounce rays fills up with shadow rays
-    int flow_order = 1;                  // 1: the shallowest stage with work first, 0: the deepest
-    int flow_idle_polls = 4096;          // polls without work before a wave leaves the launch whatever is outstanding (a bound, not a policy)
-    int flow_exit_rays = 512;            // a wave without work leaves when fewer rays than this PER WAVE of the launch are outstanding in the pass
-    int flow_slots = 0;                  // waves of the launch; 0 = the occupancy query's answer
-    int flow_slots_auto = 0; size_t flow_slots_for_stack = ~(size_t)0;
-    int alloc_flow(FrameLane &L);
     int alloc_planes(FrameLane &L);
     bool tail_accumulate = true;         // the last passes of a draw (one per lane) are accumulated in one launch after the join instead of one after the other
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
-    bool wide_stream = true;             // wide bounce/shadow traversal with lane refill (one wave walks 384 consecutive rays)
-    bool wide_bounce = true;             // fused pipeline: trace the bounce / shadow queues on the 8-wide layout (needs scene option wide=1)
-    bool use_wide = false;               // traverse the 8-wide compressed layout (LDS stack) instead of the rope layout (measured slower: DESIGN.md §6)
+    bool wide_bounce = true;             // A/B switch: 0 = bounce / shadow rays on the rope kernels although the scene has the 8-wide layout
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays
 

@@ -5,20 +5,20 @@
 // The reference is one megakernel over Apple's opaque intersector; here the frame is a wavefront
 // pipeline over ray / hit records in HBM:
 //
-//   k_raygen      Halton-jittered primary rays                       (Raytracing.metal:171-221)
-//   k_extend      closest hit: stackless rope traversal + Möller–Trumbore   (:230-247, opaque in the reference)
+//   primary rays  Halton-jittered, traced to their closest hit                                (Raytracing.metal:171-247)
 //   k_shade       normal interpolation, light pick + evaluation, throughput, NEE shadow-ray emit,
-//                 cosine-hemisphere bounce; wave-ballot compaction of both output queues  (:249-391)
-//   k_shadow      any hit; unoccluded contributions are added to the pixel's sample        (:360-374)
-//   k_accumulate  running average with the previous target                                  (:394-403)
+//                 cosine-hemisphere bounce; wave-ballot compaction of both output queues      (:249-391)
+//   traversal     bounce rays (closest hit) and shadow rays (any hit) of that shade, ONE launch (:244, :367)
+//   accumulate    running average with the previous target                                    (:394-403)
 //
-// That is the plain sequence (renderer option fused = 0).  The DEFAULT pass carries four frames and runs
-//   k_shade<.., TRACE0>          primary rays generated, traced (rope walk + last frame's hit as a hint) and shaded in one launch
+// The DEFAULT pass carries up to eight frames and runs
+//   k_shade<.., TRACE0>          primary rays generated, traced (last frame's hit as a hint) and shaded in one launch
 //   k_trace_mixed_wide_persist   per bounce: its bounce rays (closest hit) and shadow rays (any hit) in ONE launch of persistent waves on the
 //                                8-wide layout (traverse_wide.h); a shadow ray that gets through sets one byte
 //   k_shade                      bounces 1, 2: the light's contribution goes to a per-bounce plane, the throughput is rebuilt from resource slots
 //   k_accumulate_planes          contributions whose byte is set, summed in bounce order; running average (the last passes of a draw: one launch)
-// on up to twelve streams; instanced scenes walk both levels with the same kernels (<TWO_LEVEL>); flow.h is the one-launch-per-pass experiment.
+// on up to six streams; instanced scenes walk both levels with the same kernels (<TWO_LEVEL>).  Scenes without the 8-wide layout (scene option wide = 0, a tree
+// deeper than WIDE_STACK_MAX) and the materials extension / more than three bounces take the general form of the same pipeline (k_trace_primary, k_trace_mixed, k_accumulate).
 //
 // Record layout (all 16-byte lanes, one dwordx4 per lane per access, fully coalesced):
 //   rayA = {origin.xyz, tmax}   rayB = {direction.xyz, pixel}   thr = {throughput.rgb, -}   (path rays)
@@ -52,41 +52,13 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // out by the shard's own slots, so a rank of N holds 1/N of it and a wave's 8x8 tile is 64 consecutive entries); k_accumulate applies the sub-frames in order.
     uint32_t npix, capacity;
     int32_t batch;
-    // Halton table (renderer option halton_table): row i = every value a path of up to HTAB_BOUNCES bounces draws for Halton index i, or nullptr
-    // when this launch's indices / bounce are not covered (the kernels then run the digit loop of device_math.h)
-    const float4 *htab;
-    const float *hprim;
     // throughput chain (fused pipeline, diffuse-only, max_bounces <= 3, <= 65 536 resource slots): a bounce ray carries the resource slots of the surfaces its path has left
     // (16 bits each, in the tmax word — always +inf for a bounce ray, and every traversal kernel takes it as such) instead of a 16-byte throughput record; the next
     // shade multiplies the same base colours in the same order (Raytracing.metal:339), so the floats are the ones the record would have held
-    int32_t chain;          // halton_table = 2: only dimension 1 of the pixel jitter (base 3, 13 digits: the longest digit loop), one float per index (4.4 MB)
+    int32_t chain;
+    uint32_t wide_stack_words;      // k_shade<.., TRACE0 = 2>: 32-bit words of LDS stack per wave (the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES / 4)
 };
 
-// The Halton values are a pure function of (index, dimension), the index is seed offset + frame < 2^20 + frames, and one frame evaluates ~22 M
-// of them with a digit loop of 100-400 issue cycles each (most of k_shade, a fifth of k_trace_primary): the table holds them
-// for every index the first HTAB_FRAMES frames can reach — 19 M values, fewer than ONE frame computes — one 128-byte row per index:
-//   float4 0: dims 0, 1 (pixel jitter, Raytracing.metal:202-203)       float4 2 + 2b, 3 + 2b: dims 2 + 5b .. 6 + 5b of bounce b < 3 (:272, :281-290, :384-385)
-// so that a hit reads ONE 32-byte segment instead of running five digit loops.  Same function, same floats: the image does not change.
-constexpr uint32_t HTAB_BOUNCES = 3, HTAB_ROW = 8, HTAB_FRAMES = 65536;
-constexpr uint32_t HTAB_ROWS = (1u << 20) + HTAB_FRAMES + 64;
-__global__ void k_halton_dim1(float *__restrict__ tab, uint32_t rows) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) tab[i] = halton_dev((int)i, 1);
-}
-__global__ void k_halton_table(float4 *__restrict__ tab, uint32_t rows) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    float4 *row = tab + (size_t)HTAB_ROW * i;
-    row[0] = make_float4(halton_dev((int)i, 0), halton_dev((int)i, 1), 0.0f, 0.0f);
-    row[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t b = 0; b < HTAB_BOUNCES; b++) {
-        const int d = 2 + 5 * (int)b;
-        row[2 + 2 * b] = make_float4(halton_dev((int)i, d), halton_dev((int)i, d + 1), halton_dev((int)i, d + 2), halton_dev((int)i, d + 3));
-        row[3 + 2 * b] = make_float4(halton_dev((int)i, d + 4), 0.0f, 0.0f, 0.0f);
-    }
-}
-
-constexpr uint32_t DEAD_PIXEL = 0xFFFFFFFFu;
 
 // local slot -> pixel: one wave = one 8x8 tile (Renderer.swift:295-300), tiles dealt round-robin to shards
 MRT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, int &x, int &y) {
@@ -118,9 +90,7 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
     uint32_t offset = q2load(&seeds[sample_index]);                      // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
     float r0, r1;                                                        // :202-203
-    if (fp.htab) { const float4 q = fp.htab[(size_t)HTAB_ROW * (uint32_t)idx]; r0 = q.x; r1 = q.y; }
-    else if (fp.hprim) { r0 = halton_dev(idx, 0); r1 = fp.hprim[(uint32_t)idx]; }
-    else { r0 = halton_dev(idx, 0); r1 = halton_dev(idx, 1); }
+    r0 = halton_dev(idx, 0); r1 = halton_dev(idx, 1);
     float px = (float)x + r0, py = (float)y + r1;                        // :204
     float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
     uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
@@ -128,45 +98,7 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
     org = mk3(fp.cam_pos);                                               // :214
 }
 
-__global__ void __launch_bounds__(64) k_raygen(FrameParams fp, const uint32_t *__restrict__ seeds,
-                                               float4 *__restrict__ rayA, float4 *__restrict__ rayB, float4 *__restrict__ thr,
-                                               float4 *__restrict__ sample) {
-    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-    int x, y;
-    if (!slot_to_pixel(fp, slot, x, y)) {
-        if ((int)(slot >> 6) < fp.tiles_local) rayB[slot] = make_float4(0, 0, 0, __uint_as_float(DEAD_PIXEL));
-        return;
-    }
-    const uint32_t pix = slot;                                           // sample index (one frame per pass here)
-    uint32_t offset = seeds[pix];                                        // Raytracing.metal:175
-    int idx = (int)(offset + fp.sampleIndex);
-    float r0 = halton_dev(idx, 0), r1 = halton_dev(idx, 1);              // :202-203
-    float px = (float)x + r0, py = (float)y + r1;                        // :204
-    float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
-    uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
-    f3 dir = normalize3((uvx * mk3(fp.cam_right) + uvy * mk3(fp.cam_up)) + mk3(fp.cam_fwd));   // :216-218
-    rayA[slot] = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());      // :214,:220
-    rayB[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pix));
-    thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
-    sample[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                   // :227
-}
-
-// traversal core: traverse.h
-
-// ------------------------------------------------------------------ closest hit over a ray queue
-__global__ void __launch_bounds__(64) k_extend(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                                               const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    uint32_t n = count ? (uint32_t)*count : capacity;
-    if (i >= n) return;
-    float4 A = rayA[i], B = rayB[i];
-    if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
-    TravHit h;
-    bool hit = traverse<false>(s, mk3(A), mk3(B), 0.0f, A.w, h);
-    hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-}
-
-// ------------------------------------------------------------------ fused pipeline (default)
+// ------------------------------------------------------------------ traversal launches of the pipeline
 // Fewer, fatter traversal launches: every launch ends in a latency-bound tail (a handful of waves walking
 // the longest rays), so the frame runs  primary -> shade -> [shadow(b) + extend(b+1)] -> shade -> ... .
 //   k_trace_primary : primary-ray generation (Raytracing.metal:171-221) fused with the first closest-hit query
@@ -233,60 +165,8 @@ __global__ void __launch_bounds__(64) k_trace_mixed(SceneView s, const float4 *_
     }
 }
 
-// ------------------------------------------------------------------ wide-BVH backend (LDS stack)
-__global__ void __launch_bounds__(64) k_extend_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB,
-                                                    const unsigned long long *__restrict__ count, uint32_t capacity, float4 *__restrict__ hits) {
-    __shared__ uint32_t stk[WIDE_STACK * WIDE_STACK_LEVEL_BYTES / 4];
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    uint32_t n = count ? (uint32_t)*count : capacity;
-    if (i >= n) return;
-    float4 A = rayA[i], B = rayB[i];
-    if (__float_as_uint(B.w) == DEAD_PIXEL) { hits[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); return; }
-    TravHit h;
-    bool hit = traverse_wide<false>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
-    hits[i] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-}
-__global__ void __launch_bounds__(64) k_shadow_wide(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                    const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
-    __shared__ uint32_t stk[WIDE_STACK * WIDE_STACK_LEVEL_BYTES / 4];
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= (uint32_t)(*count >> 32)) return;
-    float4 A = srayA[i], B = srayB[i];
-    TravHit h;
-    bool occluded = traverse_wide<true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk);
-    if (!occluded) {
-        uint32_t pix = __float_as_uint(B.w);
-        float4 c = scon[i], a = sample[pix];
-        sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);
-    }
-}
-
-__global__ void __launch_bounds__(64) k_trace_mixed_wide(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
-                                                         const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                         const unsigned long long *__restrict__ counts, float4 *__restrict__ sample) {
-    extern __shared__ uint32_t stk_dyn[];     // wide-tree depth x WIDE_STACK_LEVEL_BYTES, sized by the host from the scene's depth
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32);
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_next + n_shadow) return;
-    const bool shadow = i >= n_next;
-    const uint32_t j = shadow ? i - n_next : i;
-    float4 A = shadow ? srayA[j] : rayA[j]; const float4 B = shadow ? srayB[j] : rayB[j];
-    if (!shadow) A.w = __builtin_inff();
-    TravHit h;
-    bool hit = traverse_wide<false, false, true>(s, mk3(A), mk3(B), 0.0f, A.w, h, stk_dyn, nullptr, shadow);
-    if (shadow) {
-        if (!hit) {
-            uint32_t pix = __float_as_uint(B.w);
-            float4 cc = scon[j], a = sample[pix];
-            sample[pix] = make_float4(a.x + cc.x, a.y + cc.y, a.z + cc.z, 0.0f);
-        }
-    } else {
-        hits[j] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-    }
-}
-
-// Stream variant of k_trace_mixed_wide: one wave walks `rays_per_wave` consecutive rays of the combined queue
+// ------------------------------------------------------------------ 8-wide layout (LDS stack, traverse_wide.h)
+// One wave walks `rays_per_wave` consecutive rays of the combined queue
 // [next-bounce rays | shadow rays] with lane refill (traverse_wide_stream).  Longer ranges amortise the drain at the end
 // of a wave's range, shorter ones keep the launch's tail short and the grid large; the host picks the range from the
 // size of the launch (stream_rays_per_wave): one frame per pass (4 M slots): 384 measured best (256: -2 %, 512: -1 %,
@@ -311,10 +191,10 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, int skip_shadow, uint32_t rays_per_wave, uint8_t *__restrict__ lit, uint32_t even_waves) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t rays_per_wave, uint8_t *__restrict__ lit, uint32_t even_waves) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = skip_shadow ? 0u : (uint32_t)(c >> 32), n = n_next + n_shadow;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
     // even_waves (renderer option stream_even): the launch has that many waves and the rays the queue really holds are split evenly among them (whole 64-ray
     // batches) instead of rays_per_wave each to the first n / rays_per_wave waves of a grid sized for the queue's capacity
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
@@ -676,15 +556,15 @@ __global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s
 #ifndef MRT_SHADE_WAVES
 #define MRT_SHADE_WAVES 6     // waves per SIMD k_shade is compiled for: it needs 76-78 registers; capped at 72 (7 waves) it spills 16-48 bytes and the frame is 4 % slower, at 64 (8 waves) 6 % slower
 #endif
-#ifndef MRT_SHADE_XCD_BANDS
-#define MRT_SHADE_XCD_BANDS 0
+#ifndef MRT_SHADE_WIDE_WAVES
+#define MRT_SHADE_WIDE_WAVES 5     // k_shade<.., TRACE0 = 2>: the 8-wide walk holds a node (20 registers) and a packet (10) on top of the shading state
 #endif
 constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool TAB, bool CHAIN, bool PLANES = false, bool TRACE0 = false>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (k_trace_primary's body) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); TAB: the bounce's Halton values come from the table (fp.htab covers this launch); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
-__global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
+__global__ void __launch_bounds__(SHADE_THREADS, TRACE0 == 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
@@ -697,16 +577,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
     __shared__ unsigned long long blk_base;
     // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
     const uint32_t sub = sample_primary ? blockIdx.y : 0u;
-    // bounce 0 (hits in pixel-tile order): workgroup w runs on XCD w % 8, each with its own 4 MB L2.  A contiguous eighth of the image per XCD keeps that
-    // XCD's gathers (shading records, vertex normals: 21 MB over the whole image) inside its L2; the work per hit is uniform enough for the split to stay even.
-    uint32_t bx = blockIdx.x;
-#if MRT_SHADE_XCD_BANDS
-    if (sample_primary) {
-        const uint32_t per = (gridDim.x + 7u) >> 3;
-        bx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    }
-#endif
-    const uint32_t slot = bx * SHADE_THREADS + threadIdx.x;
+    const uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
     const uint32_t i = sub * capacity + slot;
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
     bool active = slot < n;
@@ -725,7 +596,24 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
             Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
             TravHit h;
             bool hit;
-            if (hint != nullptr) {
+            if (TRACE0 == 2) {
+                extern __shared__ uint32_t shade_stk[];          // SHADE_WAVES x wide-tree depth x WIDE_STACK_LEVEL_BYTES
+                uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
+                if (hint != nullptr) {
+                    const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+                    const uint32_t guess = hint[pixel];
+                    float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
+                    if (guess < s.num_wpackets) {
+                        const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
+                        float t, U, V, ad;
+                        if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+                    }
+                    hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk);
+                    if (h.pk != guess) hint[pixel] = h.pk;
+                }
+                else hit = traverse_wide_lane<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk);
+            }
+            else if (hint != nullptr) {
                 const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
                 const uint32_t guess = hint[pixel];
                 h.t = __builtin_inff(); h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = 0xFFFFFFFFu;
@@ -785,10 +673,6 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         if (CHAIN) chain_out = fp.bounce == 0 ? rslot : (chain_in & 0xFFFFu) | (rslot << 16);
         int idx = (int)(q2load(&seeds[pix]) + fp.sampleIndex);         // pix = sub * npix + pixel: the table entry already holds + sub
         const int dim0 = 2 + fp.bounce * 5;
-        // the five Halton values of this bounce: one 32-byte segment of the table row, or the digit loops (wave-uniform choice)
-        constexpr bool tab = TAB;
-        float4 hq = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float hq4 = 0.0f;
-        if (tab) { const float4 *__restrict__ row = fp.htab + (size_t)HTAB_ROW * (uint32_t)idx + 2 + 2 * fp.bounce; hq = qload(&row[0]); hq4 = qload(&row[1]).x; }
         norg = P + nrm * 1e-3f;                                          // :350, :390
         color = mk3(C);
         bool diffuse = true;
@@ -829,7 +713,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
                 const float ud = trn > 0.0f ? (ul - trn) / (1.0f - trn) : ul;
                 const float ps = (ks > 0.0f && ns > 0.0f) ? ks / (ks + kd) : 0.0f;
                 if (ud < ps) {                                           // specular lobe
-                    const float hx = tab ? hq.w : halton_dev(idx, dim0 + 3), hy = tab ? hq4 : halton_dev(idx, dim0 + 4);
+                    const float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);
                     const float a2 = 2.0f / (ns + 2.0f);
                     const float ct2 = (1.0f - hy) / (1.0f + (a2 - 1.0f) * hy);
                     const float ct = __builtin_sqrtf(ct2), st = __builtin_sqrtf(1.0f - ct2);
@@ -848,13 +732,13 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
             }
         }
         if (diffuse) {
-        float ls = tab ? hq.x : halton_dev(idx, dim0 + 0);               // :272
+        float ls = halton_dev(idx, dim0 + 0);               // :272
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
         const LightDev L = s.lights[li];
         int ltype = __float_as_int(L.position.w);
         if (ltype == MRTLightTypeAreaLight) {                            // :281-290, :94-128
-            float ax = (tab ? hq.y : halton_dev(idx, dim0 + 1)) * 2.0f - 1.0f;
-            float ay = (tab ? hq.z : halton_dev(idx, dim0 + 2)) * 2.0f - 1.0f;
+            float ax = halton_dev(idx, dim0 + 1) * 2.0f - 1.0f;
+            float ay = halton_dev(idx, dim0 + 2) * 2.0f - 1.0f;
             f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
             ldir = sp - P;
             ldist = length3(ldir);
@@ -887,7 +771,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         want_shadow = length3(lcol) > 0.0001f;                           // :341
         want_next = fp.bounce + 1 < fp.max_bounces;
         if (want_next) {
-            float hx = tab ? hq.w : halton_dev(idx, dim0 + 3), hy = tab ? hq4 : halton_dev(idx, dim0 + 4);   // :384-385
+            float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
             ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
         }
         }
@@ -921,21 +805,6 @@ __global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneV
         qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, CHAIN ? __uint_as_float(chain_out) : __builtin_inff()));      // :390 (tmax = inf either way, see FrameParams::chain)
         qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
         if (!CHAIN) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
-    }
-}
-
-// ------------------------------------------------------------------ shadow rays (Raytracing.metal:360-374)
-__global__ void __launch_bounds__(64) k_shadow(SceneView s, const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                               const unsigned long long *__restrict__ count, float4 *__restrict__ sample) {
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= (uint32_t)(*count >> 32)) return;
-    float4 A = srayA[i], B = srayB[i];
-    TravHit h;
-    bool occluded = traverse<true>(s, mk3(A), mk3(B), 0.0f, A.w, h);
-    if (!occluded) {
-        uint32_t pix = __float_as_uint(B.w);
-        float4 c = scon[i], a = sample[pix];
-        sample[pix] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, 0.0f);   // one shadow ray per pixel per bounce: no atomics
     }
 }
 
@@ -973,7 +842,7 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
     q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
-// Shadow planes (renderer option shadow_planes, default; also what a flow pass uses): shade(b) leaves the light's contribution in con[b][pixel], a shadow ray that gets
+// Shadow planes (default): shade(b) leaves the light's contribution in con[b][pixel], a shadow ray that gets
 // through sets lit[pixel][b] (one byte of the four a pixel has per frame), and the pixel's sample is the sum of the contributions whose byte is set, in bounce order — the additions of
 // Raytracing.metal:371-373 on the same floats in the same order as the read-modify-write of one sample buffer made them (0 + c0, + c1, + c2).  Per shadow ray
 // that is 16 bytes written and one byte instead of 32 bytes through the queue and a 32-byte read-modify-write inside the traversal loop.
@@ -1059,8 +928,6 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
     q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
-#include "flow.h"
-
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
 __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4 *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1075,7 +942,7 @@ __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4
 // ------------------------------------------------------------------ query kernels (C-ABI intersect_*)
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, MRTIntersection *__restrict__ out) {
-    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
+    extern __shared__ uint32_t stk[];      // WIDE: the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES, sized by the host
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
@@ -1097,7 +964,7 @@ __global__ void __launch_bounds__(64) k_query_closest(SceneView s, const MRTRay 
 }
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int32_t *__restrict__ out) {
-    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
+    extern __shared__ uint32_t stk[];      // WIDE: the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES, sized by the host
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
@@ -1110,7 +977,7 @@ __global__ void __launch_bounds__(64) k_query_any(SceneView s, const MRTRay *__r
 // per-ray traversal statistics (steps, leaf visits, triangle tests) — diagnostics only
 template <bool WIDE>
 __global__ void __launch_bounds__(64) k_query_stats(SceneView s, const MRTRay *__restrict__ rays, uint32_t n, int any, uint32_t *__restrict__ out) {
-    __shared__ uint32_t stk[(WIDE ? WIDE_STACK : 1) * WIDE_STACK_LEVEL_BYTES / 4];
+    extern __shared__ uint32_t stk[];      // WIDE: the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES, sized by the host
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     MRTRay r = rays[i];
@@ -1300,22 +1167,19 @@ int Renderer::alloc_queues() {
     return MRT_OK;
 }
 
-// descriptors a flow queue's ready ring can hold: a session publishes its rays in granules of >= 64, the last one partly filled
-static inline size_t flow_written_words(size_t qcap) { return 2 * (qcap >> 6) + 4; }
+constexpr int PLANES_MAX_BOUNCES = 3;        // shadow planes: sample + two more contribution planes, three flag bytes of the pixel's word
+
 size_t Renderer::lane_bytes() const {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
-    const bool need_thr = !(throughput_chain && (fused || (scene && scene->num_inst)) && !use_wide && !materials && max_bounces <= 3);
+    const bool need_thr = !(throughput_chain && !materials && max_bounces <= 3);
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
-    const size_t planes_bytes = (flow || shadow_planes) ? 2 * spix * sizeof(float4) + spix * 4 : 0;
-    const size_t flow_bytes = planes_bytes + (flow ? 7 * qcap * sizeof(float4) + (FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * flow_written_words(qcap)) * 4 : 0);
+    const size_t planes_bytes = shadow_planes ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const bool need_scon = need_thr || !shadow_planes;
-    return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + flow_bytes;
+    return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + planes_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
-    for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); }
-    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release();
-    L.f_dirs.release(); L.f_lit.release(); L.f_words.release(); L.f_tab.release();
-    for (int k = 0; k < 2; k++) { L.f_sA[k].release(); L.f_sB[k].release(); L.f_hits[k].release(); L.f_con[k].release(); }
+    for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); L.f_con[k].release(); }
+    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release();
 }
 int Renderer::alloc_planes(FrameLane &L) {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
@@ -1323,32 +1187,12 @@ int Renderer::alloc_planes(FrameLane &L) {
     MRT_HIP(L.f_lit.alloc(spix * 4));          // [sub-frame][pixel][bounce]: one 32-bit word per pixel and frame
     return MRT_OK;
 }
-int Renderer::alloc_flow(FrameLane &L) {
-    const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
-    if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
-    MRT_HIP(L.f_dirs.alloc(qcap));
-    for (int k = 0; k < 2; k++) { MRT_HIP(L.f_sA[k].alloc(qcap)); MRT_HIP(L.f_sB[k].alloc(qcap)); MRT_HIP(L.f_hits[k].alloc(qcap)); }
-    const size_t ww = flow_written_words(qcap);
-    MRT_HIP(L.f_words.alloc(FLOW_HEADER_WORDS + 2 * FLOW_QUEUES * ww));      // header + five rings of 64-bit descriptors
-    // the kernel's table of pointers (flow.h FT_*)
-    const void *tab[FT_COUNT] = {};
-    for (int k = 0; k < 2; k++) { tab[FT_QA + k] = L.rayA[k].p; tab[FT_QB + k] = L.rayB[k].p; }
-    tab[FT_SA] = L.srayA.p; tab[FT_SB] = L.srayB.p; tab[FT_HITS] = L.hits.p; tab[FT_CON] = L.sample.p;
-    for (int k = 0; k < 2; k++) { tab[FT_SA + 1 + k] = L.f_sA[k].p; tab[FT_SB + 1 + k] = L.f_sB[k].p; tab[FT_HITS + 1 + k] = L.f_hits[k].p; tab[FT_CON + 1 + k] = L.f_con[k].p; }
-    for (int k = 0; k < FLOW_MAX_BOUNCES; k++) tab[FT_LIT + k] = L.f_lit.p + k;
-    for (int k = 0; k < FLOW_QUEUES; k++) tab[FT_RING + k] = reinterpret_cast<unsigned long long *>(L.f_words.p + FLOW_HEADER_WORDS) + (size_t)k * ww;
-    tab[FT_DIRS] = L.f_dirs.p;
-    MRT_HIP(L.f_tab.alloc(FT_COUNT));
-    MRT_HIP(hipMemcpy(L.f_tab.p, tab, sizeof tab, hipMemcpyHostToDevice));
-    return MRT_OK;
-}
 int Renderer::alloc_lane(FrameLane &L) {
     const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);      // a batch of frames shares one set of queues
-    const unsigned qf = queue_uncached ? hipDeviceMallocUncached : hipDeviceMallocDefault;
-    const bool need_thr = !(throughput_chain && (fused || scene->num_inst) && !use_wide && !materials && max_bounces <= 3);      // else on demand (render())
-    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap, qf)); MRT_HIP(L.rayB[k].alloc(qcap, qf)); if (need_thr) MRT_HIP(L.thr[k].alloc(qcap, qf)); }
-    MRT_HIP(L.hits.alloc(qcap, qf)); MRT_HIP(L.srayA.alloc(qcap, qf)); MRT_HIP(L.srayB.alloc(qcap, qf));
-    if (need_thr || !shadow_planes) MRT_HIP(L.scon.alloc(qcap, qf));          // the contribution queue: with shadow planes only the passes they do not cover need it (allocated then, render())
+    const bool need_thr = !(throughput_chain && !materials && max_bounces <= 3);      // else on demand (render())
+    for (int k = 0; k < 2; k++) { MRT_HIP(L.rayA[k].alloc(qcap)); MRT_HIP(L.rayB[k].alloc(qcap)); if (need_thr) MRT_HIP(L.thr[k].alloc(qcap)); }
+    MRT_HIP(L.hits.alloc(qcap)); MRT_HIP(L.srayA.alloc(qcap)); MRT_HIP(L.srayB.alloc(qcap));
+    if (need_thr || !shadow_planes) MRT_HIP(L.scon.alloc(qcap));          // the contribution queue: with shadow planes only the passes they do not cover need it (allocated then, render())
     MRT_HIP(L.sample.alloc((size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     if (shadow_planes && !need_thr) { if (int rc = alloc_planes(L)) return rc; }
@@ -1379,8 +1223,7 @@ int Renderer::render(int n_frames) {                                   // Render
     fp.tiles_x = (width + 7) / 8; fp.tiles_local = tiles_local; fp.max_bounces = max_bounces;
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
-    const bool two_level = sv.num_inst > 0;          // instanced scene: the fused pipeline on the two-level rope kernels
-    const bool wide = use_wide && sv.num_wnodes > 0 && !two_level && !materials;
+    const bool two_level = sv.num_inst > 0;          // instanced scene: TLAS + BLASes walked by the same kernels (<TWO_LEVEL>)
     if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
         const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
@@ -1396,7 +1239,7 @@ int Renderer::render(int n_frames) {                                   // Render
         frame_index = keep_frame; cur = keep_cur; frames_rendered = keep_rendered; frames_completed_known = keep_rendered; camera = keep_cam;
         return render(n_frames);
     }
-    // the first draw sizes the lanes in use.  A lane's queues take ~176 B x pixels x frame_batch (1080p, 4-frame passes: 1.5 GB); when the
+    // the first draw sizes the lanes in use.  A lane's queues take ~163 B x pixels x frame_batch (1080p, 8-frame passes: 2.7 GB); when the
     // device cannot hold all the lanes asked for, the renderer runs on the ones it got (>= 1) instead of failing in the middle of a draw
     int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
     for (; lanes_ready < F; lanes_ready++) {
@@ -1414,30 +1257,20 @@ int Renderer::render(int n_frames) {                                   // Render
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
     MRT_HIP(hipEventRecord(ev_fork, stream));
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
-    // frames are carried through the pipeline in batches of `frame_batch` (larger launches: a launch's tail and the dispatch
-    // gap between a stream's kernels are paid once per batch); the unfused sequence keeps one frame per pass
-    // measuring aid (tools/gpu_r03t.sh): MRT_ABLATE=1 skips the primary launches, =2 the bounce / shadow traversal launches — the other kernels then run on the
-    // stale but well-formed queues of an earlier pass, so their load is realistic and the frame time shows what the skipped stage costs under overlap.  Images are garbage.
+#ifdef MRT_DIAGNOSTICS
+    // measuring aid of the diagnostics build only (tools/build_variant.sh diag "-DMRT_DIAGNOSTICS"; tools/gpu_stage_ablation.sh): MRT_ABLATE=1 skips the primary launches, =2 the
+    // bounce / shadow traversal launches — the other kernels then run on the stale but well-formed queues of an earlier pass, so their load is realistic and the frame time shows
+    // what the skipped stage costs under overlap.  Images are garbage; the release library does not read the variable.
     static const int ablate = getenv("MRT_ABLATE") ? atoi(getenv("MRT_ABLATE")) : 0;
-    const bool mega = megakernel && !two_level && !materials && !wide && sv.num_wnodes > 0;
+#else
+    constexpr int ablate = 0;
+#endif
+    const bool mega = megakernel && !two_level && !materials && sv.num_wnodes > 0;
     // passes larger than the default (sharded renderers ask for up to 32 frames so that a shard's launches stay large) never take more than a third of the draw:
     // a short draw keeps about three passes to run side by side (a rank of eight over 20 frames: 7.1 Grays/s as 7 + 7 + 6, 6.0 as one pass of 20)
     const int batch_cap = alloc_batch > DEFAULT_FRAME_BATCH ? std::min(alloc_batch, std::max(DEFAULT_FRAME_BATCH, (n_frames + 2) / 3)) : alloc_batch;
-    const int batch_max = mega ? 1 : ((fused || two_level || materials) && !wide) ? batch_cap : 1;
+    const int batch_max = mega ? 1 : batch_cap;
     fp.npix = (uint32_t)((size_t)width * height); fp.capacity = capacity;
-    fp.htab = nullptr; fp.hprim = nullptr;
-    if (halton_table == 2 && !hprim.p) {
-        MRT_HIP(hprim.alloc(HTAB_ROWS));
-        hipLaunchKernelGGL(k_halton_dim1, dim3(cdiv(HTAB_ROWS, 256)), dim3(256), 0, stream, hprim.p, HTAB_ROWS);
-        MRT_HIP(hipEventRecord(ev_fork, stream));
-        for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
-    }
-    if (halton_table == 1 && !htab.p) {                                      // built once per renderer: fewer Halton values than one frame evaluates
-        MRT_HIP(htab.alloc((size_t)HTAB_ROW * HTAB_ROWS));
-        hipLaunchKernelGGL(k_halton_table, dim3(cdiv(HTAB_ROWS, 256)), dim3(256), 0, stream, htab.p, HTAB_ROWS);
-        MRT_HIP(hipEventRecord(ev_fork, stream));
-        for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
-    }
     hipEvent_t last_acc = nullptr;
     int pass = 0;
     const int n_passes = (n_frames + batch_max - 1) / batch_max;
@@ -1453,12 +1286,7 @@ int Renderer::render(int n_frames) {                                   // Render
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
-        // the table covers this pass when its largest Halton index — seed offset (< 2^20) + sub-frame + sample index — is a row of it
-        const bool covered = (uint64_t)fp.sampleIndex + (uint64_t)B + (1ull << 20) <= (uint64_t)HTAB_ROWS;
-        const float4 *const htab_pass = (halton_table == 1 && htab.p && covered) ? htab.p : nullptr;
-        fp.htab = htab_pass;
-        fp.hprim = (halton_table == 2 && hprim.p && covered) ? hprim.p : nullptr;
-        bool flow_pass = false, used_planes = false;
+        bool used_planes = false;
         if (mega) {
             // one launch per frame on the pass's stream; frames are sequential (a path's last act is the running average with the previous target)
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES;
@@ -1485,10 +1313,10 @@ int Renderer::render(int n_frames) {                                   // Render
             if (int rc = note_pass(st)) return rc;
             continue;
         }
-        if ((fused || two_level || materials) && !wide) {
-            // fused pipeline (default): trace_primary -> per bounce { shade, trace_mixed } ; bounce rays and shadow rays share one launch
+        {
+            // the pipeline: primary trace -> per bounce { shade, trace } ; bounce rays and shadow rays of a shade share one traversal launch
             const uint32_t grid_mixed = 2 * grid * (uint32_t)B;
-            const bool on_wide = wide_bounce && sv.num_wnodes > 0;
+            const bool on_wide = wide_bounce && sv.num_wnodes > 0;          // no 8-wide layout (scene option wide = 0, a tree deeper than WIDE_STACK_MAX): the rope kernels
             // two-level scenes walk TLAS and BLASes with the same kernels (traverse_wide_stream<true>); their LDS also parks the lanes' world rays
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (two_level ? WIDE_WORLD_RAY_BYTES : 0);
             if (on_wide && persistent != 0 && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
@@ -1509,51 +1337,22 @@ int Renderer::render(int n_frames) {                                   // Render
                 const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
                 for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap));
             }
-            const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave((shadow_rope ? 1 : 2) * (size_t)capacity * B);
-            // flow pass (flow.h): after the primary trace ONE launch carries the pass; the bounces' queues, hit records and contribution planes are all live at once
-            flow_pass = flow != 0 && fp.chain && on_wide && wide_stream && !two_level && !materials && max_bounces <= FLOW_MAX_BOUNCES && (size_t)capacity * B < (size_t(1) << 27) && !ablate;
-            FlowArgs fa{};
-            if (flow_pass) {
-                if (!L.f_words.p) { if (int rc = alloc_flow(L)) return rc; }
-                fa.counts = bc; fa.words = L.f_words.p;
-                fa.tab = L.f_tab.p;
-                fa.n_primary = (uint32_t)((size_t)capacity * B);
-                fa.idle_polls = (uint32_t)std::max(0, flow_idle_polls);
-                fa.exit_rays = 0;         // (set below, with the launch's size)
-                fa.take = (uint32_t)std::max(1, std::min(flow_take, (int)FLOW_MAX_TAKE));
-                fa.granule = (uint32_t)std::max(64, flow_granule) / 64u * 64u;
-                fa.session_rays = (uint32_t)std::min<size_t>((size_t)std::max(64, flow_session_rays), (size_t)60 * fa.granule);
-                fa.mix = flow_mix != 0 ? 1u : 0u;
-                fa.breadth_first = flow_order != 0 ? 1u : 0u;
-                if (flow_slots_for_stack != stack_bytes) {
-                    int per_cu = 0, dev = 0; hipDeviceProp_t prop;
-                    MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
-                    MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow, 64, stack_bytes));
-                    flow_slots_auto = std::max(1, per_cu) * prop.multiProcessorCount; flow_slots_for_stack = stack_bytes;
-                }
-                // primary slots per stage-0 session: at least two sessions per wave of the launch, so that every wave starts with work and the stage ends evenly
-                const size_t slots = (size_t)(flow_slots > 0 ? flow_slots : flow_slots_auto);
-                uint32_t chunk = (uint32_t)std::max(64, flow_chunk) / 64u * 64u;
-                while (chunk > 64u && (size_t)fa.n_primary / chunk < 2 * slots) chunk -= 64u;
-                chunk = std::min(chunk, 64u * fa.granule);                  // a session publishes at most 64 descriptors per queue
-                fa.chunk = chunk;
-                fa.exit_rays = (uint32_t)std::min<size_t>((size_t)std::max(0, flow_exit_rays) * slots + 1, 0x7FFFFFFFu);
-                MRT_HIP(hipMemsetAsync(L.f_words.p, 0, L.f_words.bytes(), st));
-                MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)capacity * (size_t)B, st));
-            }
-            float4 *const dirs = flow_pass ? L.f_dirs.p : L.rayB[1].p;
+            const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave(2 * (size_t)capacity * B);
+            float4 *const dirs = L.rayB[1].p;
             // shadow planes: contribution per pixel and bounce + one byte per shadow ray that got through, instead of the contribution queue and the read-modify-write of the sample buffer
-            const bool planes_pass = !flow_pass && shadow_planes != 0 && fp.chain && on_wide && wide_stream && !materials && !shadow_rope && max_bounces <= FLOW_MAX_BOUNCES && !ablate;
+            const bool planes_pass = shadow_planes != 0 && fp.chain && on_wide && !materials && max_bounces <= PLANES_MAX_BOUNCES && !ablate;
             if (planes_pass) {
                 if (!L.f_lit.p) { if (int rc = alloc_planes(L)) return rc; }
                 MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)capacity * (size_t)B, st));
             }
             used_planes = planes_pass;
-            // the primary trace inside shade(0): flattened scenes on the rope layout (the primary rays' kernel), planes passes
+            // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
             // fuse_primary = 2 fuses always)
-            const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && !(primary_wide && sv.num_wnodes) && (fuse_primary == 2 || F > 1 || B > 1);
-            if (!planes_pass && !flow_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
+            const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && primary_wide != 1 && (fuse_primary == 2 || F > 1 || B > 1);
+            const bool trace0_wide = trace0_pass && primary_wide == 2;          // (planes_pass implies the 8-wide layout)
+            fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
+            if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
             else if (two_level && on_wide) {
                 // the hint of two-level scenes is (packet | instance << 24): scenes of at most 255 instances and 2^24 packets
@@ -1561,34 +1360,27 @@ int Renderer::render(int n_frames) {                                   // Render
                 if (seeded) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
                 else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
-            else if (primary_wide && sv.num_wnodes && !two_level) {
+            else if (primary_wide == 1 && on_wide && !two_level) {
                 if (primary_hint) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
                 else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
             else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
-            if (flow_pass) {
-                const size_t slots = (size_t)(flow_slots > 0 ? flow_slots : flow_slots_auto);
-                const size_t sessions = cdiv(fa.n_primary, fa.chunk);
-                launch_timed(timed(MRT_KERNEL_TRACE), k_flow, dim3((uint32_t)std::max<size_t>(1, std::min(slots, sessions))), dim3(64), stack_bytes, st, sv, fp, fa, (const uint32_t *)seeds.p);
-                if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-                launch_timed(timed(MRT_KERNEL_ACCUMULATE), k_accumulate_flow, dim3(grid), dim3(64), 0, st, fp, fa, (const float4 *)accum[cur].p, accum[1 - cur].p, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
-            }
             int q = 0;                                                  // shade(b) writes next rays into queue q
-            for (int b = 0; b < max_bounces && !flow_pass; b++) {
+            for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
-                fp.htab = (uint32_t)b < HTAB_BOUNCES ? htab_pass : nullptr;
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
-                const dim3 gs = b == 0 ? dim3(MRT_SHADE_XCD_BANDS ? (grid_shade + 7u) / 8u * 8u : grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                auto shade_kernel = materials ? (fp.htab ? k_shade<true, true, false> : k_shade<true, false, false>)
-                                              : (planes_pass && trace0_pass && b == 0) ? (fp.htab ? k_shade<false, true, true, true, true> : k_shade<false, false, true, true, true>)
-                                              : planes_pass ? (fp.htab ? k_shade<false, true, true, true> : k_shade<false, false, true, true>)
-                                              : fp.chain ? (fp.htab ? k_shade<false, true, true> : k_shade<false, false, true>) : (fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>);
+                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
+                auto shade_kernel = materials ? k_shade<true, false>
+                                              : (trace0_wide && b == 0) ? k_shade<false, true, true, 2>
+                                              : (trace0_pass && b == 0) ? k_shade<false, true, true, 1>
+                                              : planes_pass ? k_shade<false, true, true>
+                                              : fp.chain ? k_shade<false, true> : k_shade<false, false>;
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
-                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES : 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && primary_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
@@ -1597,7 +1389,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 // 7.63 against 7.20 Grays/s, a rank of eight over the driver's 20 frames 6.65 against 5.73): stream_even below
                 const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || (std::min(F, n_passes) >= 5 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 256)));      // (below 256 slots per wave slot — Cornell 256^2 in 8-frame passes — the even split: 6.46 against 5.40 Grays/s)
                 if (ablate & 2) {}
-                else if (on_wide && wide_stream && pull) {
+                else if (on_wide && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
                     // persist_chunk; 128-ray pulls of a one-frame launch are ~78 atomics per microsecond on the one counter word (limit ~88)
                     const size_t slots = 2 * (size_t)capacity * B;
@@ -1618,38 +1410,15 @@ int Renderer::render(int n_frames) {                                   // Render
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
                                  (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg, lit_b);
                 }
-                else if (on_wide && (wide_stream || two_level)) {
-                    const size_t slots_m = (shadow_rope && !two_level ? 1 : 2) * (size_t)capacity * B;
+                else if (on_wide) {
+                    const size_t slots_m = 2 * (size_t)capacity * B;
                     const uint32_t even = stream_even > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)stream_even / 100)) : 0u;     // stream_even: percent of the wave slots
                     const dim3 grid_s(even ? even : cdiv(slots_m, rpw_m));
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, 0, rpw_m, lit_b, even);
-                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, shadow_rope ? 1 : 0, rpw_m, lit_b, even);
-                    if (shadow_rope && !two_level) hipLaunchKernelGGL(k_shadow, dim3(grid * B), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }
-                else if (on_wide) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide, dim3(grid_mixed), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<true>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<false>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
-                q = 1 - q;
-            }
-        } else {
-            // unfused sequence: raygen -> per bounce { extend, shade, shadow }
-            fp.chain = 0;
-            if (!L.thr[0].p) { const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch); for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap)); }
-            if (!L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
-            hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(64), 0, st, fp, seeds.p, L.rayA[0].p, L.rayB[0].p, L.thr[0].p, L.sample.p);
-            int q = 0;
-            for (int b = 0; b < max_bounces; b++) {
-                fp.bounce = b;
-                fp.htab = (uint32_t)b < HTAB_BOUNCES ? htab_pass : nullptr;
-                const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);   // bounce 0: every slot of the primary queue
-                EvPair *ev = nullptr;
-                if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
-                if (wide) launch_timed(ev, k_extend_wide, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                else launch_timed(ev, k_extend, dim3(grid), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, cin, capacity, L.hits.p);
-                hipLaunchKernelGGL((fp.htab ? k_shade<false, true, false> : k_shade<false, false, false>), dim3(grid_shade), dim3(SHADE_THREADS), 0, st, sv, fp, seeds.p, L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.hits.p, cin, capacity,
-                                   L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.srayA.p, L.srayB.p, L.scon.p, bc + b, (float4 *)nullptr, L.sample.p, (uint32_t *)nullptr);
-                if (wide) hipLaunchKernelGGL(k_shadow_wide, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
-                else hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(64), 0, st, sv, L.srayA.p, L.srayB.p, L.scon.p, bc + b, L.sample.p);
                 q = 1 - q;
             }
         }
@@ -1662,8 +1431,8 @@ int Renderer::render(int n_frames) {                                   // Render
             frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
             continue;
         }
-        if (last_acc && !flow_pass) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
-        if (!flow_pass) {
+        if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
+        {
             EvPair *ev = nullptr;
             if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
             if (used_planes) launch_timed(ev, k_accumulate_planes, dim3(grid), dim3(64), 0, st, fp, (const float4 *)L.sample.p, (const float4 *)L.f_con[0].p, (const float4 *)L.f_con[1].p, (const uint8_t *)L.f_lit.p,
@@ -1709,20 +1478,6 @@ static int check_bounds_record() { return MRT_OK; }
 
 int Renderer::wait() {
     MRT_HIP(hipStreamSynchronize(stream));
-#ifdef MRT_FLOW_STATS
-    if (lanes[0].f_words.p) {         // the last pass of lane 0: ticks of 10 ns summed over the launch's waves
-        std::vector<uint32_t> w(FLOW_HEADER_WORDS);
-        MRT_HIP(hipMemcpy(w.data(), lanes[0].f_words.p, FLOW_HEADER_WORDS * 4, hipMemcpyDeviceToHost));
-        auto W = [&](int k) { return (double)w[(FW_STATS + k) * FLOW_LINE]; };
-        fprintf(stderr, "flow queues: Q %u %u %u, SQ %u %u %u, pending+primary %u, errors %u, tails %u %u %u %u %u, heads %u %u %u %u %u\n", w[FW_TRUE_Q * FLOW_LINE], w[(FW_TRUE_Q + 1) * FLOW_LINE], w[(FW_TRUE_Q + 2) * FLOW_LINE],
-                w[FW_TRUE_S * FLOW_LINE], w[(FW_TRUE_S + 1) * FLOW_LINE], w[(FW_TRUE_S + 2) * FLOW_LINE], w[FW_PENDING * FLOW_LINE] + (uint32_t)((size_t)capacity * alloc_batch), w[FW_ERROR * FLOW_LINE],
-                w[FW_TAIL * FLOW_LINE], w[(FW_TAIL + 1) * FLOW_LINE], w[(FW_TAIL + 2) * FLOW_LINE], w[(FW_TAIL + 3) * FLOW_LINE], w[(FW_TAIL + 4) * FLOW_LINE],
-                w[FW_HEAD * FLOW_LINE], w[(FW_HEAD + 1) * FLOW_LINE], w[(FW_HEAD + 2) * FLOW_LINE], w[(FW_HEAD + 3) * FLOW_LINE], w[(FW_HEAD + 4) * FLOW_LINE]);
-        fprintf(stderr, "flow claims: %.0f calls, %.0f descriptors, %.1f ms in successful claims, %.1f ms in contested ones\n", W(11), W(15), W(0) * 1e-5, W(2) * 1e-5);
-        fprintf(stderr, "flow stats (lane 0, last pass): waves %.0f, wave time %.1f ms: traversal sessions %.1f (%.0f sessions, %.0f bounce rays, %.0f shadow rays), shade %.1f (%.0f sessions, %.0f rays), publish %.1f, idle %.1f (%.0f polls)\n",
-                W(14), W(7) * 1e-5, W(1) * 1e-5, W(10), W(8), W(9), W(3) * 1e-5, W(13), W(12), W(6) * 1e-5, W(4) * 1e-5, W(5));
-    }
-#endif
     if (int rc = check_bounds_record()) return rc;
     { uint64_t done = 0; if (int rc = poll_completed(&done)) return rc; }
     if (pending_timing) {
@@ -1773,7 +1528,6 @@ int Renderer::stats(MRTRenderStats *out) {
     unsigned long long t[4];
     MRT_HIP(hipMemcpy(t, totals.p, sizeof t, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
-    if (t[3] != 0) { set_error("flow: " + std::to_string(t[3]) + " pass(es) ended with rays left in their queues"); return MRT_ERR_STATE; }
     out->frames = frames_rendered; out->closest_rays = t[0]; out->shadow_rays = t[1]; out->primary_rays = t[2];
     // 96 B per closest ray, 72 B per shadow ray, 36 B per pixel (20 on frame 0), + one read of the scene per frame
     uint64_t px = owned_pixels;
@@ -1797,7 +1551,7 @@ int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays,
     DevBuf<MRTRay> d_r; DevBuf<MRTIntersection> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_closest<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_closest<true>, dim3(cdiv(n, 64)), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     else hipLaunchKernelGGL(k_query_closest<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * sizeof(MRTIntersection), hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
@@ -1809,7 +1563,7 @@ int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, siz
     DevBuf<MRTRay> d_r; DevBuf<int32_t> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_any<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_any<true>, dim3(cdiv(n, 64)), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     else hipLaunchKernelGGL(k_query_any<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, d_o.p);
     MRT_HIP(hipMemcpyAsync(out, d_o.p, n * 4, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
@@ -1822,7 +1576,7 @@ int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, s
     DevBuf<MRTRay> d_r; DevBuf<uint32_t> d_o;
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * n));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_stats<true>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
+    if (sc.num_wnodes) hipLaunchKernelGGL(k_query_stats<true>, dim3(cdiv(n, 64)), dim3(64), (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
     else hipLaunchKernelGGL(k_query_stats<false>, dim3(cdiv(n, 64)), dim3(64), 0, stream, sc.view(), d_r.p, (uint32_t)n, any, d_o.p);
     MRT_HIP(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));

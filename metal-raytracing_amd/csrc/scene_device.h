@@ -49,7 +49,8 @@ constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wi
 #define MRT_WPACKET_STRIDE 3
 #endif
 constexpr uint32_t WPK = MRT_WPACKET_STRIDE;          // float4 units between the triangle packets of the 8-wide layout (3 = packed 48 B; 4 = one 64-byte sector each, never straddling two)
-constexpr int WIDE_STACK = 16;   // LDS traversal stack entries per lane = max wide-tree depth supported
+constexpr int WIDE_STACK_MAX = 64;   // deepest 8-wide tree the traversal kernels walk: their LDS stack is sized per launch from the scene's depth (320 B per wave and level: 4.2 KB at DragonScene's 13
+                                     // levels, 7.7 KB at 24 — five instead of six waves per SIMD —, 20 KB at 64); a deeper tree (a chain of nested triangles) keeps the rope layout, and MRTSceneStats::wide_layout says so
 constexpr int WIDE_STACK_TWO_LEVEL = 30;   // two-level scenes: TLAS levels + 1 (the TLAS group parked at instance entry) + the deepest BLAS; 5-bit depth fields
 constexpr uint32_t WIDE_WORLD_RAY_BYTES = 6 * 64 * 4;   // two-level stream traversal: the world-space ray of every lane (o.xyz, d.xyz) parked in LDS in front of the stack
 constexpr uint32_t WIDE_STACK_LEVEL_BYTES = 320;   // per wave and level: 64 x 4 B {child_base << 8 | hit bits} + 64 x 1 B {imask}
@@ -151,6 +152,23 @@ template <class T> struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// Pinned host memory that only grows: the staging area of a scene's uploads.  A commit concatenates the caller's arrays straight into it (one pass, no zero fill)
+// and the copies to the device are DMA from pinned pages; it stays with the scene, so the commits of an animated scene pay no allocation.
+struct PinnedBuf {
+    void *p = nullptr; size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+};
+
 struct HostMesh {                  // what the caller handed over through mrt_scene_add_mesh / _add_submesh / _add_instance
     int source = -1;               // >= 0: an instance of that mesh (shares its vertex arrays, submeshes and materials; its own arrays stay empty)
     std::vector<float> positions;  // packed xyz, object space
@@ -195,6 +213,7 @@ struct DeviceScene {
     std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each
     float tlas_ms = 0;                                         // host + upload time of the last TLAS build
     bool validate = true, validated_blas = false;              // commit-time index validation (two_level.hip validate_layout); BLAS part already checked
+    PinnedBuf stage;                                           // upload staging of build_flat (grow-only, reused by every commit of this scene)
     SceneView view() const;
 };
 
@@ -206,7 +225,7 @@ int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hi
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
 void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched

@@ -19,34 +19,16 @@
 namespace mrt {
 namespace {
 
-typedef float float2v __attribute__((ext_vector_type(2)));
 // Compile-time switches kept for A/B builds (tools/build_variant.sh); the defaults are the measured best.
-#ifndef MRT_WIDE_NODE_MIN
-#define MRT_WIDE_NODE_MIN 0   // > 0: take the node branch only when this many lanes want it (-2 % for every value tried)
-#endif
-#ifndef MRT_WIDE_DUAL_TRI
-#define MRT_WIDE_DUAL_TRI 0   // measured: trace launches 13 % shorter, frame rate -1.5 % — the frame is bound by VALU issue in aggregate, and this adds instructions
-#endif
-#ifndef MRT_WIDE_PK_FMA
-#define MRT_WIDE_PK_FMA 0   // v_pk_fma_f32 plane evaluation: -1.5 ... -2.6 % (no spills at 72 VGPRs either: the packed form is not cheaper to issue here)
-#endif
-#ifndef MRT_WIDE_FLAT_HITS
-#define MRT_WIDE_FLAT_HITS 1   // hit children recorded without an inner node/leaf branch: +0.8 % / +1.8 %
-#endif
+// (measured and removed, DESIGN.md §6: packed-FMA plane evaluation, two triangles per iteration, a lane quorum for the node branch, an inner / leaf branch per hit child)
 #ifndef MRT_WIDE_SCALED
 #define MRT_WIDE_SCALED 1   // stream kernels: box distances in units of the ray's limit, interval ends from the clamp modifier (wide_node_test<true>)
 #endif
 #ifndef MRT_WIDE_SPEC
 #define MRT_WIDE_SPEC 1     // flattened scenes: a lane that still has triangles to test visits its next node anyway and keeps that node's triangles in a second group (below)
 #endif
-#ifndef MRT_WIDE_DUAL_TRI_TWO_LEVEL
-#define MRT_WIDE_DUAL_TRI_TWO_LEVEL 0     // two-level scenes: two pending triangles per iteration (a two-triangle wall or floor instance then costs one iteration instead of two)
-#endif
 #ifndef MRT_WIDE_SPEC_TWO_LEVEL
 #define MRT_WIDE_SPEC_TWO_LEVEL 0     // the same inside the BLASes of two-level scenes: measured twice, no gain
-#endif
-#if MRT_WIDE_DUAL_TRI && MRT_WIDE_SPEC
-#error "MRT_WIDE_DUAL_TRI predates the second triangle group of MRT_WIDE_SPEC and is wrong with it (it consumes the first group behind the node test's back): build with -DMRT_WIDE_SPEC=0"
 #endif
 #ifndef MRT_COOP_MODE
 #define MRT_COOP_MODE 3   // drain phase: idle lanes test the pending triangles of a straggler ray; bit 0 = any-hit owners, bit 1 = closest-hit owners (0 = off: A/B)
@@ -115,13 +97,6 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int w = i >> 2, k = i & 3;
-#if MRT_WIDE_PK_FMA        // near and far plane of an axis in one v_pk_fma_f32 (packed fp32 runs at twice the scalar rate)
-        const float2v px = __builtin_elementwise_fma(float2v{ubyte_f(nrx[w], k), ubyte_f(frx[w], k)}, float2v{ax, ax}, float2v{bx, bx});
-        const float2v py = __builtin_elementwise_fma(float2v{ubyte_f(nry[w], k), ubyte_f(fry[w], k)}, float2v{ay, ay}, float2v{by, by});
-        const float2v pz = __builtin_elementwise_fma(float2v{ubyte_f(nrz[w], k), ubyte_f(frz[w], k)}, float2v{az, az}, float2v{bz, bz});
-        const float tn = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, tmin));
-        const float tf = fminf(fminf(fminf(px.y, py.y), pz.y) * 1.0000005f, tmax);
-#else
         float tn, tf;
         if (SCALED) {
             tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[w], k), ax, bx), __builtin_fmaf(ubyte_f(nry[w], k), ay, by)),
@@ -134,15 +109,10 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
             tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[w], k), ax, bx), __builtin_fmaf(ubyte_f(fry[w], k), ay, by)),
                              __builtin_fmaf(ubyte_f(frz[w], k), az, bz)) * 1.0000005f, tmax);
         }
-#endif
         if (SCALED ? tn < tf : tn <= tf) {
-#if MRT_WIDE_FLAT_HITS      // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
+            // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
             nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
             th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
-#else
-            if ((imask >> i) & 1u) nh |= 1u << ((uint32_t)i ^ oct);
-            else { const uint32_t m = (meta[w] >> (8 * k)) & 0xFFu; th |= ((1u << (m >> 5)) - 1u) << (m & 31u); }
-#endif
         }
     }
     node_hits = nh; tri_hits = th;
@@ -211,6 +181,80 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
         }
     }
     return h.gid != 0xFFFFFFFFu;
+}
+
+// One ray per lane on the 8-wide layout, closest hit, the stream loop's iteration (node and triangle fetched in one round trip, scaled box test) without
+// refill: for COHERENT rays — the primary rays of an 8x8 tile, traced inside k_shade<.., TRACE0 = 2> — whose lanes stay in step by themselves.
+// SEED: `seed_pk` is a packet the caller has already tested (distance in tmax); the walk starts with it as its closest hit.  h.pk = packet of the final hit.
+template <bool SEED>
+MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */) {
+    const uint32_t lane = threadIdx.x & 63;
+    const float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
+    const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    float best_t = tmax; uint32_t best_pk = SEED ? seed_pk : 0xFFFFFFFFu;
+    uint32_t g_base = 0, g_mask = s.num_wnodes != 0 ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
+    for (;;) {
+        const bool has_tri = t_mask != 0;
+        const uint32_t t_rest = t_mask & (t_mask - 1u);
+        bool want_node = t_rest == 0u;
+        uint32_t pending = 0;
+        if (want_node) {
+            if ((g_mask & 0xFF00u) == 0) {
+                const uint32_t sp = g_mask >> 16;
+                if (sp == 0) { want_node = false; if (!has_tri) break; }
+                else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
+            }
+            if (want_node) {
+                const uint32_t hits = (g_mask >> 8) & 0xFFu;
+                const uint32_t b = (uint32_t)__ffs((int)hits) - 1u;       // nearest remaining child in (slot ^ octant) order
+                g_mask &= ~(0x100u << b);
+                const uint32_t slot = b ^ oct;
+                pending = g_base + (uint32_t)__popc(g_mask & 0xFFu & ((1u << slot) - 1u));
+            }
+        }
+        float4 r0, r1, r2, n0, n1, n2, n3, n4;
+        asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r2.x), "=v"(r2.y), "=v"(r2.z));
+        asm volatile("" : "=v"(n0.x), "=v"(n0.y), "=v"(n0.z), "=v"(n0.w), "=v"(n1.x), "=v"(n1.y), "=v"(n1.z), "=v"(n1.w), "=v"(n2.x), "=v"(n2.y), "=v"(n2.z), "=v"(n2.w));
+        asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
+        r1.w = 0.0f; r2.w = 0.0f;
+        uint32_t tri_pk = 0;
+        if (has_tri) {
+            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u; t_mask = t_rest;
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
+            r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
+        }
+        if (want_node) {
+            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+        }
+        if (has_tri) {
+            float t, U, V, ad;
+            if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
+                bool better = t < best_t || best_pk == 0xFFFFFFFFu;
+                if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);      // t == best_t: ties go to the lowest id
+                if (better) { best_t = t; best_pk = tri_pk; }
+            }
+        }
+        if (want_node) {
+            uint32_t node_hits, tri_hits;
+            wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            uint32_t sp = g_mask >> 16;
+            if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
+            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            t_base = __float_as_uint(n1.y); t_mask = tri_hits;
+        }
+        else if (t_rest == 0u) break;        // no node left and this was the last pending triangle
+    }
+    h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = best_pk;
+    if (best_pk == 0xFFFFFFFFu) return false;
+    // id and barycentrics of the winning triangle: recomputed (same arithmetic) instead of living in four registers through the loop
+    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
+    const float4 q0 = pk[0];
+    float t_;
+    (void)tri_test(q0, pk[1], pk[2], o, d, 0.0f, __builtin_inff(), t_, h.U, h.V, h.ad);
+    h.gid = __float_as_uint(q0.w);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,15 +468,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         bool has_tri = live && t_mask != 0 && !has_inst;
         uint32_t t_rest = t_mask & (t_mask - 1u);               // triangles left after this iteration's first one
         bool want_node = live && (t_rest == 0u || (SPEC && u_mask == 0u && (!TWO_LEVEL || in_blas))) && !has_inst;      // a place for the node's triangles after this iteration's test
-#if MRT_WIDE_NODE_MIN > 0       // experiment: take the (expensive) node branch only when enough lanes want it, or nobody has triangles to chew on
-        {
-            const uint32_t n_want = (uint32_t)__popcll(__ballot(want_node)), n_busy = (uint32_t)__popcll(__ballot(live && t_rest != 0u));
-            if (n_busy != 0u && n_want < (uint32_t)MRT_WIDE_NODE_MIN) want_node = false;
-        }
-#endif
-        constexpr bool DUAL = (TWO_LEVEL ? MRT_WIDE_DUAL_TRI_TWO_LEVEL : MRT_WIDE_DUAL_TRI) != 0;
-        bool has_tri2 = DUAL && has_tri && t_rest != 0u && !want_node;      // two or more pending: test two this iteration (the node registers carry the second packet)
-        uint32_t pending = 0, tri_pk = 0, tri_pk2 = 0;
+        uint32_t pending = 0, tri_pk = 0;
         bool last_step = false;         // flattened scenes: nothing but this iteration's triangle is left of the ray — it is finished when the test is done
         if (TWO_LEVEL && has_inst) {
             // enter the next instance of the TLAS leaf: park the TLAS group (always, also without siblings left: the exit pops it), take the ray
@@ -454,7 +490,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             t_base = 0; t_mask = 0;
             insts = (insts & 0xFFFF0000u) | id;
             if (I.ntri <= 8u) {          // a BLAS of a few triangles (a wall, a floor): no node to test, its packets are the pending set, the first one is tested now
-                t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true; has_tri2 = DUAL && t_rest != 0u;
+                t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true;
             } else { pending = I.wroot; want_node = true; }
         }
         else if (want_node) {
@@ -493,12 +529,6 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
             r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
         }
-        if (has_tri2) {
-            tri_pk2 = t_base + (uint32_t)__ffs((int)t_rest) - 1u;
-            t_mask = t_rest & (t_rest - 1u);
-            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk2;
-            n0 = pk[0]; n1 = pk[1]; n2 = pk[2];
-        }
         if (want_node) {
             MRT_BOUND(pending, s.num_wnodes, 1);
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
@@ -519,7 +549,6 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         };
         if (has_tri) consider(r0, r1, r2, tri_pk);
-        if (has_tri2 && live) consider(n0, n1, n2, tri_pk2);
         if (owner >= 0) {                                        // wave-uniform
             float h_t = 0.0f; bool h_hit = false;
             if (helping) { float U_, V_, ad_; h_hit = tri_test(r0, r1, r2, o, d, 0.0f, best_t, h_t, U_, V_, ad_); }

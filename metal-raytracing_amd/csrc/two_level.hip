@@ -406,7 +406,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     for (size_t b = 0; b < B; b++) {
         const HostMesh &g = meshes[blas_src[b]];
         std::vector<MeshRef> one{MeshRef{&g, identity}};
-        int rc = build_flat(one, opt, stream, blas[b]); if (rc) return rc;
+        int rc = build_flat(one, opt, stream, blas[b], &out.stage); if (rc) return rc;
         node_base[b] = (uint32_t)nodes_total; packet_base[b] = (uint32_t)packets_total; ts_base[b] = (uint32_t)ts_total; vbase[b] = (uint32_t)V_total;
         ntri[b] = (uint32_t)blas[b].stats.triangles;
         wnode_base[b] = (uint32_t)wnodes_total; wnodes_total += blas[b].num_wnodes;

@@ -182,12 +182,17 @@ class Renderer:
         check(lib.mrt_renderer_frames_completed(self.handle, C.byref(v)))
         return v.value
 
+    # the host's knobs (include/mrt_abi.h mrt_renderer_set_option); every other key is one of the library's A/B switches (mrt_debug_renderer_set_option: tests, tools/, bench.py --opt)
+    PUBLIC_OPTIONS = ("max_bounces", "frames_in_flight", "sample_offset", "frame_batch", "megakernel", "materials", "lanes_used", "lane_bytes")
+
     def set_option(self, key, value):
-        check(lib.mrt_renderer_set_option(self.handle, key.encode(), float(value)))
+        fn = lib.mrt_renderer_set_option if key in self.PUBLIC_OPTIONS else lib.mrt_debug_renderer_set_option
+        check(fn(self.handle, key.encode(), float(value)))
 
     def get_option(self, key):
         v = C.c_double(0.0)
-        check(lib.mrt_renderer_get_option(self.handle, key.encode(), C.byref(v)))
+        fn = lib.mrt_renderer_get_option if key in self.PUBLIC_OPTIONS else lib.mrt_debug_renderer_get_option
+        check(fn(self.handle, key.encode(), C.byref(v)))
         return v.value
 
     def set_shard(self, rank, world):
@@ -320,12 +325,18 @@ class GroupRenderer:
         check(lib.mrt_group_set_reduce_mode(self.group, int(mode)))
 
     def set_option(self, key, value):
-        check(lib.mrt_group_set_option(self.handle, key.encode(), float(value)))
+        if key in Renderer.PUBLIC_OPTIONS:
+            check(lib.mrt_group_set_option(self.handle, key.encode(), float(value)))
+            return
+        for rank in range(self.world):                       # an A/B switch: through every device's renderer
+            r = C.c_void_p()
+            check(lib.mrt_group_renderer_rank(self.handle, rank, C.byref(r)))
+            check(lib.mrt_debug_renderer_set_option(r, key.encode(), float(value)))
 
     def rank_option(self, rank, key):
         r = C.c_void_p(); v = C.c_double()
         check(lib.mrt_group_renderer_rank(self.handle, int(rank), C.byref(r)))
-        check(lib.mrt_renderer_get_option(r, key.encode(), C.byref(v)))
+        check(lib.mrt_debug_renderer_get_option(r, key.encode(), C.byref(v)))
         return v.value
 
     def draw(self, frames=1, wait=False):

@@ -20,7 +20,7 @@ ORACLE_BUILD = "-O3 -march=native" if ORACLE_NATIVE else "-O2 -march=x86-64-v3"
 def build_oracle(force=False):
     src = os.path.join(ORACLE_DIR, "mrt_oracle.cpp")
     if force or not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["native"] if ORACLE_NATIVE else []))
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["-B"] if force else []) + (["native"] if ORACLE_NATIVE else []))      # force: really recompile (-march=native is only valid on the box that compiled it)
     return ORACLE_LIB
 
 

@@ -1,6 +1,11 @@
 """What one rank of an N-GPU tile-sharded run does, measured on ONE GPU: rank 0 of world N renders its 1/N of the 8x8 tiles for
 `steps` frames (the collective is not part of this probe).  Prints wall time, the aggregate rate N ranks would reach if all took
-this long, and the efficiency against the 1-GPU run — for several pass shapes (frame_batch)."""
+this long, and the efficiency against the 1-GPU run — for several pass shapes (frame_batch), or for the pass size the sharded
+renderers themselves choose (`--batches auto`: distributed.py / group.hip: min(32, 8 x world), at most a third of the run).
+
+    python tools/tile_scaling_probe.py --scene garden --width 3840 --height 2160 --batches auto --steps 20      # BASELINE config C4
+    python tools/tile_scaling_probe.py --scene dragon4 --batches auto --steps 16                              # BASELINE config C5 (spp 16)
+"""
 import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,26 +14,38 @@ import metal_raytracing_amd as mrt
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--worlds", default="1,2,4,8"); ap.add_argument("--batches", default="1,2,4,8,16,32")
-ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable), e.g. flow=1")
+ap.add_argument("--scene", default="dragon", choices=sorted(mrt.SCENES)); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--bounces", type=int, default=3)
+ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
+ap.add_argument("--sopt", action="append", default=[], help="scene option key=value (repeatable), e.g. instancing=1")
 a = ap.parse_args()
-w, h = 1920, 1080
-scene = mrt.DragonScene((w, h))
+w, h = a.width, a.height
+scene = mrt.SCENES[a.scene]((w, h))
+sopts = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in a.sopt}
+ctx = mrt.Context(0)
 base = None
+print(f"# {a.scene} {w}x{h}, {a.bounces} bounces, {a.steps} timed frames after {a.warmup}; rank 0 of N on one GPU, no collective; best of 3", flush=True)
 for world in [int(x) for x in a.worlds.split(",")]:
-    for fb in [int(x) for x in a.batches.split(",")]:
-        r = mrt.Renderer((w, h), scene, seed=1)
+    batches = ["auto"] if a.batches == "auto" else [int(x) for x in a.batches.split(",")]
+    for fb in batches:
+        r = mrt.Renderer((w, h), scene, ctx=ctx, seed=1, max_bounces=a.bounces, scene_options=sopts)
         if world > 1: r.set_shard(0, world)
-        r.set_option("frame_batch", fb)
+        if fb == "auto":
+            d = int(r.get_option("frame_batch"))
+            fb_used = d if world == 1 else min(min(32, d * world), max(d, (a.warmup + a.steps) // 3))      # distributed.py ShardedRenderer
+        else:
+            fb_used = fb
+        r.set_option("frame_batch", fb_used)
         for kv in a.opt:
             k, v = kv.split("="); r.set_option(k, float(v))
-        best = None
+        best, best_dt = None, None
         for rep in range(3):
             r.draw(a.warmup); r.wait(); r.reset_stats()
             t0 = time.perf_counter(); r.draw(a.steps); r.wait(); dt = time.perf_counter() - t0
             st = r.stats
             rate = (st.closest_rays + st.shadow_rays) / dt / 1e6
-            best = max(best or 0.0, rate)
+            if best is None or rate > best: best, best_dt = rate, dt
         if world == 1: base = max(base or 0.0, best)
         if base is None: base = float('nan')
-        print(f"world {world} frame_batch {fb:2d}: rank rate {best:8.1f} Mrays/s  x{world} = {best * world:8.1f}  efficiency vs best 1-GPU {best * world / base:5.2f}", flush=True)
+        print(f"world {world} frame_batch {fb_used:2d}: rank time {best_dt * 1e3:7.2f} ms  rank rate {best:8.1f} Mrays/s  x{world} = {best * world:8.1f}  efficiency vs best 1-GPU {best * world / base:5.2f}", flush=True)
         r.close()
