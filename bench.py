@@ -229,25 +229,37 @@ def main_group(a):
     g.close()
 
 
+def launch_plan(gpus_arg, steps, warmup, shard, env, ndev):
+    """What one process of a bench run does, from its arguments and environment alone (no GPU touched; tests/test_bench_contract.py checks it against DESIGN.md §7):
+    torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK and those win over --gpus; without them --gpus N > 1 means ONE process driving N devices through
+    the C ABI's device group.  Tile sharding: the rank's frame_batch and the passes its warm-up and timed draws split into."""
+    from metal_raytracing_amd.distributed import shard_frame_batch, pass_sizes
+    world = int(env.get("WORLD_SIZE", "1")); rank = int(env.get("RANK", "0")); local_rank = int(env.get("LOCAL_RANK", "0"))
+    plan = {"world": world, "rank": rank, "mode": "ranks" if world > 1 else ("group" if gpus_arg > 1 else "single"), "gpus": world if world > 1 else gpus_arg,
+            "device": local_rank % max(1, ndev)}                                  # more ranks than GPUs: a gloo rehearsal on one box
+    n = plan["gpus"]
+    fb = shard_frame_batch(n, warmup + steps) if shard == "tile" else shard_frame_batch(1)
+    if plan["mode"] == "group":
+        fb = shard_frame_batch(n)                                                 # mrt_group_renderer_create knows no run length; Renderer::render caps every draw itself
+    plan.update(frame_batch=fb, warmup_passes=pass_sizes(warmup, fb) if warmup else [], timed_passes=pass_sizes(steps, fb))
+    return plan
+
+
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        a.gpus = world
+    plan = launch_plan(a.gpus, a.steps, a.warmup, a.shard, os.environ, torch.cuda.device_count())
+    world, rank, local_rank = plan["world"], plan["rank"], plan["device"]
+    a.gpus = plan["gpus"]
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = max(1, torch.cuda.device_count())
-        local_rank = local_rank % ndev                      # rehearsal with more ranks than GPUs (gloo only)
         torch.cuda.set_device(local_rank)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif a.gpus > 1:
+    elif plan["mode"] == "group":
         return main_group(a)             # one process, N devices: the C ABI's device group (mrt_group_*), no torch.distributed
 
     oracle_note = prebuild_oracle() if (world == 1 and not a.no_cpu_baseline) else None
@@ -345,7 +357,7 @@ def main():
                        "bvh_build_ms": round(sst.build_ms, 3), "bvh_build_mtris_per_s": round(sst.triangles / max(sst.build_ms, 1e-6) / 1e3, 1), "sah_cost": round(sst.sah_cost, 3),
                        "rays_per_frame": {"closest": closest / steps_total, "shadow": shadow / steps_total, "primary": primary / steps_total},
                        "shard": a.shard if world > 1 else "none", "frames_total": steps_total,
-                       "frame_batch": frame_batch, "frames_in_flight": int(r.get_option("frames_in_flight")), "lanes_used": int(r.get_option("lanes_used")),
+                       "frame_batch": frame_batch, "passes_of_timed_draw": plan["timed_passes"], "frames_in_flight": int(r.get_option("frames_in_flight")), "lanes_used": int(r.get_option("lanes_used")),
                        "lane_bytes": int(r.get_option("lane_bytes")), "persistent_traversal": int(r.get_option("persistent")),
                        "ms_per_step_is": "wall time of the timed region / steps with passes of frame_batch frames overlapped on frames_in_flight streams (inverse throughput); the per-frame device time is latency.ms_per_frame",
                        "device": r.ctx.device_name},

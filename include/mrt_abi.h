@@ -338,6 +338,9 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
 int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, MRTIntersection *out);
 /* Diagnostics: fill of the 8-wide nodes: out12[c] = nodes with c children (c = 0..8), [9] internal children, [10] leaf children, [11] triangles. */
 int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
+/* Diagnostics: host wall time (ms) of the last mrt_scene_commit of a flattened scene by phase: {upload staging, device allocations + upload enqueue,
+ * topology (flatten .. refit, with its read-backs), 8-wide emit, rope emit, validation}.                                                              */
+int mrt_debug_commit_times(MRTScene scene, double *out6);
 /* The index validation mrt_scene_commit runs (scene option "validate", default 1): every child / packet / instance index of the committed
  * 8-wide layout, the instance rows and the TLAS lies inside its array and children come after their parents; MRT_ERR_STATE + message
  * otherwise.  mrt_debug_poke_wnode overwrites one 32-bit word (0..19) of one 8-wide node — for the validator's own test only.            */

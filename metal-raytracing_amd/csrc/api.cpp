@@ -173,6 +173,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "cost_trav") scene->opt.cost_trav = (float)value;
     else if (k == "cost_isect") scene->opt.cost_isect = (float)value;
     else if (k == "wide") scene->opt.wide = (int)value;
+    else if (k == "rope") { REQUIRE(value == 0 || value == 1, "rope must be 0 (the rope layout only for scenes without the 8-wide one) or 1 (always)"); scene->opt.rope = (int)value; }
     else if (k == "presplit") { REQUIRE(value >= 0, "presplit must be >= 0 (0 = off; k: triangles longer than k x the mean extent are split into references)"); scene->opt.presplit = (float)value; }
     else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
@@ -611,6 +612,12 @@ int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12) {
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::wide_histogram(scene->dev, scene->ctx->stream, out12);
     MRT_CATCH
+}
+// host wall time of the last commit of a flattened scene by phase (ms): staging, device allocations, topology, 8-wide emit, rope emit, validation
+int mrt_debug_commit_times(MRTScene scene, double *out6) {
+    REQUIRE(scene && out6, "mrt_debug_commit_times: bad argument");
+    for (int k = 0; k < 6; k++) out6[k] = scene->dev.commit_ms[k];
+    return MRT_OK;
 }
 // the commit-time validator on demand, and a way for its test to break one word of one 8-wide node (tests/test_instancing.py)
 int mrt_debug_validate(MRTScene scene) {

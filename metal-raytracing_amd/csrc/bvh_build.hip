@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cmath>
+#include <chrono>
 
 namespace mrt {
 namespace {
@@ -914,7 +915,7 @@ SceneView DeviceScene::view() const {
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / WPK) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
     v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
-    v.num_nodes = (uint32_t)stats.bvh_nodes; v.num_tris = num_packets;      // entries of `packets` (>= triangles when long triangles were pre-split into references)
+    v.num_nodes = rope_nodes; v.num_tris = num_packets;      // entries of `packets` (>= triangles when long triangles were pre-split into references)
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
 }
@@ -971,7 +972,10 @@ int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt,
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
     if (int rc = build_flat(refs, opt, stream, out)) return rc;
-    return out.validate ? validate_layout(out, stream, false) : MRT_OK;
+    const auto tv = std::chrono::steady_clock::now();
+    const int rc = out.validate ? validate_layout(out, stream, false) : MRT_OK;
+    out.commit_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
+    return rc;
 }
 
 // One world-space BVH over the given (geometry, transform) pairs: the whole flattened scene, or one BLAS (a single mesh under the identity).
@@ -988,7 +992,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     }
     const size_t I = meshes.size();
     if (V >= 0xFFFFFFF0ull || I >= 65536 || max_sub >= 65536) { set_error("scene too large (limits: 2^32 - 16 vertices, 65535 instances / submeshes)"); return MRT_ERR_UNSUPPORTED; }
-    if (int rc = layout_limits(T, 0)) return rc;                // before any device work: what no tree of T triangles can satisfy
+    if (T >= (1ull << 26)) { set_error("scene too large: the builder supports fewer than 2^26 triangles"); return MRT_ERR_UNSUPPORTED; }
+    const auto tw0 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    for (double &c : out.commit_ms) c = 0.0;
     // one pinned staging area for everything that goes up (positions, normals as float4, indices, the small tables): filled in ONE pass straight from the caller's
     // arrays (no zero-filled intermediate vectors), copied to the device by DMA from pinned pages.  DragonScene: 24 MB; the pageable path took 4 of the commit's 8.4 ms.
     const size_t slots = std::max<size_t>(I * max_sub, 1);
@@ -1029,6 +1036,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.stats = MRTSceneStats{};
     out.stats.triangles = T; out.stats.vertices = V; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub;
     out.stats.max_leaf_tris = opt.max_leaf;
+    out.commit_ms[0] = since(tw0);
+    const auto tw1 = std::chrono::steady_clock::now();
 
     MRT_HIP(out.normals.alloc(n_nrm));
     MRT_HIP(out.base_color.alloc(slots)); MRT_HIP(out.materials.alloc(3 * slots));
@@ -1045,13 +1054,14 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(out.nodes.alloc(8)); out.packets_offset = 4;
         MRT_HIP(hipStreamSynchronize(stream));
         out.stats.bvh_nodes = 0; out.stats.bvh_leaves = 0; out.num_packets = 0;
+        out.rope_nodes = 0; out.num_wnodes = 0; out.wide_depth = 0; out.wnodes.release(); out.wpackets.release();
         out.stats.scene_bytes = 0;
         return MRT_OK;
     }
 
     const uint32_t T32 = (uint32_t)T;
     ScratchArena arena;                                          // before the buffers that borrow from it
-    arena.chunk_bytes = ((size_t)T * (576 + (opt.wide && opt.max_leaf <= 4 ? 16 * WNODE_STRIDE : 0)) + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle + the 8-wide nodes' scratch): one allocation, more if pre-splitting adds references
+    arena.chunk_bytes = ((size_t)T * (576 + 48 + (opt.wide && opt.max_leaf <= 4 ? 16 * WNODE_STRIDE : 0)) + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle + the 8-wide nodes' scratch): one allocation, more if pre-splitting adds references
     DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
     DevBuf<float4> tri_world, tri_lo, tri_hi, ref_lo, ref_hi, node_lo, node_hi;
     DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat, ref_tri;
@@ -1079,6 +1089,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(hipMemsetAsync(stat.p, 0xFF, stat.bytes(), stream));       // [0] depth and [1] leaves are cleared below; [2] = root stays NONE until k_assign finds it
     MRT_HIP(hipMemsetAsync(stat.p, 0, 8, stream));
     const int B = 256;
+    out.commit_ms[1] = since(tw1);
+    const auto tw2 = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs.p, (int)nrec, d_pos.p, d_idx.p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
@@ -1113,7 +1125,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         }
     }
     out.num_packets = n;
-    if (int rc = layout_limits(n, 0)) return rc;
+    if (n >= (1u << 26)) { set_error("scene too large: the builder supports fewer than 2^26 references"); return MRT_ERR_UNSUPPORTED; }
     const uint32_t nnodes = 2 * n - 1;
     const uint32_t leaf_base = n - 1;
     MRT_HIP(node_lo.alloc_in(arena, nnodes)); MRT_HIP(node_hi.alloc_in(arena, nnodes));
@@ -1205,13 +1217,9 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
                        dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, 1024)), dim3(1024), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
-    // surviving node count = size[root]; root = the node whose parent is NONE. For Karras and n==1 it is id 0;
-    // for PLOC read it back through new_index == 0.  We over-allocate nodes to nnodes and trim the count.
-    // one allocation: [nodes (worst case 2n-1) | packets], so the traversal addresses both from one base
-    MRT_HIP(out.nodes.alloc(4 * (size_t)nnodes + 3 * (size_t)n));
-    float4 *const packets_p = out.nodes.p + 4 * (size_t)nnodes;
-    out.packets_offset = 4 * (size_t)nnodes;
-    hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, out.nodes.p);
+    // the triangle packets in the leaf order of the binary tree (scratch): the source of the 8-wide layout's packets, and of the rope layout's when that one is emitted too
+    DevBuf<float4> pk_tmp; MRT_HIP(pk_tmp.alloc_in(arena, 3 * (size_t)n));
+    float4 *const packets_p = pk_tmp.p;
     hipLaunchKernelGGL(k_emit_packets, dim3(cdiv(n, B)), dim3(B), 0, stream, vin, leaf_offset.p, leaf_base, n, tri_world.p, ref_tri_p, packets_p);
     // ---- stats: the root (k_assign found it), its size, cost and box, depth and leaf count in one small read-back
     DevBuf<uint32_t> summary; MRT_HIP(summary.alloc_in(arena, 12));
@@ -1227,17 +1235,18 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const uint32_t h_size = h_sum[1]; const uint32_t h_stat[2] = {h_sum[3], h_sum[4]};
     float h_cost; memcpy(&h_cost, &h_sum[2], 4);
     float4 rlo, rhi; memcpy(&rlo.x, &h_sum[6], 12); memcpy(&rhi.x, &h_sum[9], 12);
-    if (int rc = layout_limits(T, h_size)) return rc;           // the surviving node count must fit the 24-bit child index
     float dx = rhi.x - rlo.x, dy = rhi.y - rlo.y, dz = rhi.z - rlo.z;
     float area = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.root_lo[0] = rlo.x; out.root_lo[1] = rlo.y; out.root_lo[2] = rlo.z; out.root_hi[0] = rhi.x; out.root_hi[1] = rhi.y; out.root_hi[2] = rhi.z;
-    out.stats.bvh_nodes = h_size; out.rope_nodes = h_size;
+    out.stats.bvh_nodes = h_size; out.rope_nodes = 0;
     out.stats.bvh_leaves = h_stat[1];
     out.stats.max_depth = (int32_t)h_stat[0];
     out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;
     out.stats.build_ms = ms;
-    out.stats.scene_bytes = (uint64_t)h_size * 64 + (uint64_t)n * 48 + (uint64_t)T * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
+    out.stats.scene_bytes = (uint64_t)T * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
     out.num_wnodes = 0; out.wide_depth = 0;
+    out.commit_ms[2] = since(tw2);
+    const auto tw3 = std::chrono::steady_clock::now();
     // a wide node addresses its leaf triangles with a 32-bit mask: 8 leaf children x max_leaf triangles must fit
     if (opt.wide && opt.max_leaf <= 4) {
         // ---- 8-wide compressed layout, level by level (BFS numbering)
@@ -1283,7 +1292,30 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;
+        if (!out.num_wnodes) { out.wnodes.release(); out.wpackets.release(); out.stats.scene_bytes -= (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48; }      // not usable: the rope layout below is what this scene gets
     }
+    // ---- the rope layout (64-byte binary nodes with escape links + a second copy of the packets): only for scenes without the 8-wide layout, or on request (scene option rope = 1:
+    // the A/B switches that walk it, the BLASes of a two-level scene).  Every ray of the default pipeline walks the 8-wide layout, so DragonScene keeps 48 instead of 148 MB of BVH.
+    out.commit_ms[3] = since(tw3);
+    const auto tw4 = std::chrono::steady_clock::now();
+    out.nodes.release(); out.packets_offset = 0;
+    if (opt.rope || !out.num_wnodes) {
+        if (int rc = layout_limits(n, h_size)) return rc;       // its 32-bit byte offsets and 24-bit child index bound the scene (about 24.4 M references)
+        MRT_HIP(hipEventRecord(ev0, stream));
+        // one allocation: [nodes | packets], so the traversal addresses both from one base
+        MRT_HIP(out.nodes.alloc(4 * (size_t)h_size + 3 * (size_t)n));
+        out.packets_offset = 4 * (size_t)h_size;
+        hipLaunchKernelGGL(k_emit_nodes, dim3(cdiv(nnodes, B)), dim3(B), 0, stream, t, nnodes, new_index.p, leaf_offset.p, out.nodes.p);
+        MRT_HIP(hipMemcpyAsync(out.nodes.p + out.packets_offset, packets_p, 3 * (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        MRT_HIP(hipEventRecord(ev1, stream));
+        MRT_HIP(hipStreamSynchronize(stream));
+        MRT_HIP(hipGetLastError());
+        float rms = 0; MRT_HIP(hipEventElapsedTime(&rms, ev0, ev1));
+        out.stats.build_ms += rms;
+        out.rope_nodes = h_size;
+        out.stats.scene_bytes += (uint64_t)h_size * 64 + (uint64_t)n * 48;
+    }
+    out.commit_ms[4] = since(tw4);
     return MRT_OK;
 }
 

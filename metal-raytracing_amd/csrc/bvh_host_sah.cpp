@@ -26,7 +26,6 @@ struct Builder {
     uint32_t n;
     std::vector<uint32_t> &order, &left, &right, &parent;
     std::vector<float> cx, cy, cz;          // centroids (2 x centre)
-    std::atomic<uint32_t> next_internal{0};
     static constexpr int BINS = 32;
 
     const float *cen(int a) const { return a == 0 ? cx.data() : a == 1 ? cy.data() : cz.data(); }
@@ -35,8 +34,6 @@ struct Builder {
     uint32_t build(uint32_t b, uint32_t e, uint32_t par, int depth, std::vector<std::thread> *pool) {
         const uint32_t cnt = e - b;
         if (cnt == 1) { const uint32_t id = n - 1 + b; parent[id] = par; return id; }
-        const uint32_t id = next_internal.fetch_add(1);
-        parent[id] = par;
         float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (uint32_t i = b; i < e; i++) {
             const uint32_t r = order[i];
@@ -95,12 +92,18 @@ struct Builder {
         if (!found) {                    // all centroids equal (or a failed partition): median split in the current order
             mid = b + cnt / 2;
         }
+        // the internal node that splits [b, e) between positions mid - 1 and mid is node mid - 1: every split position occurs once in the tree, so the ids are
+        // 0 .. n - 2 whatever the threads' timing (an atomic counter used to hand them out in arrival order: a different numbering from run to run)
+        const uint32_t id = mid - 1;
+        parent[id] = par;
         uint32_t l, r;
-        if (pool && depth < 6 && cnt > 4096) {       // the top of the tree fans out over threads
-            uint32_t lr = 0;
-            std::thread th([&, this] { lr = build(b, mid, id, depth + 1, nullptr); });
+        if (pool && depth < 6 && cnt > 4096) {       // the top of the tree fans out over threads: both halves keep fanning out, 2^6 threads at most
+            uint32_t lr = 0; bool spawned = false;
+            std::thread th;
+            try { th = std::thread([&, this] { lr = build(b, mid, id, depth + 1, pool); }); spawned = true; } catch (...) {}      // no thread to be had: this half is built here
+            struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{th};      // joined on every path out of this scope, also when the other half throws
             r = build(mid, e, id, depth + 1, pool);
-            th.join(); l = lr;
+            if (spawned) { th.join(); l = lr; } else l = build(b, mid, id, depth + 1, pool);
         } else { l = build(b, mid, id, depth + 1, pool); r = build(mid, e, id, depth + 1, pool); }
         left[id] = l; right[id] = r;
         return id;

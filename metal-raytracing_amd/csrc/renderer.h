@@ -57,7 +57,7 @@ struct Renderer {
     bool megakernel = false;             // one launch per frame (k_megakernel): lowest latency of a single frame; the wavefront pipeline has the higher throughput
     int mega_slots = 0; size_t mega_slots_for_stack = ~(size_t)0;
     bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
-    int primary_wide = 0;                // A/B switch: 1 = primary rays on the wide stream kernel (own launch) instead of inside shade(0)
+    int primary_wide = 2;                // primary rays of a flattened scene: 2 = one ray per lane on the 8-wide layout (inside shade(0) or in their own launch; default), 1 = the 8-wide stream kernel with lane refill (own launch), 0 = the rope walk (scene option rope = 1)
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)

@@ -105,7 +105,8 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
 //   k_trace_mixed   : one launch over two queues — the next-bounce rays (closest hit -> hit records) and the
 //                     shadow rays of the same shade pass (any hit -> sample accumulation).  The two kinds share
 //                     the loop; a shadow lane simply stops at its first hit.
-template <bool TWO_LEVEL>
+// WIDE (flattened scenes with the 8-wide layout): one ray per lane on that layout (traverse_wide_lane), the wave's stack in dynamic LDS; the hint then names a packet of wpackets
+template <bool TWO_LEVEL, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, float4 *__restrict__ hits, float4 *__restrict__ dirs, uint32_t *__restrict__ hint) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x, sub = blockIdx.y;      // grid = (local tiles, sub-frames of the batch)
     float4 *__restrict__ hits_s = hits + (size_t)sub * fp.capacity;
@@ -121,7 +122,23 @@ __global__ void __launch_bounds__(64) k_trace_primary(SceneView s, FrameParams f
     qstore(&dirs[(size_t)sub * fp.capacity + slot], make_float4(dir.x, dir.y, dir.z, __uint_as_float(sub * fp.capacity + slot)));
     TravHit h;
     bool hit;
-    if (!TWO_LEVEL && hint != nullptr) {
+    if (WIDE && !TWO_LEVEL) {
+        extern __shared__ uint32_t stk_dyn[];
+        if (hint != nullptr) {
+            const uint32_t pixel = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
+            const uint32_t guess = hint[pixel];
+            float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
+            if (guess < s.num_wpackets) {
+                const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
+                float t, U, V, ad;
+                if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+            }
+            hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk_dyn);
+            if (h.pk != guess) hint[pixel] = h.pk;
+        }
+        else hit = traverse_wide_lane<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk_dyn);
+    }
+    else if (!TWO_LEVEL && hint != nullptr) {
         // the triangle this pixel hit in an earlier frame is tested first: the jittered ray most often hits it again, and the walk then starts with
         // the right distance bound instead of discovering it.  Any packet is a legal guess (a wrong one is one wasted test); the result is unchanged.
         const uint32_t pixel = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
@@ -1349,8 +1366,13 @@ int Renderer::render(int n_frames) {                                   // Render
             // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
             // fuse_primary = 2 fuses always)
+            // which layout the primary rays of a flattened scene walk: the 8-wide one when the scene has it (primary_wide = 2, default: one ray per lane inside shade(0) or in its own launch;
+            // = 1: the stream kernel with lane refill, A/B), the rope layout otherwise — or on request (primary_wide = 0; needs scene option rope = 1)
+            const bool prim_rope = !two_level && (!sv.num_wnodes || primary_wide == 0);
+            if (prim_rope && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("primary_wide = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
+            if (!on_wide && !two_level && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("wide_bounce = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
             const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && primary_wide != 1 && (fuse_primary == 2 || F > 1 || B > 1);
-            const bool trace0_wide = trace0_pass && primary_wide == 2;          // (planes_pass implies the 8-wide layout)
+            const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
             if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
@@ -1360,11 +1382,12 @@ int Renderer::render(int n_frames) {                                   // Render
                 if (seeded) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
                 else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
-            else if (primary_wide == 1 && on_wide && !two_level) {
+            else if (primary_wide == 1 && sv.num_wnodes && !two_level) {
                 if (primary_hint) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
                 else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
             else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
+            else if (!prim_rope) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false, true>, dim3(grid, B), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
             else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {

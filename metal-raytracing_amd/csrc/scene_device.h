@@ -184,7 +184,8 @@ struct BuildOptions {
     float cost_trav = 1.0f;   // SAH constants
     float cost_isect = 1.0f;
     int ploc_radius = 16;
-    int wide = 1;             // also build the 8-wide compressed layout: the fused pipeline traces bounce + shadow rays on it
+    int wide = 1;             // build the 8-wide compressed layout: every ray of the pipeline walks it
+    int rope = 0;             // 1: also emit the rope layout (binary nodes with escape links + its own copy of the packets); 0: only when the scene cannot have the 8-wide layout
     int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
     float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
@@ -214,6 +215,7 @@ struct DeviceScene {
     float tlas_ms = 0;                                         // host + upload time of the last TLAS build
     bool validate = true, validated_blas = false;              // commit-time index validation (two_level.hip validate_layout); BLAS part already checked
     PinnedBuf stage;                                           // upload staging of build_flat (grow-only, reused by every commit of this scene)
+    double commit_ms[6] = {0, 0, 0, 0, 0, 0};                    // host wall time of the last flat build, by phase: staging (reserve + fill), device allocations + upload enqueue, topology (sort .. refit, incl. its read-backs), 8-wide emit, rope emit, validation (mrt_debug_commit_times)
     SceneView view() const;
 };
 

@@ -369,6 +369,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
     MRT_HIP(hipStreamSynchronize(stream));
     out.num_inst = (uint32_t)I;
     out.stats.bvh_nodes = tb.nodes.size() / 4;          // TLAS nodes; the BLAS nodes are counted in scene_bytes
+    out.rope_nodes = (uint32_t)(tb.nodes.size() / 4);
     out.stats.max_depth = tb.depth;
     out.tlas_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (out.validate) { if (int rc = validate_layout(out, stream, out.validated_blas)) return rc; out.validated_blas = true; }
@@ -377,7 +378,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
 
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt_in, hipStream_t stream, DeviceScene &out) {
     const size_t I = meshes.size();
-    BuildOptions opt = opt_in; opt.instancing = 0;
+    BuildOptions opt = opt_in; opt.instancing = 0; opt.rope = 1;      // the BLASes keep both layouts: the stackless two-level walk serves the query API and is the fallback of the render kernels
     opt.presplit = 0.0f;                                                // one packet per triangle in a BLAS: the instance rows address packets by triangle count (ntri)                      // a BLAS is a flat scene of one mesh: rope layout (queries, A/B path) + 8-wide layout (render kernels)
     // distinct geometries, in order of first use
     std::vector<int> blas_of(I, -1); std::vector<size_t> blas_src;

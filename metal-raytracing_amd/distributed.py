@@ -15,6 +15,35 @@ import torch
 import torch.distributed as dist
 
 
+DEFAULT_FRAME_BATCH = 8      # csrc/renderer.h DEFAULT_FRAME_BATCH: frames a pass carries at most on one GPU
+MAX_FRAME_BATCH = 32         # csrc/renderer.h MAX_FRAME_BATCH
+
+
+def shard_frame_batch(world, frames_total=None, base=DEFAULT_FRAME_BATCH):
+    """Frames per pass of one rank of a `world`-GPU tile-sharded run.  A rank owns 1/world of the pixels of every frame, so it carries
+    proportionally more frames per pass to keep its launches large (base x world, at most 32) — but never more than a third of the run's frames (and never
+    fewer than the 1-GPU default): a short run keeps about three passes to overlap.  mrt_group_renderer_create applies the first half of the rule, and
+    Renderer::render the second to every draw (csrc/renderer.hip `batch_cap`), so both launch paths agree."""
+    if world <= 1:
+        return base
+    fb = min(MAX_FRAME_BATCH, base * world)
+    if frames_total is not None:
+        fb = min(fb, max(base, int(frames_total) // 3))
+    return fb
+
+
+def pass_sizes(n_frames, frame_batch, base=DEFAULT_FRAME_BATCH):
+    """How Renderer::render (csrc/renderer.hip) splits a draw of n_frames into passes: passes larger than the default take at most a third of the draw,
+    and the draw's frames go in ceil(n / batch) passes of (almost) equal size — 20 frames at frame_batch 8 = 7 + 7 + 6."""
+    cap = min(frame_batch, max(base, (n_frames + 2) // 3)) if frame_batch > base else frame_batch
+    n_passes = (n_frames + cap - 1) // cap
+    out, f = [], 0
+    for p in range(n_passes):
+        b = min(cap, (n_frames - f + (n_passes - p) - 1) // max(1, n_passes - p))
+        out.append(b); f += b
+    return out
+
+
 def tile_owner_map(width, height, world):
     """(height, width) int32: owning rank of every pixel under the "tile" partition."""
     tiles_x = (width + 7) // 8
@@ -56,10 +85,7 @@ class ShardedRenderer:
                 # still needs about three passes to overlap (tools/tile_scaling_probe.py, rank 0 of N on one GPU, 20 frames: N = 8 at 32 frames
                 # per pass 4.98, at 8 frames per pass 5.42 Grays/s per rank; 240 frames: 9.73 at 32, 8.66 at 8)
                 base = int(self.renderer.get_option("frame_batch"))          # the library's default (8)
-                fb = min(32, base * world)
-                if frames_total is not None:
-                    fb = min(fb, max(base, int(frames_total) // 3))
-                self.renderer.set_option("frame_batch", fb)
+                self.renderer.set_option("frame_batch", shard_frame_batch(world, frames_total, base))
             else:
                 if frames_total is None:
                     raise ValueError("sample sharding needs frames_total (frames per rank)")

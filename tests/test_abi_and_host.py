@@ -209,6 +209,10 @@ def test_host_sah_builder_makes_a_valid_tree_of_lower_cost_than_a_median_split(m
     kids = np.concatenate([left, right])
     assert np.array_equal(np.sort(kids), np.setdiff1d(np.arange(2 * n - 1), np.where(parent == 0xFFFFFFFF)[0]))      # every non-root node is a child exactly once
     assert np.array_equal(parent[left], np.arange(n - 1)) and np.array_equal(parent[right], np.arange(n - 1))
+    # the numbering does not depend on the threads' timing: a second build gives the same arrays
+    o2 = np.zeros_like(order); l2 = np.zeros_like(left); r2 = np.zeros_like(right); p2 = np.zeros_like(parent)
+    mrt._ffi.check(mrt.lib.mrt_debug_host_sah(mrt._ffi.ptr(lo4), mrt._ffi.ptr(hi4), n, mrt._ffi.ptr(o2), mrt._ffi.ptr(l2), mrt._ffi.ptr(r2), mrt._ffi.ptr(p2)))
+    assert np.array_equal(order, o2) and np.array_equal(left, l2) and np.array_equal(right, r2) and np.array_equal(parent, p2)
     cost, depth = _sah_cost(lo4[:, :3].astype(np.float64), hi4[:, :3].astype(np.float64), order, left, right, parent)
     # object-median tree over the same boxes
     m_order = np.zeros(n, np.uint32); m_left = np.zeros(n - 1, np.uint32); m_right = np.zeros(n - 1, np.uint32); m_parent = np.full(2 * n - 1, 0xFFFFFFFF, np.uint32)

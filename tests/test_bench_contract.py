@@ -9,6 +9,37 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_launch_plan_of_every_rank_count_matches_design_section_7():
+    """bench.py's N > 1 argument / environment handling without a GPU: what torch.distributed.run's variables make of --gpus, which device a rank binds, the
+    frame_batch a tile-sharded rank gets and the passes its draws split into — the per-rank configuration DESIGN.md §7 states (and SCALE records are read against)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from metal_raytracing_amd.distributed import pass_sizes, shard_frame_batch
+    # the driver's command: --steps 20 --warmup 5 on N = 1, 2, 4, 8 (25 frames in all: a pass takes at most a third of them, never fewer than 8)
+    for n in (1, 2, 4, 8):
+        env = {} if n == 1 else {"WORLD_SIZE": str(n), "RANK": str(n - 1), "LOCAL_RANK": str(n - 1)}
+        p = bench.launch_plan(1 if n == 1 else n, 20, 5, "tile", env, ndev=8)
+        assert p["world"] == n and p["gpus"] == n and p["device"] == n - 1 and p["mode"] == ("single" if n == 1 else "ranks")
+        assert p["frame_batch"] == 8 and p["timed_passes"] == [7, 7, 6] and p["warmup_passes"] == [5], (n, p)
+    # a long run (240 + 24 frames): 8 x N frames per pass, at most 32; the timed draw in passes of equal size
+    for n, fb, passes in ((1, 8, [8] * 30), (2, 16, [16] * 15), (4, 32, [30] * 8), (8, 32, [30] * 8)):
+        env = {} if n == 1 else {"WORLD_SIZE": str(n), "RANK": "0", "LOCAL_RANK": "0"}
+        p = bench.launch_plan(n, 240, 24, "tile", env, ndev=8)
+        assert p["frame_batch"] == fb and p["timed_passes"] == passes and sum(p["timed_passes"]) == 240, (n, p)
+    # WORLD_SIZE wins over a stale --gpus; more ranks than devices (a gloo rehearsal on one box) wrap around; sample sharding keeps the 1-GPU pass
+    p = bench.launch_plan(1, 20, 5, "tile", {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}, ndev=1)
+    assert p["gpus"] == 4 and p["device"] == 0 and p["mode"] == "ranks"
+    assert bench.launch_plan(8, 20, 5, "sample", {"WORLD_SIZE": "8", "RANK": "1", "LOCAL_RANK": "1"}, ndev=8)["frame_batch"] == 8
+    # --gpus N without torch.distributed.run: one process, the C ABI's device group (min(32, 8 N) per rank; every draw capped by Renderer::render itself)
+    p = bench.launch_plan(8, 20, 5, "tile", {}, ndev=8)
+    assert p["mode"] == "group" and p["world"] == 1 and p["gpus"] == 8 and p["frame_batch"] == 32 and p["timed_passes"] == [7, 7, 6]
+    # the rule itself
+    assert [shard_frame_batch(n) for n in (1, 2, 3, 4, 8, 16)] == [8, 16, 24, 32, 32, 32]
+    assert shard_frame_batch(8, frames_total=25) == 8 and shard_frame_batch(8, frames_total=60) == 20 and shard_frame_batch(2, frames_total=1000) == 16
+    assert pass_sizes(20, 8) == [7, 7, 6] and pass_sizes(20, 32) == [7, 7, 6] and pass_sizes(16, 8) == [8, 8] and pass_sizes(1, 8) == [1] and pass_sizes(48, 8) == [8] * 6
+    assert pass_sizes(100, 32) == [25] * 4 and pass_sizes(5, 1) == [1] * 5
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--width", "320", "--height", "180", "--cpu-threads", "4"],
@@ -25,6 +56,8 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and "traffic" in r
     assert r["frame"]["frac"] > 0 and r["launches_timed"] > 0 and r["avg_launch_ms"] > 0
+    assert d["config"]["passes_of_timed_draw"] == [6] and r["launches_timed"] == 3 * len(d["config"]["passes_of_timed_draw"])      # the passes bench.py's launch_plan predicts are the ones the library ran (one traversal launch per bounce and pass)
+    assert d["config"]["wide_layout"] == 1 and d["config"]["wide_depth"] >= 1 and d["config"]["scene_commit_wall_ms"] > 0
     lat = d["latency"]
     assert lat["ms_per_frame"] > 0 and lat["kernel_ms_serialised"]["trace"] > 0 and lat["reference_like_3_in_flight_ms_per_frame"] > 0
     assert d["calibration"]["v_fma_f32_Ginst_per_s"] > 100

@@ -358,19 +358,19 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 
 # ---------------------------------------------------------------- alternative traversal backends
-@pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "wide_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
+@pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
-    """Every path a scene or option can reach must give the oracle's image: the default (primary rays traced inside shade(0), 8-wide layout + LDS
-    stack for bounce and shadow rays), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide layout
-    (own launch / inside shade(0)), bounce and shadow rays on the rope kernels, and any pass shape / number of passes in flight."""
+    """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
+    shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
+    inside shade(0), bounce and shadow rays on the rope kernels (scene option rope = 1), and any pass shape / number of passes in flight."""
     w, h = 256, 144
     sc = mrt.DragonScene((w, h))
-    sopt = {"wide": 0} if backend.startswith("rope_only") else None
+    sopt = {"wide": 0} if backend.startswith("rope_only") else {"rope": 1} if backend in ("rope_bounce", "rope_primary_in_shade") else None
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
-    assert r.device_scene.stats.wide_layout == (0 if sopt else 1)
+    assert r.device_scene.stats.wide_layout == (0 if backend.startswith("rope_only") else 1)
     if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
-    if backend == "wide_primary_in_shade": r.set_option("primary_wide", 2)
+    if backend == "rope_primary_in_shade": r.set_option("primary_wide", 0)
     if backend == "rope_bounce": r.set_option("wide_bounce", 0)
     if backend == "no_primary_hint": r.set_option("primary_hint", 0)
     if backend == "persistent_always": r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
