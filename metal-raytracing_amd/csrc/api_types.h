@@ -15,7 +15,8 @@ struct MRTScene_ {
     mrt::BuildOptions opt;
     mrt::DeviceScene dev;
     bool committed = false;
-    bool only_transforms_changed = false;   // since the last commit of a two-level scene: the next commit rebuilds the TLAS only
+    bool only_transforms_changed = false;   // since the last commit: a two-level scene rebuilds its TLAS only, a flattened one rebuilds from the geometry already on the device
+    size_t stage_need = 0;                  // bytes the upload staging of the meshes added so far will take (mrt_mesh_add_submesh grows the pinned area)
 };
 struct MRTRenderer_ {
     MRTContext ctx = nullptr;

@@ -21,6 +21,9 @@
 #include <cstring>
 #include <cmath>
 #include <chrono>
+#include <thread>
+#include <atomic>
+#include <functional>
 
 namespace mrt {
 namespace {
@@ -964,14 +967,14 @@ void pack_material(const MRTMaterial &m, float4 *out3) {
     out3[2] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.refractionIndex);
 }
 
-int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed) {
     out.validate = opt.validate != 0;
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
     out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
     // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
-    if (int rc = build_flat(refs, opt, stream, out)) return rc;
+    if (int rc = build_flat(refs, opt, stream, out, nullptr, only_transforms_changed)) return rc;
     const auto tv = std::chrono::steady_clock::now();
     const int rc = out.validate ? validate_layout(out, stream, false) : MRT_OK;
     out.commit_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
@@ -979,7 +982,18 @@ int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt,
 }
 
 // One world-space BVH over the given (geometry, transform) pairs: the whole flattened scene, or one BLAS (a single mesh under the identity).
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage) {
+// Copies of tens of megabytes on the host (the staging fill of a first commit): a few threads, each pulling tasks of <= 2 MB; serial when the work is small or no thread is to be had
+static void run_tasks(std::vector<std::function<void()>> &tasks, size_t bytes) {
+    const unsigned want = bytes < ((size_t)4 << 20) ? 1u : std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) tasks[i](); };
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < want; k++) { try { th.emplace_back(work); } catch (...) { break; } }
+    work();
+    for (auto &t : th) t.join();
+}
+
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage, bool geometry_unchanged) {
     struct MeshView { const std::vector<float> &positions, &normals; const float *xf; const std::vector<std::vector<uint32_t>> &sub_indices; const std::vector<MRTMaterial> &sub_materials; };
     std::vector<MeshView> meshes;
     for (auto &r : refs) meshes.push_back(MeshView{r.g->positions, r.g->normals, r.xf, r.g->sub_indices, r.g->sub_materials});
@@ -1005,21 +1019,33 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const size_t o_pos = 0, o_nrm = o_pos + up(std::max<size_t>(V * 3, 3) * 4), o_idx = o_nrm + up(std::max<size_t>(V, 1) * 16), o_rec = o_idx + up(std::max<size_t>(NI, 3) * 4),
                  o_cols = o_rec + up(std::max<size_t>(nrec, 1) * sizeof(SubRec)), o_base = o_cols + up(std::max<size_t>(I * 4, 4) * 16), o_mat = o_base + up(slots * 16), o_gb = o_mat + up(3 * slots * 16), o_end = o_gb + up(slots * 4);
     PinnedBuf &stg = stage ? *stage : out.stage;
-    MRT_HIP(stg.reserve(o_end));
-    uint8_t *const S = (uint8_t *)stg.p;
+    const size_t n_pos = std::max<size_t>(V * 3, 3), n_nrm = std::max<size_t>(V, 1), n_idx = std::max<size_t>(NI, 3), n_cols = std::max<size_t>(I * 4, 4);
+    // the geometry is on the device already (the previous commit of this scene left it there) and only transforms changed since: nothing of it is staged or uploaded again —
+    // the commit of an animated flattened scene is the build itself
+    const bool keep_geometry = geometry_unchanged && out.g_pos.p && out.g_pos.n == n_pos && out.g_idx.n == n_idx && out.g_recs.n == 6 * std::max<size_t>(nrec, 1) && out.normals.p && out.normals.n == n_nrm;
+    MRT_HIP(stg.reserve(keep_geometry ? o_end - o_cols : o_end));
+    uint8_t *const S = (uint8_t *)stg.p - (keep_geometry ? o_cols : 0);          // (keep_geometry: only the small tables are staged, at the start of the area; the geometry pointers below are never used)
     float *const h_pos = (float *)(S + o_pos); float4 *const h_nrm = (float4 *)(S + o_nrm); uint32_t *const h_idx = (uint32_t *)(S + o_idx); SubRec *const recs = (SubRec *)(S + o_rec);
     float4 *const h_cols = (float4 *)(S + o_cols), *const h_base = (float4 *)(S + o_base), *const h_mat = (float4 *)(S + o_mat); uint32_t *const h_gbase = (uint32_t *)(S + o_gb);
-    const size_t n_pos = std::max<size_t>(V * 3, 3), n_nrm = std::max<size_t>(V, 1), n_idx = std::max<size_t>(NI, 3), n_cols = std::max<size_t>(I * 4, 4);
     memset(h_base, 0, slots * 16); memset(h_mat, 0, 3 * slots * 16); memset(h_gbase, 0, slots * 4);
-    if (V == 0) { h_pos[0] = h_pos[1] = h_pos[2] = 0.0f; h_nrm[0] = make_float4(0, 0, 0, 0); }
-    if (NI == 0) { h_idx[0] = h_idx[1] = h_idx[2] = 0u; }
+    if (!keep_geometry) {
+        if (V == 0) { h_pos[0] = h_pos[1] = h_pos[2] = 0.0f; h_nrm[0] = make_float4(0, 0, 0, 0); }
+        if (NI == 0) { h_idx[0] = h_idx[1] = h_idx[2] = 0u; }
+    }
     if (I == 0) for (int c = 0; c < 4; c++) h_cols[c] = make_float4(0, 0, 0, 0);
+    // the big copies (positions, normals float3 -> float4, indices) as tasks of <= 2 MB for a few threads; the small tables here
+    std::vector<std::function<void()>> tasks; size_t task_bytes = 0;
+    constexpr size_t CH = (size_t)1 << 19;        // elements per task (2 MB of floats)
     size_t vb = 0, tb = 0, ib = 0, nr = 0;
     for (size_t mi = 0; mi < I; mi++) {
         const MeshView &m = meshes[mi];
         size_t nv = m.positions.size() / 3;
-        memcpy(&h_pos[vb * 3], m.positions.data(), nv * 12);
-        for (size_t v = 0; v < nv; v++) h_nrm[vb + v] = make_float4(m.normals[v * 3], m.normals[v * 3 + 1], m.normals[v * 3 + 2], 0.0f);
+        if (!keep_geometry) {
+            const float *sp = m.positions.data(), *sn = m.normals.data(); float *dp = &h_pos[vb * 3]; float4 *dn = &h_nrm[vb];
+            for (size_t a = 0; a < nv * 3; a += CH) { const size_t c = std::min(CH, nv * 3 - a); tasks.push_back([=] { memcpy(dp + a, sp + a, c * 4); }); }
+            for (size_t a = 0; a < nv; a += CH / 4) { const size_t c = std::min(CH / 4, nv - a); tasks.push_back([=] { for (size_t v = a; v < a + c; v++) dn[v] = make_float4(sn[v * 3], sn[v * 3 + 1], sn[v * 3 + 2], 0.0f); }); }
+            task_bytes += nv * 28;
+        }
         for (int c = 0; c < 4; c++) h_cols[mi * 4 + c] = make_float4(m.xf[c * 4 + 0], m.xf[c * 4 + 1], m.xf[c * 4 + 2], 0.0f);
         for (size_t g = 0; g < m.sub_indices.size(); g++) {
             const auto &ix = m.sub_indices[g];
@@ -1027,25 +1053,30 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
             pack_material(m.sub_materials[g], &h_mat[3 * (mi * max_sub + g)]);
             h_gbase[mi * max_sub + g] = (uint32_t)tb;
             if (ix.empty()) continue;
-            memcpy(&h_idx[ib], ix.data(), ix.size() * 4);
-            recs[nr++] = SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)ib, (uint32_t)vb, (uint32_t)mi, (uint32_t)g};
+            if (!keep_geometry) {
+                const uint32_t *si = ix.data(); uint32_t *di = &h_idx[ib];
+                for (size_t a = 0; a < ix.size(); a += CH) { const size_t c = std::min(CH, ix.size() - a); tasks.push_back([=] { memcpy(di + a, si + a, c * 4); }); }
+                task_bytes += ix.size() * 4;
+                recs[nr++] = SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)ib, (uint32_t)vb, (uint32_t)mi, (uint32_t)g};
+            }
             tb += ix.size() / 3; ib += ix.size();
         }
         vb += nv;
     }
+    run_tasks(tasks, task_bytes);
     out.stats = MRTSceneStats{};
     out.stats.triangles = T; out.stats.vertices = V; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub;
     out.stats.max_leaf_tris = opt.max_leaf;
     out.commit_ms[0] = since(tw0);
     const auto tw1 = std::chrono::steady_clock::now();
 
-    MRT_HIP(out.normals.alloc(n_nrm));
+    if (!keep_geometry) MRT_HIP(out.normals.alloc(n_nrm));
     MRT_HIP(out.base_color.alloc(slots)); MRT_HIP(out.materials.alloc(3 * slots));
     MRT_HIP(hipMemcpyAsync(out.materials.p, h_mat, 3 * slots * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(out.geom_base.alloc(slots));
     MRT_HIP(out.inst_cols.alloc(n_cols));
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(T, 1)));
-    MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream));
+    if (!keep_geometry) MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.base_color.p, h_base, slots * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase, slots * 4, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols, n_cols * 16, hipMemcpyHostToDevice, stream));
@@ -1062,13 +1093,15 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const uint32_t T32 = (uint32_t)T;
     ScratchArena arena;                                          // before the buffers that borrow from it
     arena.chunk_bytes = ((size_t)T * (576 + 48 + (opt.wide && opt.max_leaf <= 4 ? 16 * WNODE_STRIDE : 0)) + ((size_t)4 << 20) + 255) & ~(size_t)255;     // what a build of T triangles takes (~510 B per triangle + the 8-wide nodes' scratch): one allocation, more if pre-splitting adds references
-    DevBuf<float> d_pos; DevBuf<uint32_t> d_idx; DevBuf<SubRec> d_recs;
     DevBuf<float4> tri_world, tri_lo, tri_hi, ref_lo, ref_hi, node_lo, node_hi;
     DevBuf<uint32_t> cbounds, vals_a, vals_b, ghist, parent, left, right, flags, ntri, size, new_index, leaf_offset, stat, ref_tri;
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<float> cost;
     DevBuf<uint8_t> collapsed, mask;
-    MRT_HIP(d_pos.alloc_in(arena, n_pos)); MRT_HIP(d_idx.alloc_in(arena, n_idx)); MRT_HIP(d_recs.alloc_in(arena, std::max<size_t>(nrec, 1)));
+    // the build's geometry inputs stay with the scene (15 MB for DragonScene): the next commit of the same geometry under new transforms reads them where they are
+    if (!keep_geometry) { MRT_HIP(out.g_pos.alloc(n_pos)); MRT_HIP(out.g_idx.alloc(n_idx)); MRT_HIP(out.g_recs.alloc(6 * std::max<size_t>(nrec, 1))); }
+    float *const d_pos_p = out.g_pos.p; uint32_t *const d_idx_p = out.g_idx.p; SubRec *const d_recs_p = reinterpret_cast<SubRec *>(out.g_recs.p);
+    static_assert(sizeof(SubRec) == 24, "SubRec is six 32-bit words");
     MRT_HIP(tri_world.alloc_in(arena, 3 * (size_t)T32)); MRT_HIP(tri_lo.alloc_in(arena, T32)); MRT_HIP(tri_hi.alloc_in(arena, T32));
     MRT_HIP(cbounds.alloc_in(arena, 6)); MRT_HIP(stat.alloc_in(arena, 4));
 
@@ -1078,9 +1111,11 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     } evs;
     MRT_HIP(hipEventCreate(&evs.a)); MRT_HIP(hipEventCreate(&evs.b));
     const hipEvent_t ev0 = evs.a, ev1 = evs.b;
-    MRT_HIP(hipMemcpyAsync(d_pos.p, h_pos, n_pos * 4, hipMemcpyHostToDevice, stream));
-    MRT_HIP(hipMemcpyAsync(d_idx.p, h_idx, n_idx * 4, hipMemcpyHostToDevice, stream));
-    if (nrec) MRT_HIP(hipMemcpyAsync(d_recs.p, recs, nrec * sizeof(SubRec), hipMemcpyHostToDevice, stream));
+    if (!keep_geometry) {
+        MRT_HIP(hipMemcpyAsync(d_pos_p, h_pos, n_pos * 4, hipMemcpyHostToDevice, stream));
+        MRT_HIP(hipMemcpyAsync(d_idx_p, h_idx, n_idx * 4, hipMemcpyHostToDevice, stream));
+        if (nrec) MRT_HIP(hipMemcpyAsync(d_recs_p, recs, nrec * sizeof(SubRec), hipMemcpyHostToDevice, stream));
+    }
     MRT_HIP(hipEventRecord(ev0, stream));
     {
         uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0};
@@ -1091,7 +1126,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const int B = 256;
     out.commit_ms[1] = since(tw1);
     const auto tw2 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs.p, (int)nrec, d_pos.p, d_idx.p, out.inst_cols.p, T32,
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs_p, (int)nrec, d_pos_p, d_idx_p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
     uint32_t n = T32;

@@ -214,6 +214,7 @@ struct DeviceScene {
     std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each
     float tlas_ms = 0;                                         // host + upload time of the last TLAS build
     bool validate = true, validated_blas = false;              // commit-time index validation (two_level.hip validate_layout); BLAS part already checked
+    DevBuf<float> g_pos; DevBuf<uint32_t> g_idx, g_recs;       // flattened build: packed object-space positions, indices and submesh records as uploaded (kept: a commit that only changes transforms does not upload them again)
     PinnedBuf stage;                                           // upload staging of build_flat (grow-only, reused by every commit of this scene)
     double commit_ms[6] = {0, 0, 0, 0, 0, 0};                    // host wall time of the last flat build, by phase: staging (reserve + fill), device allocations + upload enqueue, topology (sort .. refit, incl. its read-backs), 8-wide emit, rope emit, validation (mrt_debug_commit_times)
     SceneView view() const;
@@ -223,11 +224,11 @@ struct DeviceScene {
 void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
-int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
 void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr, bool geometry_unchanged = false);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched

@@ -279,6 +279,38 @@ def test_commit_validates_every_index_of_the_layout(mrt, gpu_ctx, instancing):
 
 
 @pytest.mark.gpu
+def test_flattened_scene_recommits_new_transforms_without_its_geometry(mrt, gpu_ctx):
+    """An animated FLATTENED scene: mrt_scene_set_instance_transform + mrt_scene_commit rebuilds the world-space BVH from the geometry the previous commit left on the
+    device (no staging, no upload of positions / normals / indices).  The image must be the one a scene created with those transforms gives, bit for bit, twice in a
+    row, and any other change of the scene (an option) must take the full path again."""
+    import ctypes as C
+    w, h = 160, 96
+    sc = _scene(mrt, (w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    r.draw(2, wait=True)
+    first = (C.c_double * 6)(); mrt._ffi.check(mrt.lib.mrt_debug_commit_times(r.device_scene.handle, first))
+    for step, (mesh_id, pos) in enumerate([(2, [1.0, 0.3, -0.8]), (4, [-0.9, 0.2, 0.7])]):
+        xf = np.eye(4, dtype=np.float32); xf[:3, 3] = pos; xf[0, 0] = xf[1, 1] = xf[2, 2] = 0.8 if mesh_id == 2 else 0.012
+        xf = np.ascontiguousarray(xf.T)                                # (4,4) [col][row], as Mesh.transform
+        r.device_scene.set_instance_transform(mesh_id, xf); r.device_scene.commit()
+        again = (C.c_double * 6)(); mrt._ffi.check(mrt.lib.mrt_debug_commit_times(r.device_scene.handle, again))
+        sc.meshes[mesh_id].transform = xf.reshape(4, 4)
+        r.drawableSizeWillChange((w, h)); r.draw(3, wait=True)
+        fresh = mrt.Renderer((w, h), sc, ctx=gpu_ctx); fresh.draw(3, wait=True)
+        assert np.array_equal(r.accumulation().view(np.uint32), fresh.accumulation().view(np.uint32)), step
+        assert (r.stats.closest_rays, r.stats.shadow_rays) == (fresh.stats.closest_rays, fresh.stats.shadow_rays)
+        a, b = r.device_scene.stats, fresh.device_scene.stats
+        assert (a.triangles, a.bvh_nodes, a.bvh_leaves, a.wide_depth, a.scene_bytes) == (b.triangles, b.bvh_nodes, b.bvh_leaves, b.wide_depth, b.scene_bytes)
+        fresh.close()
+        print("commit phases, first:", [round(x, 3) for x in first], "transform-only:", [round(x, 3) for x in again])
+    mrt._ffi.check(mrt.lib.mrt_scene_set_option(r.device_scene.handle, b"presplit", 0.0)); r.device_scene.commit()      # not a transform change: full path
+    r.drawableSizeWillChange((w, h)); r.draw(3, wait=True)
+    fresh = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"presplit": 0}); fresh.draw(3, wait=True)
+    assert np.array_equal(r.accumulation().view(np.uint32), fresh.accumulation().view(np.uint32))
+    fresh.close(); r.close()
+
+
+@pytest.mark.gpu
 def test_primary_hint_on_two_level_scenes(mrt, orc, gpu_ctx):
     """The hint of two-level scenes — (packet | instance << 24) of the pixel's last primary hit, tested first in that instance's object space — changes no pixel:
     with it and without it, over frames that reuse it, after the instances have moved (stale hints: legal guesses or rejected), and against the oracle."""

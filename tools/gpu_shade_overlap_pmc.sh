@@ -7,7 +7,7 @@
 # SQ_ACTIVE_INST_ANY (resident cycles spent waiting on memory / waiting to issue / issuing), and the L2 hit rate.  A launch whose duration grows under overlap while its waves'
 # resident cycles do not is waiting for WAVE SLOTS (held by the persistent traversal waves); one whose resident cycles grow in step is waiting for memory or issue slots.
 # usage: tools/gpu_shade_overlap_pmc.sh [OUTDIR]  -> OUTDIR/shade_overlap_pmc.txt (+ the kernel-trace durations of the same three commands)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=${1:-$R/gpurun_out/shade_overlap}; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=${1:-$R/gpurun_out/shade_overlap}; case $O in /*) ;; *) O=$R/$O ;; esac; rm -rf $O; mkdir -p $O
 COMMON="--no-cpu-baseline --no-strict --no-latency"
 declare -A CMD=( [serial]="--steps 16 --warmup 8 $COMMON --opt frames_in_flight=1 --opt frame_batch=8" [driver]="--steps 20 --warmup 5 $COMMON" [steady]="--steps 240 --warmup 24 $COMMON" )
 cd /tmp && export TMPDIR=/tmp
