@@ -173,12 +173,13 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     out["kernel_ms_serialised_pass"] = {k: round(statistics.median(v), 4) for k, v in four.items()}; out["frames_per_serialised_pass"] = PASS_FRAMES
     q.set_option("frame_batch", 1); q.draw(2, wait=True)
     # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
-    q.set_option("megakernel", 1); q.draw(3, wait=True)
-    mk = []
-    for _ in range(frames):
-        q.draw(1, wait=True); mk.append(q.stats.ms_gpu_last)
-    out["megakernel_ms_per_frame"] = round(statistics.median(mk), 4)
-    q.set_option("megakernel", 0)
+    if q.device_scene.stats.wide_layout and not (opts or {}).get("instancing"):      # (the one-launch mode renders flattened scenes on the 8-wide layout; it refuses others)
+        q.set_option("megakernel", 1); q.draw(3, wait=True)
+        mk = []
+        for _ in range(frames):
+            q.draw(1, wait=True); mk.append(q.stats.ms_gpu_last)
+        out["megakernel_ms_per_frame"] = round(statistics.median(mk), 4)
+        q.set_option("megakernel", 0)
     q.set_option("frames_in_flight", 3)
     q.draw(6, wait=True)
     t0 = time.perf_counter(); q.draw(30, wait=True); dt = time.perf_counter() - t0

@@ -917,7 +917,7 @@ SceneView DeviceScene::view() const {
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / WPK) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
-    v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
+    v.inst = inst.p; v.tlas_index = tlas_index.p; v.wtlas_index = wtlas_index.p; v.tri_packet = (num_inst && num_wnodes) ? tri_packet.p : nullptr; v.inst_box = num_inst ? inst_box.p : nullptr; v.bnodes = bnodes.p; v.bpackets = bnodes.p ? bnodes.p + bpackets_offset : nullptr; v.num_inst = num_inst;
     v.num_nodes = rope_nodes; v.num_tris = num_packets;      // entries of `packets` (>= triangles when long triangles were pre-split into references)
     v.light_count = light_count; v.max_sub = stats.max_submeshes;
     return v;
@@ -970,7 +970,7 @@ void pack_material(const MRTMaterial &m, float4 *out3) {
 int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed) {
     out.validate = opt.validate != 0;
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
-    out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
+    out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tri_packet.release(); out.inst_box.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
     // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});

@@ -23,6 +23,7 @@ struct FrameLane {
     // shadow planes (default path): the light's contribution of bounces 1 and 2 per sample (bounce 0 uses `sample`) and one byte per sample and bounce "the shadow ray got through"
     DevBuf<float4> f_con[2];
     DevBuf<uint8_t> f_lit;               // [sub-frame][pixel][bounce]: one 32-bit word per sample
+    DevBuf<uint4> pairs;                 // two-level scenes, binned walk (tl_pairs): {ray, instance, bound, report tag} queued by the TLAS pass for the BLAS pass; allocated at the first such pass
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
 constexpr int MAX_FRAME_BATCH = 32;
@@ -68,6 +69,8 @@ struct Renderer {
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
+    int tl_pair_cap = 0;                 // test aid: > 0 bounds the pair queue (pushes beyond it walk their instance in place); 0 = one pair per virtual ray
+    int tl_pairs = 1;                    // two-level scenes: bounce / shadow rays as TLAS pass + BLAS pass over (ray, instance) pairs (k_tl_top / k_tl_blas) instead of one loop over both levels; 0 = the one-loop walk
     bool wide_bounce = true;             // A/B switch: 0 = bounce / shadow rays on the rope kernels although the scene has the 8-wide layout
     hipEvent_t ev_fork = nullptr;
     DevBuf<unsigned long long> totals;   // [0] closest rays, [1] shadow rays, [2] primary rays

@@ -281,6 +281,133 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         );
 }
 
+// ------------------------------------------------------------------ two-level scenes, binned: TLAS pass + BLAS pass (renderer option tl_pairs, default)
+// In the one-loop walk of a two-level scene (k_trace_mixed_wide_persist<true>) the lanes of a wave are out of step — node / triangle / level change — and dragon x 4 costs
+// 17.1 wave-iterations per 64 bounce rays where the flattened scene costs 13.5 (tools/two_level_binning_probe.py).  Here the bounce / shadow rays of a shade pass take two launches:
+//   k_tl_top    the same loop, but an instance of more than eight triangles is not entered: {ray, instance} goes to a queue (ballot-compacted, one atomic per wave and iteration).
+//               What a ray finds at the TLAS level (walls, floor: tested in place) becomes its result so far: a 64-bit key (t bits << 32 | global triangle id), ~0 = nothing;
+//               a shadow ray not occluded so far sets its pixel's byte.
+//   k_tl_blas   every pair walked in its instance's object space by the FLATTENED loop (per-ray root; the ray transformed once, at fetch), starting with the distance its ray
+//               has so far; a hit is folded into the ray's key with atomicMin — minimum t, ties to the lowest global id: the one-loop walk's result — or clears the pixel's byte.
+// k_shade<.., PAIRS> of the next bounce turns a key back into a hit record (the winning triangle re-tested in object space: the traversal's own arithmetic).
+__global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
+                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                                 uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
+    extern __shared__ uint32_t stk_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if (blockIdx.x * chunk >= n) return;
+    uint32_t *const cursor = stk_dyn + stack_words;          // two words behind the wave's stack: its block of the pair queue
+    cursor[0] = 0; cursor[1] = 0;
+    const PairQueue pq{pairs, pair_count, pair_cap, cursor};
+    traverse_wide_stream<true, false, false, PairQueue>(s, SharedCounter{work, n, chunk}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word carries the throughput chain
+            else tag = __float_as_uint(B.w);            // a shadow ray reports to its pixel's byte
+        },
+        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }          // not occluded at the TLAS level: lit unless one of its pairs finds an occluder
+            else __builtin_nontemporal_store(hit ? ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | h.gid : ~0ull, &keys[j]);      // (+ 0.0f: a distance of -0 must order as 0)
+        }, nullptr, pq);
+    pq.close();
+}
+// The TLAS pass of a scene with FEW instances (at most TL_FLAT_MAX_INSTANCES; DragonScene x 4 has ten), without a tree: one ray per lane, every lane visits every instance in the same
+// order — the rows and boxes are wave-uniform (scalar loads), nothing diverges, nothing is gathered, no stack, no refill.  First the instances of at most eight triangles, tested in
+// place in object space (they give the ray its bound); then the large ones: the ray against the instance's BLAS box in object space, and a pair for the BLAS pass where it enters
+// before that bound.  A refused pair (queue full) is walked here, one ray per lane (traverse_wide from the BLAS root).  Pairs leave instance-major, so the BLAS pass's waves see one
+// instance at a time.  The stream walk of the 8-wide TLAS (k_tl_top) spent 1.16 ms per launch on the 12 M rays of an 8-frame pass of dragon x 4, refilling lanes every other iteration; this takes them in 0.53 ms (profiles/r04_two_level_binned_ab.txt).
+constexpr uint32_t TL_FLAT_MAX_INSTANCES = 64;
+__global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
+                                                    const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                    uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
+    extern __shared__ uint32_t stk_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n = n_next + (uint32_t)(c >> 32);
+    if (blockIdx.x * 64u >= n) return;
+    uint32_t *const cursor = stk_dyn + stack_words;
+    cursor[0] = 0; cursor[1] = 0;
+    const PairQueue pq{pairs, pair_count, pair_cap, cursor};
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {          // (wave-uniform) the launch has as many waves as the chip has slots for them
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < n, sh = i >= n_next;
+    const uint32_t j = sh ? i - n_next : i;
+    float4 A = make_float4(0.0f, 0.0f, 0.0f, -1.0f), B = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (active) { A = qload(sh ? &srayA[j] : &rayA[j]); B = qload(sh ? &srayB[j] : &rayB[j]); if (!sh) A.w = __builtin_inff(); }
+    const f3 o = mk3(A), d = mk3(B);
+    const uint32_t tagw = sh ? (__float_as_uint(B.w) | 0x80000000u) : j;      // what the BLAS pass reports to: the pixel's byte (shadow) / the ray's key
+    float best_t = A.w; uint32_t best_gid = 0xFFFFFFFFu; bool done = !active;
+    for (uint32_t id = 0; id < s.num_inst; id++) {                  // the small instances, in place
+        const InstanceDev &I = s.inst[id];
+        if (I.ntri == 0u || I.ntri > 8u || s.inst_box[2 * id].x > s.inst_box[2 * id + 1].x) continue;          // (wave-uniform)
+        const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
+        for (uint32_t k = 0; k < I.ntri; k++) {
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)(I.packet_base + k);
+            const float4 q0 = pk[0], q1 = pk[1], q2 = pk[2];
+            float t, U, V, ad;
+            if (!done && tri_test(q0, q1, q2, oo, dd, 0.0f, best_t, t, U, V, ad)) {
+                const uint32_t gid = I.gid_base + __float_as_uint(q0.w);
+                if (sh) done = true;                                // occluded: lit stays 0
+                else if (t < best_t || gid < best_gid) { best_t = t; best_gid = gid; }      // (t <= best_t here: ties go to the lowest global id)
+            }
+        }
+    }
+    for (uint32_t id = 0; id < s.num_inst; id++) {                  // the large instances: a pair where the ray enters the BLAS's box before its bound
+        const InstanceDev &I = s.inst[id];
+        const float4 blo = s.inst_box[2 * id], bhi = s.inst_box[2 * id + 1];
+        if (I.ntri <= 8u || blo.x > bhi.x) continue;
+        const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
+        const float ix = box_inv(dd.x), iy = box_inv(dd.y), iz = box_inv(dd.z);
+        const bool enters = !done && rope_box_hit(blo, bhi, ix, iy, iz, -(oo.x * ix), -(oo.y * iy), -(oo.z * iz), 0.0f, best_t);
+        if (enters) {
+            if (!pq.push(i, id, best_t, tagw)) {                    // the queue is full: this instance is walked here
+                TravHit h;
+                if (traverse_wide<false, false, true>(s, oo, dd, 0.0f, best_t, h, stk_dyn, nullptr, sh, I.wroot)) {
+                    if (sh) done = true;
+                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; } }
+                }
+            }
+        }
+    }
+    if (active) {
+        if (sh) { if (!done) lit[4 * (size_t)(tagw & 0x7FFFFFFFu)] = 1; }          // not occluded so far: lit unless one of its pairs finds an occluder
+        else __builtin_nontemporal_store(best_gid != 0xFFFFFFFFu ? ((unsigned long long)__float_as_uint(best_t + 0.0f) << 32) | best_gid : ~0ull, &keys[j]);
+    }
+    }
+    pq.close();
+}
+__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
+                                                                   const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
+    extern __shared__ uint32_t stk_dyn[];
+    const uint32_t n_next = (uint32_t)*counts, np = min(*pair_count, pair_cap / PairQueue::BLOCK * PairQueue::BLOCK);        // whole blocks only (blocks beyond the capacity were refused — their rays walked in place — but counted)
+    if (blockIdx.x * chunk >= np) return;
+    traverse_wide_stream<false, false, true>(s, SharedCounter{work, np, chunk}, stk_dyn,
+        [&](uint32_t k, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, uint32_t &root) {
+            const float4 Pf = qload(reinterpret_cast<const float4 *>(&pairs[k]));
+            const uint32_t i = __float_as_uint(Pf.x), id = __float_as_uint(Pf.y);
+            if (i == 0xFFFFFFFFu) {          // the unused rest of a wave's block: a ray that cannot hit anything
+                A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); tag = k; is_any = 1u; root = 0u;
+                return;
+            }
+            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
+            const float4 Aw = qload(sh ? &srayA[j] : &rayA[j]), Bw = qload(sh ? &srayB[j] : &rayB[j]);
+            const InstanceDev &I = s.inst[id];
+            const f3 o = to_object_point(I, mk3(Aw)), d = to_object_dir(I, mk3(Bw));        // direction not renormalised: t stays the world distance
+            float tmax = Aw.w;
+            if (!sh) { const unsigned long long key = keys[j]; tmax = key == ~0ull ? __builtin_inff() : __uint_as_float((uint32_t)(key >> 32)); }      // what the ray has so far (TLAS-level hits; other pairs of the same ray may shorten it further while this one walks)
+            A = make_float4(o.x, o.y, o.z, tmax); B = make_float4(d.x, d.y, d.z, 0.0f);
+            tag = k; is_any = sh ? 1u : 0u; root = I.wroot;
+        },
+        [&](uint32_t k, bool is_any, bool hit, const TravHit &h) {
+            if (!hit) return;
+            const uint4 P = pairs[k];
+            if (is_any) lit[4 * (size_t)(P.w & 0x7FFFFFFFu)] = 0;          // occluded inside this instance
+            else atomicMin(&keys[P.x], ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | (unsigned long long)(s.inst[P.y].gid_base + h.gid));      // (h.gid: the triangle's id inside its BLAS)
+        });
+}
+
 // ------------------------------------------------------------------ one launch per frame: the wave-level megakernel (option megakernel = 1)
 // The reference is ONE kernel per frame (Raytracing.metal:156-405).  The wavefront pipeline above is faster in throughput (its shading runs at
 // full lane width, its traversal launches are large) but a single frame pays eight dependent launches, each with its own ramp-up and tail:
@@ -580,8 +707,8 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills)
-__global__ void __launch_bounds__(SHADE_THREADS, TRACE0 == 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
+template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0, bool PAIRS = false>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills); PAIRS (two-level scenes, bounces >= 1, renderer option tl_pairs): `hits` holds 64-bit keys (t bits << 32 | global triangle id, ~0 = miss) left by k_tl_top / k_tl_blas instead of hit records — the barycentrics come from re-testing the winning triangle in its instance's object space
+__global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
                                               float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
@@ -613,7 +740,28 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 == 2 ? MRT_SHADE_WIDE_WA
             Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
             TravHit h;
             bool hit;
-            if (TRACE0 == 2) {
+            if (TRACE0 == 3) {            // two-level scene: both levels on one stack, one ray per lane (traverse_wide_lane_two_level); the hint is (packet | instance << 24)
+                extern __shared__ uint32_t shade_stk[];
+                uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
+                if (hint != nullptr) {
+                    const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+                    const uint32_t guess = hint[pixel];
+                    float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
+                    const uint32_t gpk = guess & 0xFFFFFFu, gin = guess >> 24;
+                    if (guess != 0xFFFFFFFFu && gin < s.num_inst) {
+                        const InstanceDev &I = s.inst[gin];
+                        if (gpk - I.packet_base < I.ntri) {           // a legal guess names a packet of its instance's BLAS (a stale one — moved instances — is one wasted test or none)
+                            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)gpk;
+                            float t, U, V, ad;
+                            if (tri_test(pk[0], pk[1], pk[2], to_object_point(I, org), to_object_dir(I, dir), 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+                        }
+                    }
+                    hit = traverse_wide_lane_two_level<true>(s, org, dir, t0, seed, h, stk);
+                    if (hit && h.pk != guess) hint[pixel] = h.pk;
+                }
+                else hit = traverse_wide_lane_two_level<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk);
+            }
+            else if (TRACE0 == 2) {
                 extern __shared__ uint32_t shade_stk[];          // SHADE_WAVES x wide-tree depth x WIDE_STACK_LEVEL_BYTES
                 uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
                 if (hint != nullptr) {
@@ -645,6 +793,19 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 == 2 ? MRT_SHADE_WIDE_WA
             }
             else hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
             if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
+        }
+    }
+    else if (active && PAIRS) {
+        const unsigned long long key = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + i);
+        if (key != ~0ull) {
+            const uint32_t g = (uint32_t)key;
+            const InstanceDev &I = s.inst[instance_of_gid(s, g)];
+            const uint32_t pk = s.tri_packet[I.ts_base + (g - I.gid_base)];
+            const float4 Aw = qload(&rayA[i]), Bw = qload(&rayB[i]);
+            const float4 *__restrict__ q = s.wpackets + WPK * (size_t)pk;
+            float t_, U, V, ad;
+            (void)tri_test(q[0], q[1], q[2], to_object_point(I, mk3(Aw)), to_object_dir(I, mk3(Bw)), 0.0f, __builtin_inff(), t_, U, V, ad);      // the traversal's own test of the winner: the same U, V, |det|
+            H = make_float4(__uint_as_float((uint32_t)(key >> 32)), U / ad, V / ad, __uint_as_float(g));
         }
     }
     else if (active) H = qload(&hits[i]);
@@ -838,6 +999,7 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
             shadow += c >> 32;
             bounce_counts[b] = 0;
             bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
+            bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
     }
@@ -881,6 +1043,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
             shadow += c >> 32;
             bounce_counts[b] = 0;
             bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
+            bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
     }
@@ -917,7 +1080,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
                 const unsigned long long c = g.p[p].counts[b];
                 if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
                 shadow += c >> 32;
-                g.p[p].counts[b] = 0; g.p[p].counts[32 + b] = 0;
+                g.p[p].counts[b] = 0; g.p[p].counts[32 + b] = 0; g.p[p].counts[65 + b] = 0;
             }
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
@@ -1094,7 +1257,7 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
-        MRT_HIP(L.bounce_counts.alloc(65));       // [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches; [64]: the megakernel's pixel counter
+        MRT_HIP(L.bounce_counts.alloc(97));       // [65, 97): two-level scenes, binned — per bounce {pairs queued (lo 32), work counter of the BLAS pass (hi 32)};  [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches; [64]: the megakernel's pixel counter
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -1192,11 +1355,12 @@ size_t Renderer::lane_bytes() const {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
     const size_t planes_bytes = shadow_planes ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const bool need_scon = need_thr || !shadow_planes;
-    return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + planes_bytes;
+    const size_t pairs_bytes = (scene && scene->num_inst && scene->num_wnodes && tl_pairs && shadow_planes && !need_thr) ? 2 * qcap * sizeof(uint4) : 0;      // two-level scenes: the (ray, instance) queue of the binned walk
+    return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + planes_bytes + pairs_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); L.f_con[k].release(); }
-    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release();
+    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release(); L.pairs.release();
 }
 int Renderer::alloc_planes(FrameLane &L) {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
@@ -1282,7 +1446,11 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
     constexpr int ablate = 0;
 #endif
-    const bool mega = megakernel && !two_level && !materials && sv.num_wnodes > 0;
+    if (megakernel && (two_level || materials || sv.num_wnodes == 0)) {          // the one-launch-per-frame mode exists for flattened scenes on the 8-wide layout, diffuse kernel: say so instead of quietly rendering through the pipeline
+        set_error(std::string("megakernel = 1 renders flattened scenes with the 8-wide layout and the reference's diffuse kernel only; this renderer has ") + (two_level ? "a two-level scene (scene option instancing = 1)" : materials ? "materials = 1" : "a scene without the 8-wide layout") + ": set megakernel = 0");
+        return MRT_ERR_UNSUPPORTED;
+    }
+    const bool mega = megakernel;
     // passes larger than the default (sharded renderers ask for up to 32 frames so that a shard's launches stay large) never take more than a third of the draw:
     // a short draw keeps about three passes to run side by side (a rank of eight over 20 frames: 7.1 Grays/s as 7 + 7 + 6, 6.0 as one pass of 20)
     const int batch_cap = alloc_batch > DEFAULT_FRAME_BATCH ? std::min(alloc_batch, std::max(DEFAULT_FRAME_BATCH, (n_frames + 2) / 3)) : alloc_batch;
@@ -1363,6 +1531,11 @@ int Renderer::render(int n_frames) {                                   // Render
                 MRT_HIP(hipMemsetAsync(L.f_lit.p, 0, 4 * (size_t)capacity * (size_t)B, st));
             }
             used_planes = planes_pass;
+            // two-level scenes: the binned walk (TLAS pass + BLAS pass over (ray, instance) pairs) for the bounce / shadow rays of planes passes
+            const bool pairs_pass = two_level && planes_pass && tl_pairs != 0 && sv.tri_packet != nullptr;
+            const size_t pair_cap = 2 * (size_t)capacity * (size_t)std::max(1, alloc_batch);          // one pair per virtual ray of the combined queue; a push beyond it walks its instance in place
+            if (pairs_pass && !L.pairs.p) MRT_HIP(L.pairs.alloc(std::max<size_t>(pair_cap, 1)));
+            const uint32_t pair_cap_used = (uint32_t)std::min<size_t>(tl_pair_cap > 0 ? std::min<size_t>((size_t)tl_pair_cap, pair_cap) : pair_cap, 0xFFFFFFFFu);
             // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
             // fuse_primary = 2 fuses always)
@@ -1371,8 +1544,9 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool prim_rope = !two_level && (!sv.num_wnodes || primary_wide == 0);
             if (prim_rope && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("primary_wide = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
             if (!on_wide && !two_level && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("wide_bounce = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
-            const bool trace0_pass = planes_pass && fuse_primary != 0 && !two_level && primary_wide != 1 && (fuse_primary == 2 || F > 1 || B > 1);
+            const bool trace0_pass = planes_pass && fuse_primary != 0 && primary_wide != 1 && !(two_level && primary_wide == 0) && (fuse_primary == 2 || F > 1 || B > 1);
             const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
+            const bool trace0_hint = primary_hint && (!two_level || (sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24)));      // two-level: the hint is (packet | instance << 24)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
             if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
@@ -1397,6 +1571,8 @@ int Renderer::render(int n_frames) {                                   // Render
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
                 const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
                 auto shade_kernel = materials ? k_shade<true, false>
+                                              : (pairs_pass && b > 0) ? k_shade<false, true, true, 0, true>
+                                              : (trace0_wide && b == 0 && two_level) ? k_shade<false, true, true, 3>
                                               : (trace0_wide && b == 0) ? k_shade<false, true, true, 2>
                                               : (trace0_pass && b == 0) ? k_shade<false, true, true, 1>
                                               : planes_pass ? k_shade<false, true, true>
@@ -1404,7 +1580,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES : 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
-                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && primary_hint) ? hint.p : (uint32_t *)nullptr);
+                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && trace0_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 // [r3] smaller launches pull as well when five or more passes are in flight (6 lanes x one-frame passes: 9.33 against 8.76 Grays/s; a rank of eight over 240 frames
@@ -1412,6 +1588,24 @@ int Renderer::render(int n_frames) {                                   // Render
                 // 7.63 against 7.20 Grays/s, a rank of eight over the driver's 20 frames 6.65 against 5.73): stream_even below
                 const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || (std::min(F, n_passes) >= 5 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 256)));      // (below 256 slots per wave slot — Cornell 256^2 in 8-frame passes — the even split: 6.46 against 5.40 Grays/s)
                 if (ablate & 2) {}
+                else if (pairs_pass) {
+                    const size_t slots = 2 * (size_t)capacity * B;
+                    const uint32_t chunk = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(64, slots / ((size_t)wave_slots * 4) / 64 * 64));
+                    const size_t grid_slots = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? (size_t)std::max(1, wave_slots / 2) : (size_t)wave_slots;
+                    const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk), grid_slots));
+                    uint32_t *const pc = reinterpret_cast<uint32_t *>(bc + 65 + b);          // {pairs queued, work counter of the BLAS pass}
+                    unsigned long long *const keys = reinterpret_cast<unsigned long long *>(L.hits.p);
+                    // few instances: the TLAS pass without a tree (every lane visits every instance: nothing diverges); many: the stream walk of the 8-wide TLAS
+                    if (sv.num_inst <= TL_FLAT_MAX_INSTANCES && tl_pairs != 2)
+                        launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top_flat, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, 64), 2 * grid_slots))), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
+                                     (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
+                    else
+                    launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top, dim3(waves), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
+                                 (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
+                    // the pairs' count is on the device: the launch has the wave slots it may use and the surplus leaves at once
+                    launch_timed(timed(MRT_KERNEL_TRACE), k_tl_blas, dim3((uint32_t)grid_slots), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
+                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used);
+                }
                 else if (on_wide && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
                     // persist_chunk; 128-ray pulls of a one-frame launch are ~78 atomics per microsecond on the one counter word (limit ~88)

@@ -97,6 +97,8 @@ struct SceneView {           // passed by value to kernels
     const InstanceDev *inst;
     const uint32_t *tlas_index;  // instance ids, TLAS leaf order
     const uint32_t *wtlas_index; // instance ids in the leaf order of the 8-wide TLAS (wnodes[0 ..]: its leaf children are single instances)
+    const float4 *inst_box;      // two-level scenes: per instance the box of its BLAS in OBJECT space (lo, hi): what the flat TLAS pass (k_tl_top_flat) tests a transformed ray against
+    const uint32_t *tri_packet;  // two-level scenes with the 8-wide layout: per shading record (InstanceDev::ts_base + triangle of the BLAS) its packet in wpackets — how k_shade<.., PAIRS> finds the triangle a key names
     const float4 *bnodes;        // rope nodes of all BLASes, 4 x float4 each; followed, in the same allocation, by
     const float4 *bpackets;      // their triangle packets (object space), 3 x float4 each
     uint32_t num_inst;
@@ -207,7 +209,7 @@ struct DeviceScene {
     MRTSceneStats stats{};
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};     // box of the whole tree (padded leaf boxes)
     // two-level scenes (two_level.hip)
-    DevBuf<InstanceDev> inst; DevBuf<uint32_t> tlas_index, wtlas_index; DevBuf<float4> bnodes;
+    DevBuf<InstanceDev> inst; DevBuf<uint32_t> tlas_index, wtlas_index, tri_packet; DevBuf<float4> bnodes, inst_box;
     uint32_t tlas_wcap = 0; int blas_wdepth = 0;               // 8-wide layout: node slots reserved for the TLAS in front of the BLASes, deepest BLAS (0: rope only)
     size_t bpackets_offset = 0; uint32_t num_inst = 0;
     std::vector<InstanceDev> h_inst;                           // host copy: transform updates rewrite the rows and rebuild the TLAS only

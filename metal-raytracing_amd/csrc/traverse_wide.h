@@ -120,7 +120,7 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
 
 // stack: depth x WIDE_STACK_LEVEL_BYTES of LDS for the wave (depth = the scene's wide-tree depth, <= WIDE_STACK)
 template <bool ANY, bool STATS = false, bool RUNTIME_ANY = false>
-MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES in LDS */, TravCounters *tc = nullptr, bool any_rt = false) {
+MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tmax, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES in LDS */, TravCounters *tc = nullptr, bool any_rt = false, uint32_t root = 0 /* the node the walk starts at: a BLAS root of a two-level scene, with the ray in that instance's object space */) {
     h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
     if (s.num_wnodes == 0) return false;
     const uint32_t lane = threadIdx.x & 63;
@@ -130,7 +130,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
     uint32_t sp = 0;
     uint32_t g_base = 0, g_mask = 0;      // node group: (permuted hit bits << 8) | imask
     uint32_t t_base = 0, t_mask = 0;      // triangle group: bit k = packet t_base + k still to test
-    uint32_t pending = 0; bool have_pending = true;     // start by entering the root
+    uint32_t pending = root; bool have_pending = true;     // start by entering the root
     for (;;) {
         const bool do_tri = t_mask != 0;
         if (!do_tri && !have_pending) {
@@ -257,6 +257,116 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
     return true;
 }
 
+// The same for TWO-LEVEL scenes (wnodes = [8-wide TLAS | BLASes], see traverse_wide_stream<TWO_LEVEL> below): one ray per lane walks both levels on one stack — at an instance it
+// parks the TLAS group, goes into object space (direction not renormalised: t stays the world distance), walks the BLAS and comes back.  The primary rays of a tile enter and
+// leave the same instances together, so the lanes stay in step across the level changes that put the stream loop's incoherent rays out of step.  The world ray is the caller's
+// (wo, wd: the camera position and the primary direction, live in registers anyway): nothing is parked in LDS.  g_mask: imask | hit bits << 8 | stack depth << 16 | entry depth << 24.
+// seed (SEED): (packet | instance << 24) already tested by the caller, its distance in tmax.  h.pk = the final hit in the same encoding; h.gid = the GLOBAL triangle id.
+template <bool SEED>
+MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const f3 wd, float tmax, uint32_t seed, TravHit &h, uint32_t *stack) {
+    const uint32_t lane = threadIdx.x & 63;
+    f3 o = wo, d = wd;
+    float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
+    bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    float best_t = tmax; uint32_t best_pk = 0xFFFFFFFFu;
+    uint32_t insts = 0;                                   // instance being walked | instance of the closest hit << 16
+    if (SEED && seed != 0xFFFFFFFFu) { best_pk = seed & 0xFFFFFFu; insts = (seed >> 24) << 16; }
+    uint32_t tl_pack = 0;                                 // the TLAS leaf's remaining instances while inside a BLAS: tri_base << 8 | mask
+    uint32_t g_base = 0, g_mask = s.num_wnodes != 0 ? 0x100u : 0u, t_base = 0, t_mask = 0;
+    for (;;) {
+        {   // nothing of the BLAS left (no triangle pending, no hit child, stack back at the entry depth): back to world space and to the TLAS group parked at entry
+            const uint32_t sp = (g_mask >> 16) & 0xFFu, isp = g_mask >> 24;
+            if (isp != 0u && t_mask == 0u && (g_mask & 0xFF00u) == 0u && sp == isp) {
+                o = wo; d = wd; ix = box_inv(d.x); iy = box_inv(d.y); iz = box_inv(d.z);
+                nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16;
+                t_base = tl_pack >> 8; t_mask = tl_pack & 0xFFu;
+            }
+        }
+        const bool in_blas = (g_mask >> 24) != 0u;
+        const bool has_inst = t_mask != 0u && !in_blas;          // at the TLAS level a pending "triangle" is an instance to enter
+        bool has_tri = t_mask != 0u && !has_inst;
+        uint32_t t_rest = t_mask & (t_mask - 1u);
+        bool want_node = t_rest == 0u && !has_inst;
+        uint32_t pending = 0, tri_pk = 0;
+        if (has_inst) {
+            const uint32_t k = (uint32_t)__ffs((int)t_mask) - 1u;
+            t_mask &= t_mask - 1u;
+            const uint32_t id = s.wtlas_index[t_base + k];
+            const InstanceDev &I = s.inst[id];
+            tl_pack = (t_base << 8) | t_mask;
+            uint32_t sp = (g_mask >> 16) & 0xFFu;
+            wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++;          // parked always, also without siblings left: the exit pops it
+            const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
+            o = oo; d = dd; ix = box_inv(d.x); iy = box_inv(d.y); iz = box_inv(d.z);
+            nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+            g_base = 0; g_mask = (sp << 24) | (sp << 16);
+            t_base = 0; t_mask = 0;
+            insts = (insts & 0xFFFF0000u) | id;
+            if (I.ntri <= 8u) { t_base = I.packet_base; t_mask = (1u << I.ntri) - 1u; t_rest = t_mask & (t_mask - 1u); has_tri = true; }      // a wall, the floor: its packets are the pending set
+            else { pending = I.wroot; want_node = true; }
+        }
+        else if (want_node) {
+            if ((g_mask & 0xFF00u) == 0) {
+                const uint32_t sp = (g_mask >> 16) & 0xFFu, isp = g_mask >> 24;
+                if (isp != 0u && sp == isp) want_node = false;          // the BLAS's last triangle is tested in this iteration; the lane leaves in the next
+                else if (sp == 0) { want_node = false; if (!has_tri) break; }
+                else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= ((sp - 1u) << 16) | (isp << 24); }
+            }
+            if (want_node) {
+                const uint32_t hits = (g_mask >> 8) & 0xFFu;
+                const uint32_t b = (uint32_t)__ffs((int)hits) - 1u;
+                g_mask &= ~(0x100u << b);
+                const uint32_t slot = b ^ oct;
+                pending = g_base + (uint32_t)__popc(g_mask & 0xFFu & ((1u << slot) - 1u));
+            }
+        }
+        float4 r0, r1, r2, n0, n1, n2, n3, n4;
+        asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r2.x), "=v"(r2.y), "=v"(r2.z));
+        asm volatile("" : "=v"(n0.x), "=v"(n0.y), "=v"(n0.z), "=v"(n0.w), "=v"(n1.x), "=v"(n1.y), "=v"(n1.z), "=v"(n1.w), "=v"(n2.x), "=v"(n2.y), "=v"(n2.z), "=v"(n2.w));
+        asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
+        r1.w = 0.0f; r2.w = 0.0f;
+        if (has_tri) {
+            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u; t_mask = t_rest;
+            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
+            r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
+        }
+        if (want_node) {
+            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+        }
+        if (has_tri) {
+            float t, U, V, ad;
+            if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
+                bool better = t < best_t || best_pk == 0xFFFFFFFFu;
+                if (!better) better = s.inst[insts & 0xFFFFu].gid_base + __float_as_uint(r0.w) < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);      // t == best_t: lowest global id
+                if (better) { best_t = t; best_pk = tri_pk; insts = (insts & 0xFFFFu) | (insts << 16); }
+            }
+        }
+        if (want_node) {
+            uint32_t node_hits, tri_hits;
+            wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            uint32_t sp = (g_mask >> 16) & 0xFFu;
+            const uint32_t isp = g_mask & 0xFF000000u;
+            if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
+            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            t_base = __float_as_uint(n1.y); t_mask = tri_hits;
+        }
+    }
+    h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = 0xFFFFFFFFu;
+    if (best_pk == 0xFFFFFFFFu) return false;
+    // id and barycentrics of the winning triangle, in the object space of its instance (the walk's own arithmetic)
+    const InstanceDev &I = s.inst[insts >> 16];
+    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
+    const float4 q0 = pk[0];
+    float t_;
+    (void)tri_test(q0, pk[1], pk[2], to_object_point(I, wo), to_object_dir(I, wd), 0.0f, __builtin_inff(), t_, h.U, h.V, h.ad);
+    h.gid = I.gid_base + __float_as_uint(q0.w);
+    h.pk = best_pk | ((insts >> 16) << 24);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-level stream traversal with lane refill (the "persistent wavefront + ray compaction" of BASELINE.json
 // configs[4]) on the wide layout.  rocprofv3 on the one-ray-per-lane kernel: VALUBusy 81 %, VALUUtilization 19 % —
@@ -306,6 +416,47 @@ struct SharedCounter {
     }
 };
 
+// Two-level scenes, binned form (renderer option tl_pairs).  The TLAS pass — this loop with a PairQueue — tests instances of at most eight triangles in place and,
+// instead of entering a larger one, appends {ray, instance} to a queue; a second launch walks every pair in object space with the FLATTENED loop (TWO_LEVEL = false, per-ray root:
+// ROOTS), its lanes never changing level, and folds the hits into the rays' results with atomics.  When the queue is full a lane enters the instance in place, as without a queue.
+struct NoPairs { static constexpr bool on = false; };
+struct PairQueue {
+    static constexpr bool on = true;
+    static constexpr uint32_t BLOCK = 256;            // pair slots a wave reserves at a time: ONE atomic on the queue's counter per 256 pairs (a counter word sustains ~88 returning
+                                                      // atomics per microsecond; one per wave and iteration — the first form — made the TLAS pass five times slower than the walk it replaces)
+    uint4 *__restrict__ pairs; uint32_t *__restrict__ count; uint32_t cap;
+    uint32_t *cursor;                                 // LDS, two words of this wave: {next free slot, end of the wave's block}; both 0 at the start
+    // called by the lanes that reached a large instance in this iteration (a divergent branch: the ballot sees exactly them); true = the pair is stored
+    MRT_DEV bool push(uint32_t ray_index, uint32_t inst, float tmax, uint32_t tagw) const {
+        const unsigned long long m = __ballot(1);
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t lane = threadIdx.x & 63, n = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint32_t cur = 0, fits = 0, fresh = 0xFFFFFFFFu;          // leader: the old block's cursor, how many of the n pairs it still takes, the new block (none / refused: ~0)
+        if ((int)lane == leader) {
+            cur = cursor[0]; const uint32_t end = cursor[1];
+            fits = min(n, end - cur);
+            if (fits < n) {
+                const uint32_t base = atomicAdd(count, BLOCK);
+                if (base < cap && cap - base >= BLOCK) { fresh = base; cursor[0] = base + (n - fits); cursor[1] = base + BLOCK; }
+                else { cursor[0] = end; }                           // the queue is full: the lanes beyond `fits` walk their instance in place
+            } else cursor[0] = cur + n;
+        }
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader); fits = (uint32_t)__builtin_amdgcn_readlane((int)fits, leader); fresh = (uint32_t)__builtin_amdgcn_readlane((int)fresh, leader);
+        uint32_t slot;
+        if (rank < fits) slot = cur + rank;
+        else if (fresh != 0xFFFFFFFFu) slot = fresh + (rank - fits);
+        else return false;
+        qstore(reinterpret_cast<float4 *>(&pairs[slot]), make_float4(__uint_as_float(ray_index), __uint_as_float(inst), tmax, __uint_as_float(tagw)));      // (written once, read once by the next launch)
+        return true;
+    }
+    // the whole wave, when it has no rays left: the unused rest of its block becomes pairs that name no ray (the BLAS pass skips them)
+    MRT_DEV void close() const {
+        const uint32_t lane = threadIdx.x & 63, cur = cursor[0], end = cursor[1];
+        for (uint32_t k = cur + lane; k < end; k += 64) qstore(reinterpret_cast<float4 *>(&pairs[k]), make_float4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f));
+        cursor[0] = end;
+    }
+};
+
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -315,8 +466,9 @@ struct SharedCounter {
 // TLAS level), the stack depth in bits 16..20.  `stack` then starts with WIDE_WORLD_RAY_BYTES of parked world rays.
 // SEED (primary rays with a hint, k_trace_primary_wide_stream): `fetch` also returns a candidate hit — a packet (| instance << 24) whose distance it has already put
 // into the ray's limit word — and the walk starts with it as its closest hit so far; TravHit::pk at emit time is the final hit in the same encoding.
-template <bool TWO_LEVEL = false, bool SEED = false, class Chunks, class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr) {
+// ROOTS (with TWO_LEVEL = false): `fetch` also returns the node the ray's walk starts at (the root of its instance's BLAS in the shared node array) instead of node 0.
+template <bool TWO_LEVEL = false, bool SEED = false, bool ROOTS = false, class Pairs = NoPairs, class Chunks, class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr, Pairs pq = Pairs{}) {
     const uint32_t lane = threadIdx.x & 63;
     float *const wray = reinterpret_cast<float *>(stack);      // [6][64]: o.xyz, d.xyz of the lane's ray in world space (TWO_LEVEL)
     if (TWO_LEVEL) stack += WIDE_WORLD_RAY_BYTES / 4u;
@@ -325,8 +477,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     const unsigned long long lt = (1ull << lane) - 1ull;
     // prefetched batch: rays batch_base .. batch_base + batch_n - 1, one per lane; pB.w = tag | any-hit flag << 31
     float4 pA = make_float4(0, 0, 0, 0), pB = pA;
-    uint32_t pS = 0xFFFFFFFFu;                        // SEED: the prefetched ray's candidate
+    uint32_t pS = 0xFFFFFFFFu;                        // SEED: the prefetched ray's candidate; ROOTS: its start node
     uint32_t batch_n = 0, batch_used = 0;             // wave-uniform; used == n -> nothing prefetched
+    uint32_t batch_first = 0, qi = 0;                 // Pairs: index of the batch's first ray in the launch's queue, and of the lane's own ray
+    bool pq_refused = false;                          // Pairs: the queue refused one of this lane's pairs (it is full)
     uint32_t cur = 0, end = 0;                        // unfetched part of the current chunk
     bool more = true;                                 // the chunk source may have more
     bool draining = false;                            // nothing left to hand out: the wave runs until its last rays are done
@@ -373,9 +527,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             if (batch_used >= batch_n) {                        // prefetch the next (up to) 64 rays (coalesced), all lanes
                 if (cur >= end && more) more = next_chunk(cur, end);
                 batch_n = cur < end ? min(64u, end - cur) : 0u; batch_used = 0;
+                if (Pairs::on) batch_first = cur;
                 if (lane < batch_n) {
                     uint32_t tag = 0, is_any = 0;
-                    if constexpr (SEED) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any);
+                    if constexpr (SEED || ROOTS) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any);
                     pB.w = __uint_as_float((tag & 0x7FFFFFFFu) | (is_any << 31));
                 }
                 cur += batch_n;
@@ -389,16 +544,17 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 const int sl = (int)(take ? batch_used + rank : lane);
                 const float ax_ = __shfl(pA.x, sl), ay_ = __shfl(pA.y, sl), az_ = __shfl(pA.z, sl), aw_ = __shfl(pA.w, sl);
                 const float bx_ = __shfl(pB.x, sl), by_ = __shfl(pB.y, sl), bz_ = __shfl(pB.z, sl), bw_ = __shfl(pB.w, sl);
-                const uint32_t seed_ = SEED ? (uint32_t)__shfl((int)pS, sl) : 0xFFFFFFFFu;
+                const uint32_t seed_ = (SEED || ROOTS) ? (uint32_t)__shfl((int)pS, sl) : 0xFFFFFFFFu;
                 if (take) {
                     o = mk3(ax_, ay_, az_); d = mk3(bx_, by_, bz_); ix = box_inv(bx_); iy = box_inv(by_); iz = box_inv(bz_);
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                     best_t = aw_; best_pk = 0xFFFFFFFFu;
                     tagw = __float_as_uint(bw_);
                     // enter the root as the only "hit child" of a pseudo group: base 0, no internal-child bits -> node 0; empty stack
-                    g_base = 0; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;
+                    g_base = ROOTS ? seed_ : 0u; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;      // (the pseudo group has no internal-child bits: its one "hit child" is node g_base itself)
                     if (SPEC) { u_base = 0; u_mask = 0; }
                     live = true;
+                    if (Pairs::on) qi = batch_first + (uint32_t)sl;
                     if (TWO_LEVEL) {
                         wray[lane] = ax_; wray[64 + lane] = ay_; wray[128 + lane] = az_; wray[192 + lane] = bx_; wray[256 + lane] = by_; wray[320 + lane] = bz_;
                         insts = 0; tl_pack = 0;
@@ -462,6 +618,23 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     help_pk = o_tb + bit;
                 }
                 if ((int)lane == owner) t_mask &= ~((f_lo | f_hi) & o_tm);      // these are being tested now
+            }
+        }
+        if constexpr (Pairs::on) {
+            // TLAS pass: every LARGE instance among the lane's pending ones goes to the pair queue now (a short divergent loop: at most eight trips); the small ones stay pending and are
+            // entered in place, one per iteration, as without a queue.  A lane whose pending instances were all large goes on to its next node in this same iteration.
+            if (live && t_mask != 0u && !in_blas && !pq_refused) {
+                uint32_t rest = t_mask, keep = 0u;
+                while (rest != 0u) {
+                    const uint32_t k = (uint32_t)__ffs((int)rest) - 1u; rest &= rest - 1u;
+                    uint32_t tl_slot = t_base + k;
+                    MRT_BOUND(tl_slot, s.num_wtlas, 3);
+                    uint32_t id = s.wtlas_index[tl_slot];
+                    MRT_BOUND(id, s.num_inst, 4);
+                    if (s.inst[id].ntri > 8u && !pq_refused) { if (!pq.push(qi, id, best_t, tagw)) { pq_refused = true; keep |= 1u << k; } }      // refused (the queue is full): this lane walks its large instances in place from here on
+                    else keep |= 1u << k;
+                }
+                t_mask = keep;
             }
         }
         const bool has_inst = TWO_LEVEL && live && t_mask != 0 && !in_blas;      // at the TLAS level a pending "triangle" is an instance to enter

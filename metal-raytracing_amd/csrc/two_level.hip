@@ -242,6 +242,14 @@ __global__ void k_relocate_wide(float4 *__restrict__ wnodes, uint32_t n, uint32_
     wnodes[WNODE_STRIDE * (size_t)i + 1] = n1;
 }
 
+// tri_packet[ts_base + t] = the packet (absolute index in wpackets) of triangle t of a BLAS: the inverse of the packets' id words
+__global__ void k_packet_map(const float4 *__restrict__ wpackets, uint32_t packet_base, uint32_t nt, uint32_t ts_base, uint32_t *__restrict__ tri_packet) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nt) return;
+    const uint32_t local = __float_as_uint(wpackets[WPK * (size_t)(packet_base + p)].w);
+    if (local < nt) tri_packet[ts_base + local] = packet_base + p;
+}
+
 // The per-node checks of validate_layout for the nodes [first, last) of the 8-wide array that are NOT TLAS slots, on the device: the first violation (lowest node) is left in
 // *err as node << 8 | code.  (The host loop over 73 K downloaded nodes was 2.2 of DragonScene's 9.1 ms commit; the TLAS slots, a handful of nodes whose leaves name instances, stay on the host.)
 enum { V_OK = 0, V_ORDER = 1, V_RANGE = 2, V_INTO_TLAS = 3, V_BOTH = 4, V_MASK = 5, V_PACKETS = 6 };
@@ -371,6 +379,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
     std::vector<Box> boxes(I);
     std::vector<uint32_t> live;
     std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
+    std::vector<float4> h_box(2 * std::max<size_t>(I, 1), make_float4(0, 0, 0, 0));      // per instance, the box of its BLAS in OBJECT space (the flat TLAS pass tests the transformed ray against it); lo > hi: no ray enters
     for (size_t i = 0; i < I; i++) {
         InstanceDev &d = out.h_inst[i];
         const float *xf = meshes[i].xf;
@@ -378,11 +387,17 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
         float rows[3][4];
         const bool ok = invert_affine(xf, rows);
         for (int r = 0; r < 3; r++) d.w2o[r] = ok ? make_float4(rows[r][0], rows[r][1], rows[r][2], rows[r][3]) : make_float4(0, 0, 0, 0);
-        if (ok && d.ntri > 0) { boxes[i] = instance_box(xf, &out.blas_lo[3 * (size_t)d.blas], &out.blas_hi[3 * (size_t)d.blas]); live.push_back((uint32_t)i); }
+        if (ok && d.ntri > 0) {
+            boxes[i] = instance_box(xf, &out.blas_lo[3 * (size_t)d.blas], &out.blas_hi[3 * (size_t)d.blas]); live.push_back((uint32_t)i);
+            h_box[2 * i] = make_float4(out.blas_lo[3 * (size_t)d.blas], out.blas_lo[3 * (size_t)d.blas + 1], out.blas_lo[3 * (size_t)d.blas + 2], 0);
+            h_box[2 * i + 1] = make_float4(out.blas_hi[3 * (size_t)d.blas], out.blas_hi[3 * (size_t)d.blas + 1], out.blas_hi[3 * (size_t)d.blas + 2], 0);
+        } else { h_box[2 * i] = make_float4(1, 1, 1, 0); h_box[2 * i + 1] = make_float4(-1, -1, -1, 0); }
     }
     TlasBuilder tb(boxes);
     tb.order = live;
     if (!live.empty()) tb.build(0, (uint32_t)live.size(), NODE_TERM, 1);
+    MRT_HIP(out.inst_box.alloc(h_box.size()));
+    MRT_HIP(hipMemcpyAsync(out.inst_box.p, h_box.data(), h_box.size() * 16, hipMemcpyHostToDevice, stream));
     MRT_HIP(out.inst.alloc(std::max<size_t>(I, 1)));
     MRT_HIP(out.tlas_index.alloc(std::max<size_t>(tb.order.size(), 1)));
     MRT_HIP(out.nodes.alloc(std::max<size_t>(tb.nodes.size(), 8))); out.packets_offset = std::max<size_t>(tb.nodes.size(), 8);
@@ -469,7 +484,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     }
     // 8-wide layout: [TLAS slots | BLAS 0 | BLAS 1 ...] with absolute indices; its packets are in the wide builder's own order (wpackets)
     all_wide = all_wide && wnodes_total < (1u << 24) && WNODE_STRIDE == 5;
-    out.wnodes.release(); out.wpackets.release(); out.tlas_wcap = 0; out.blas_wdepth = 0;
+    out.wnodes.release(); out.wpackets.release(); out.tri_packet.release(); out.tlas_wcap = 0; out.blas_wdepth = 0;
     if (all_wide) {
         MRT_HIP(out.wnodes.alloc(WNODE_STRIDE * wnodes_total)); MRT_HIP(out.wpackets.alloc(std::max<size_t>(WPK * packets_total, WPK)));
         MRT_HIP(hipMemsetAsync(out.wnodes.p, 0, out.wnodes.bytes(), stream));
@@ -479,6 +494,13 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
             MRT_HIP(hipMemcpyAsync(out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], blas[b].wnodes.p, wn * WNODE_STRIDE * 16, hipMemcpyDeviceToDevice, stream));
             MRT_HIP(hipMemcpyAsync(out.wpackets.p + WPK * (size_t)packet_base[b], blas[b].wpackets.p, nt * 16 * WPK, hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k_relocate_wide, dim3((uint32_t)((wn + 255) / 256)), dim3(256), 0, stream, out.wnodes.p + WNODE_STRIDE * (size_t)wnode_base[b], (uint32_t)wn, wnode_base[b], packet_base[b]);
+        }
+        // triangle -> packet, for the binned walk's results (renderer.hip k_shade<.., PAIRS>)
+        MRT_HIP(out.tri_packet.alloc(std::max<size_t>(ts_total, 1)));
+        MRT_HIP(hipMemsetAsync(out.tri_packet.p, 0, out.tri_packet.bytes(), stream));
+        for (size_t b = 0; b < B; b++) {
+            const uint32_t nt = (uint32_t)blas[b].stats.triangles;
+            if (nt) hipLaunchKernelGGL(k_packet_map, dim3((nt + 255) / 256), dim3(256), 0, stream, (const float4 *)out.wpackets.p, packet_base[b], nt, ts_base[b], out.tri_packet.p);
         }
         MRT_HIP(hipGetLastError());
         out.tlas_wcap = (uint32_t)tlas_wcap; out.blas_wdepth = blas_wdepth;

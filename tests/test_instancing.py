@@ -279,6 +279,46 @@ def test_commit_validates_every_index_of_the_layout(mrt, gpu_ctx, instancing):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["six_instances", "dragon4"])
+def test_binned_two_level_walk_is_the_one_loop_walk(mrt, gpu_ctx, scene_name):
+    """Bounce and shadow rays of a two-level scene as TLAS pass + BLAS pass over (ray, instance) pairs (tl_pairs = 1, default) against the one-loop walk of both levels
+    (tl_pairs = 0): same image bit for bit, same ray counts; also with a pair queue so small that almost every push is refused and walks its instance in place, with
+    one-frame passes, and with four-frame passes on three lanes (the accumulate's zeroing of the pair counters)."""
+    w, h = (160, 96) if scene_name == "six_instances" else (256, 144)
+    sc = _scene(mrt, (w, h)) if scene_name == "six_instances" else mrt.InstancedDragonScene((w, h))
+    imgs = {}
+    for name, opts in (("one_loop", {"tl_pairs": 0}), ("binned", {}), ("binned_tiny_queue", {"tl_pair_cap": 257}), ("binned_tlas_walk", {"tl_pairs": 2}), ("binned_tlas_walk_tiny_queue", {"tl_pairs": 2, "tl_pair_cap": 600}), ("binned_one_frame_passes", {"frame_batch": 1}),
+                       ("binned_three_lanes", {"frame_batch": 4, "frames_in_flight": 3})):
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
+        for k, v in opts.items(): r.set_option(k, v)
+        r.draw(5, wait=True); r.draw(20, wait=True)
+        imgs[name] = (r.accumulation().copy(), r.stats.closest_rays, r.stats.shadow_rays)
+        r.close()
+    for name, v in imgs.items():
+        assert np.array_equal(v[0].view(np.uint32), imgs["one_loop"][0].view(np.uint32)), name
+        assert v[1:] == imgs["one_loop"][1:], name
+
+
+@pytest.mark.gpu
+def test_megakernel_refuses_what_it_cannot_render(mrt, gpu_ctx):
+    """megakernel = 1 is the one-launch-per-frame mode of flattened scenes on the 8-wide layout: a two-level scene, the materials extension or a scene without that layout
+    get MRT_ERR_UNSUPPORTED and a message naming the reason — not a silent fall-back to the pipeline — and the renderer keeps working once the option is cleared."""
+    from metal_raytracing_amd._ffi import MRTError
+    w, h = 64, 48
+    sc = _scene(mrt, (w, h))
+    for sopt, ropt, why in (({"instancing": 1}, {}, "two-level"), ({}, {"materials": 1}, "materials"), ({"wide": 0}, {}, "8-wide")):
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
+        for k, v in ropt.items(): r.set_option(k, v)
+        r.set_option("megakernel", 1)
+        with pytest.raises(MRTError) as e:
+            r.draw(1, wait=True)
+        assert why in str(e.value) and "megakernel" in str(e.value), str(e.value)
+        r.set_option("megakernel", 0); r.draw(2, wait=True)
+        assert np.isfinite(r.accumulation()).all() and r.stats.frames == 2
+        r.close()
+
+
+@pytest.mark.gpu
 def test_flattened_scene_recommits_new_transforms_without_its_geometry(mrt, gpu_ctx):
     """An animated FLATTENED scene: mrt_scene_set_instance_transform + mrt_scene_commit rebuilds the world-space BVH from the geometry the previous commit left on the
     device (no staging, no upload of positions / normals / indices).  The image must be the one a scene created with those transforms gives, bit for bit, twice in a
