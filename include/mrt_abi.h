@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 1
+#define MRT_ABI_VERSION 2      /* 2: MRTSceneStats grew (wide_layout, wide_depth); the renderer's option keys split into mrt_renderer_set_option (six host keys) and mrt_debug_renderer_set_option */
 
 /* ---------------------------------------------------------------- status codes */
 enum {

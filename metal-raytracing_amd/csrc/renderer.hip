@@ -281,355 +281,8 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         );
 }
 
-// ------------------------------------------------------------------ two-level scenes, binned: TLAS pass + BLAS pass (renderer option tl_pairs, default)
-// In the one-loop walk of a two-level scene (k_trace_mixed_wide_persist<true>) the lanes of a wave are out of step — node / triangle / level change — and dragon x 4 costs
-// 17.1 wave-iterations per 64 bounce rays where the flattened scene costs 13.5 (tools/two_level_binning_probe.py).  Here the bounce / shadow rays of a shade pass take two launches:
-//   k_tl_top    the same loop, but an instance of more than eight triangles is not entered: {ray, instance} goes to a queue (ballot-compacted, one atomic per wave and iteration).
-//               What a ray finds at the TLAS level (walls, floor: tested in place) becomes its result so far: a 64-bit key (t bits << 32 | global triangle id), ~0 = nothing;
-//               a shadow ray not occluded so far sets its pixel's byte.
-//   k_tl_blas   every pair walked in its instance's object space by the FLATTENED loop (per-ray root; the ray transformed once, at fetch), starting with the distance its ray
-//               has so far; a hit is folded into the ray's key with atomicMin — minimum t, ties to the lowest global id: the one-loop walk's result — or clears the pixel's byte.
-// k_shade<.., PAIRS> of the next bounce turns a key back into a hit record (the winning triangle re-tested in object space: the traversal's own arithmetic).
-__global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
-                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                 uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
-    extern __shared__ uint32_t stk_dyn[];
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
-    if (blockIdx.x * chunk >= n) return;
-    uint32_t *const cursor = stk_dyn + stack_words;          // two words behind the wave's stack: its block of the pair queue
-    cursor[0] = 0; cursor[1] = 0;
-    const PairQueue pq{pairs, pair_count, pair_cap, cursor};
-    traverse_wide_stream<true, false, false, PairQueue>(s, SharedCounter{work, n, chunk}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
-            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
-            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
-            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word carries the throughput chain
-            else tag = __float_as_uint(B.w);            // a shadow ray reports to its pixel's byte
-        },
-        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
-            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }          // not occluded at the TLAS level: lit unless one of its pairs finds an occluder
-            else __builtin_nontemporal_store(hit ? ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | h.gid : ~0ull, &keys[j]);      // (+ 0.0f: a distance of -0 must order as 0)
-        }, nullptr, pq);
-    pq.close();
-}
-// The TLAS pass of a scene with FEW instances (at most TL_FLAT_MAX_INSTANCES; DragonScene x 4 has ten), without a tree: one ray per lane, every lane visits every instance in the same
-// order — the rows and boxes are wave-uniform (scalar loads), nothing diverges, nothing is gathered, no stack, no refill.  First the instances of at most eight triangles, tested in
-// place in object space (they give the ray its bound); then the large ones: the ray against the instance's BLAS box in object space, and a pair for the BLAS pass where it enters
-// before that bound.  A refused pair (queue full) is walked here, one ray per lane (traverse_wide from the BLAS root).  Pairs leave instance-major, so the BLAS pass's waves see one
-// instance at a time.  The stream walk of the 8-wide TLAS (k_tl_top) spent 1.16 ms per launch on the 12 M rays of an 8-frame pass of dragon x 4, refilling lanes every other iteration; this takes them in 0.53 ms (profiles/r04_two_level_binned_ab.txt).
-constexpr uint32_t TL_FLAT_MAX_INSTANCES = 64;
-__global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
-                                                    const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                    uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
-    extern __shared__ uint32_t stk_dyn[];
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n = n_next + (uint32_t)(c >> 32);
-    if (blockIdx.x * 64u >= n) return;
-    uint32_t *const cursor = stk_dyn + stack_words;
-    cursor[0] = 0; cursor[1] = 0;
-    const PairQueue pq{pairs, pair_count, pair_cap, cursor};
-    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {          // (wave-uniform) the launch has as many waves as the chip has slots for them
-    const uint32_t i = base + threadIdx.x;
-    const bool active = i < n, sh = i >= n_next;
-    const uint32_t j = sh ? i - n_next : i;
-    float4 A = make_float4(0.0f, 0.0f, 0.0f, -1.0f), B = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-    if (active) { A = qload(sh ? &srayA[j] : &rayA[j]); B = qload(sh ? &srayB[j] : &rayB[j]); if (!sh) A.w = __builtin_inff(); }
-    const f3 o = mk3(A), d = mk3(B);
-    const uint32_t tagw = sh ? (__float_as_uint(B.w) | 0x80000000u) : j;      // what the BLAS pass reports to: the pixel's byte (shadow) / the ray's key
-    float best_t = A.w; uint32_t best_gid = 0xFFFFFFFFu; bool done = !active;
-    for (uint32_t id = 0; id < s.num_inst; id++) {                  // the small instances, in place
-        const InstanceDev &I = s.inst[id];
-        if (I.ntri == 0u || I.ntri > 8u || s.inst_box[2 * id].x > s.inst_box[2 * id + 1].x) continue;          // (wave-uniform)
-        const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
-        for (uint32_t k = 0; k < I.ntri; k++) {
-            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)(I.packet_base + k);
-            const float4 q0 = pk[0], q1 = pk[1], q2 = pk[2];
-            float t, U, V, ad;
-            if (!done && tri_test(q0, q1, q2, oo, dd, 0.0f, best_t, t, U, V, ad)) {
-                const uint32_t gid = I.gid_base + __float_as_uint(q0.w);
-                if (sh) done = true;                                // occluded: lit stays 0
-                else if (t < best_t || gid < best_gid) { best_t = t; best_gid = gid; }      // (t <= best_t here: ties go to the lowest global id)
-            }
-        }
-    }
-    for (uint32_t id = 0; id < s.num_inst; id++) {                  // the large instances: a pair where the ray enters the BLAS's box before its bound
-        const InstanceDev &I = s.inst[id];
-        const float4 blo = s.inst_box[2 * id], bhi = s.inst_box[2 * id + 1];
-        if (I.ntri <= 8u || blo.x > bhi.x) continue;
-        const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
-        const float ix = box_inv(dd.x), iy = box_inv(dd.y), iz = box_inv(dd.z);
-        const bool enters = !done && rope_box_hit(blo, bhi, ix, iy, iz, -(oo.x * ix), -(oo.y * iy), -(oo.z * iz), 0.0f, best_t);
-        if (enters) {
-            if (!pq.push(i, id, best_t, tagw)) {                    // the queue is full: this instance is walked here
-                TravHit h;
-                if (traverse_wide<false, false, true>(s, oo, dd, 0.0f, best_t, h, stk_dyn, nullptr, sh, I.wroot)) {
-                    if (sh) done = true;
-                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; } }
-                }
-            }
-        }
-    }
-    if (active) {
-        if (sh) { if (!done) lit[4 * (size_t)(tagw & 0x7FFFFFFFu)] = 1; }          // not occluded so far: lit unless one of its pairs finds an occluder
-        else __builtin_nontemporal_store(best_gid != 0xFFFFFFFFu ? ((unsigned long long)__float_as_uint(best_t + 0.0f) << 32) | best_gid : ~0ull, &keys[j]);
-    }
-    }
-    pq.close();
-}
-__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
-                                                                   const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
-    extern __shared__ uint32_t stk_dyn[];
-    const uint32_t n_next = (uint32_t)*counts, np = min(*pair_count, pair_cap / PairQueue::BLOCK * PairQueue::BLOCK);        // whole blocks only (blocks beyond the capacity were refused — their rays walked in place — but counted)
-    if (blockIdx.x * chunk >= np) return;
-    traverse_wide_stream<false, false, true>(s, SharedCounter{work, np, chunk}, stk_dyn,
-        [&](uint32_t k, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, uint32_t &root) {
-            const float4 Pf = qload(reinterpret_cast<const float4 *>(&pairs[k]));
-            const uint32_t i = __float_as_uint(Pf.x), id = __float_as_uint(Pf.y);
-            if (i == 0xFFFFFFFFu) {          // the unused rest of a wave's block: a ray that cannot hit anything
-                A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); tag = k; is_any = 1u; root = 0u;
-                return;
-            }
-            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
-            const float4 Aw = qload(sh ? &srayA[j] : &rayA[j]), Bw = qload(sh ? &srayB[j] : &rayB[j]);
-            const InstanceDev &I = s.inst[id];
-            const f3 o = to_object_point(I, mk3(Aw)), d = to_object_dir(I, mk3(Bw));        // direction not renormalised: t stays the world distance
-            float tmax = Aw.w;
-            if (!sh) { const unsigned long long key = keys[j]; tmax = key == ~0ull ? __builtin_inff() : __uint_as_float((uint32_t)(key >> 32)); }      // what the ray has so far (TLAS-level hits; other pairs of the same ray may shorten it further while this one walks)
-            A = make_float4(o.x, o.y, o.z, tmax); B = make_float4(d.x, d.y, d.z, 0.0f);
-            tag = k; is_any = sh ? 1u : 0u; root = I.wroot;
-        },
-        [&](uint32_t k, bool is_any, bool hit, const TravHit &h) {
-            if (!hit) return;
-            const uint4 P = pairs[k];
-            if (is_any) lit[4 * (size_t)(P.w & 0x7FFFFFFFu)] = 0;          // occluded inside this instance
-            else atomicMin(&keys[P.x], ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | (unsigned long long)(s.inst[P.y].gid_base + h.gid));      // (h.gid: the triangle's id inside its BLAS)
-        });
-}
-
-// ------------------------------------------------------------------ one launch per frame: the wave-level megakernel (option megakernel = 1)
-// The reference is ONE kernel per frame (Raytracing.metal:156-405).  The wavefront pipeline above is faster in throughput (its shading runs at
-// full lane width, its traversal launches are large) but a single frame pays eight dependent launches, each with its own ramp-up and tail:
-// 2.07 ms for a frame whose arithmetic is 0.65 ms.  Here every lane of a persistent wave carries a whole PATH: primary ray -> closest hit ->
-// shade -> shadow ray (any hit) -> bounce ray -> ... on the 8-wide layout with the LDS stack of traverse_wide.h; finished rays are serviced
-// (shaded, turned into their follow-up ray, or replaced by the next pixel) whenever a quarter of the wave is waiting, and the pixel's running
-// average is written when its path ends (Raytracing.metal:394-403).  No ray queues, no k_shade, no k_accumulate.
-// One pixel belongs to one lane from start to end, so no atomics on the image; pixels are pulled 64 slots at a time from a shared counter.
-// Restates the shading of k_shade<false> (same expressions, same order: the image is bit-identical to the wavefront pipeline's and the oracle's).
-__global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds, const float4 *__restrict__ prev, float4 *__restrict__ dst,
-                                                      uint32_t *__restrict__ work, unsigned long long *__restrict__ totals, uint32_t primary) {
-    extern __shared__ uint32_t stk_dyn[];
-    uint32_t *stack = stk_dyn;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&totals[2], (unsigned long long)primary);
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t n_slots = fp.capacity;
-    // prefetched pixels: slot batch_base + lane -> primary direction + pixel index (0xFFFFFFFF: slot outside the image)
-    f3 pd = mk3(0, 0, 1); uint32_t ppix = 0xFFFFFFFFu;
-    uint32_t batch_n = 0, batch_used = 0, batch_base = 0;
-    bool more = true;
-    // path state of the lane
-    bool has_path = false, live = false, is_shadow = false, pending = false;
-    uint32_t pix = 0, pslot = 0; int bounce = 0;      // pixel (accumulation targets) and slot (seed table) of the lane's path
-    f3 thr = mk3(1, 1, 1), rad = mk3(0, 0, 0), con = mk3(0, 0, 0), ndir = mk3(0, 1, 0);
-    uint32_t n_closest = 0, n_shadow = 0;
-    // ray + traversal state (traverse_wide_stream)
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1); float ix = 0, iy = 0, iz = 0; bool nx = false, ny = false, nz = false; uint32_t oct = 0;
-    float best_t = 0.0f; uint32_t best_pk = 0xFFFFFFFFu;
-    uint32_t g_base = 0, g_mask = 0, t_base = 0, t_mask = 0;
-    auto start_ray = [&](f3 ro, f3 rd, float tmax) {
-        o = ro; d = rd; ix = box_inv(rd.x); iy = box_inv(rd.y); iz = box_inv(rd.z);
-        nx = rd.x < 0.0f; ny = rd.y < 0.0f; nz = rd.z < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-        best_t = tmax; best_pk = 0xFFFFFFFFu;
-        g_base = 0; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;
-        live = true;
-    };
-    for (;;) {
-        const unsigned long long m_wait = __ballot(!live);
-        if ((uint32_t)__popcll(m_wait) >= (uint32_t)WIDE_REFILL_AT || m_wait == ~0ull) {
-            // ---- 1. lanes whose ray has finished
-            if (has_path && !live) {
-                bool end_path = false;
-                if (is_shadow) {
-                    if (best_pk == 0xFFFFFFFFu) rad = rad + con;                                   // :371-373 (unoccluded)
-                    is_shadow = false;
-                    if (pending) { pending = false; bounce++; n_closest++; start_ray(o, ndir, __builtin_inff()); }      // the bounce ray leaves from the same offset point (:390)
-                    else end_path = true;
-                } else if (best_pk == 0xFFFFFFFFu) end_path = true;                                // :246-247 miss terminates the path
-                else {
-                    // hit record of the winning triangle (recomputed: same arithmetic as the traversal's test)
-                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
-                    const float4 q0 = pk[0];
-                    float t_, U, V, ad;
-                    (void)tri_test(q0, pk[1], pk[2], o, d, 0.0f, __builtin_inff(), t_, U, V, ad);
-                    const uint32_t gid = __float_as_uint(q0.w);
-                    const float bu = U / ad, bv = V / ad;
-                    const uint4 ts = s.tri_shade[gid];
-                    const uint32_t inst = ts.w >> 16, geom = ts.w & 0xFFFFu;
-                    const f3 P = o + d * best_t;                                                   // :261
-                    const float bw = 1.0f - bu - bv;                                               // :63-64
-                    const f3 n_obj = (bu * mk3(s.normals[ts.y]) + bv * mk3(s.normals[ts.z])) + bw * mk3(s.normals[ts.x]);   // :66-72
-                    const f3 c0 = mk3(s.inst_cols[inst * 4 + 0]), c1 = mk3(s.inst_cols[inst * 4 + 1]), c2 = mk3(s.inst_cols[inst * 4 + 2]);
-                    const f3 n_w = mk3((c0.x * n_obj.x + c1.x * n_obj.y) + c2.x * n_obj.z,
-                                       (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
-                                       (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);        // :267
-                    const f3 nrm = normalize3(n_w);                                                // :268
-                    const f3 surf = mk3(s.base_color[inst * (uint32_t)s.max_sub + geom]);          // :262-269
-                    const int idx = (int)(seeds[pslot] + fp.sampleIndex);
-                    const int dim0 = 2 + bounce * 5;
-                    const float ls = halton_dev(idx, dim0 + 0);                                    // :272
-                    const int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);       // :273
-                    const LightDev L = s.lights[li];
-                    const int ltype = __float_as_int(L.position.w);
-                    f3 ldir, lcol; float ldist;
-                    if (ltype == MRTLightTypeAreaLight) {                                          // :281-290, :94-128
-                        const float ax = halton_dev(idx, dim0 + 1) * 2.0f - 1.0f;
-                        const float ay = halton_dev(idx, dim0 + 2) * 2.0f - 1.0f;
-                        const f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
-                        ldir = sp - P;
-                        ldist = length3(ldir);
-                        const float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-                        ldir = ldir * inv;
-                        lcol = mk3(L.color) * (inv * inv);
-                        lcol = lcol * saturatef(dot3(neg3(ldir), mk3(L.forward)));
-                    } else if (ltype == MRTLightTypeSpotlight) {                                   // :292-316
-                        ldir = mk3(L.position) - P;
-                        ldist = length3(ldir);
-                        const float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-                        ldir = ldir * inv;
-                        lcol = mk3(0, 0, 0);
-                        const float spot = dot3(neg3(ldir), mk3(L.dirn));
-                        if (spot > L.dirn.w) lcol = (mk3(L.color) * inv) * inv;
-                    } else if (ltype == MRTLightTypePointlight) {                                  // :317-322
-                        ldir = mk3(L.position) - P;
-                        ldist = length3(ldir);
-                        const float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-                        ldir = ldir * inv;
-                        lcol = (mk3(L.color) * inv) * inv;
-                    } else {                                                                       // :323-327
-                        ldir = neg3(mk3(L.dirn));
-                        ldist = __builtin_inff();
-                        lcol = mk3(L.color);
-                    }
-                    lcol = lcol * saturatef(dot3(nrm, ldir));                                      // :331
-                    lcol = lcol * (float)fp.lightCount;                                            // :335
-                    thr = thr * surf;                                                              // :339
-                    const bool want_shadow = length3(lcol) > 0.0001f;                              // :341
-                    const bool want_next = bounce + 1 < fp.max_bounces;
-                    if (want_next) {
-                        const float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
-                        ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);       // :387-388
-                    }
-                    const f3 off = P + nrm * 1e-3f;                                                // :350, :390
-                    if (want_shadow) { con = lcol * thr; pending = want_next; is_shadow = true; n_shadow++; start_ray(off, ldir, ldist - 1e-3f); }   // :356, :372
-                    else if (want_next) { bounce++; n_closest++; start_ray(off, ndir, __builtin_inff()); }
-                    else end_path = true;
-                }
-                if (end_path) {                                                                    // :394-403
-                    float4 c = make_float4(rad.x, rad.y, rad.z, 1.0f);
-                    if (fp.frameIndex > 0) {
-                        const float4 p = prev[pix];
-                        const float fi = (float)fp.frameIndex, den = (float)(fp.frameIndex + 1);
-                        c.x = (rad.x + p.x * fi) / den; c.y = (rad.y + p.y * fi) / den; c.z = (rad.z + p.z * fi) / den;
-                    }
-                    dst[pix] = c;
-                    has_path = false;
-                }
-            }
-            // ---- 2. lanes without a path take the next pixels
-            if (batch_used >= batch_n && more) {                       // prefetch 64 pixel slots: primary rays generated by the whole wave
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work, 64u);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n_slots) { more = false; batch_n = batch_used = 0; }
-                else {
-                    batch_n = min(64u, n_slots - base); batch_used = 0; batch_base = base;
-                    int x, y; ppix = 0xFFFFFFFFu;
-                    if (lane < batch_n && slot_to_pixel(fp, base + lane, x, y)) {
-                        f3 org; primary_ray(fp, seeds, base + lane, x, y, org, pd);
-                        ppix = (uint32_t)y * (uint32_t)fp.width + (uint32_t)x;
-                    }
-                }
-            }
-            const unsigned long long m_free = __ballot(!has_path);
-            const uint32_t avail = batch_n - batch_used, n_free = (uint32_t)__popcll(m_free);
-            if (avail != 0 && n_free != 0) {
-                const uint32_t rank = (uint32_t)__popcll(m_free & lt);
-                const bool take = !has_path && rank < avail;
-                const int sl = (int)(take ? batch_used + rank : lane);
-                const float dx_ = __shfl(pd.x, sl), dy_ = __shfl(pd.y, sl), dz_ = __shfl(pd.z, sl);
-                const uint32_t px_ = (uint32_t)__shfl((int)ppix, sl);
-                if (take && px_ != 0xFFFFFFFFu) {
-                    has_path = true; is_shadow = false; pending = false; pix = px_; pslot = batch_base + (uint32_t)sl; bounce = 0;
-                    thr = mk3(1.0f, 1.0f, 1.0f); rad = mk3(0.0f, 0.0f, 0.0f);                     // :226-227
-                    n_closest++;
-                    start_ray(mk3(fp.cam_pos), mk3(dx_, dy_, dz_), __builtin_inff());              // :214-221
-                }
-                batch_used += min(avail, n_free);
-                continue;
-            }
-            if (__ballot(has_path) == 0ull) { if (!more) break; else continue; }
-            if (__ballot(live) == 0ull) continue;      // everybody was serviced into a finished state again (cannot happen: a serviced lane is live or pathless)
-        }
-        // ---- traversal step: traverse_wide_stream's iteration (one memory round trip: node and triangle fetched together)
-        const bool has_tri = live && t_mask != 0;
-        const uint32_t t_rest = t_mask & (t_mask - 1u);
-        bool want_node = live && t_rest == 0u;
-        uint32_t pending_node = 0, tri_pk = 0;
-        if (want_node) {
-            if ((g_mask & 0xFF00u) == 0) {
-                const uint32_t sp = g_mask >> 16;
-                if (sp == 0) { want_node = false; if (!has_tri) live = false; }
-                else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
-            }
-            if (want_node) {
-                const uint32_t hits = (g_mask >> 8) & 0xFFu;
-                const uint32_t b = (uint32_t)__ffs((int)hits) - 1u;
-                g_mask &= ~(0x100u << b);
-                const uint32_t slot = b ^ oct;
-                pending_node = g_base + (uint32_t)__popc(g_mask & 0xFFu & ((1u << slot) - 1u));
-            }
-        }
-        float4 r0, r1, r2, n0, n1, n2, n3, n4;
-        asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r2.x), "=v"(r2.y), "=v"(r2.z));
-        asm volatile("" : "=v"(n0.x), "=v"(n0.y), "=v"(n0.z), "=v"(n0.w), "=v"(n1.x), "=v"(n1.y), "=v"(n1.z), "=v"(n1.w), "=v"(n2.x), "=v"(n2.y), "=v"(n2.z), "=v"(n2.w));
-        asm volatile("" : "=v"(n3.x), "=v"(n3.y), "=v"(n3.z), "=v"(n3.w), "=v"(n4.x), "=v"(n4.y), "=v"(n4.z), "=v"(n4.w));
-        r1.w = 0.0f; r2.w = 0.0f;
-        if (has_tri) {
-            tri_pk = t_base + (uint32_t)__ffs((int)t_mask) - 1u;
-            t_mask = t_rest;
-            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)tri_pk;
-            r0 = pk[0]; r1 = pk[1]; r2 = pk[2];
-        }
-        if (want_node) {
-            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending_node;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
-        }
-        if (has_tri) {
-            float t, U, V, ad;
-            if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
-                if (is_shadow) { best_pk = tri_pk; live = false; }                                 // any hit: done
-                else {
-                    bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                    if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);   // ties go to the lowest id
-                    if (better) { best_t = t; best_pk = tri_pk; }
-                }
-            }
-        }
-        if (want_node && live) {
-            uint32_t node_hits, tri_hits;
-            wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);      // (the scaled form needs one more register: 128 -> spills)
-            uint32_t sp = g_mask >> 16;
-            if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
-            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
-            t_base = __float_as_uint(n1.y); t_mask = tri_hits;
-        }
-    }
-    // ray counters of the frame (Renderer::stats): one atomic per wave
-    for (int ofs = 32; ofs > 0; ofs >>= 1) { n_closest += (uint32_t)__shfl_xor((int)n_closest, ofs); n_shadow += (uint32_t)__shfl_xor((int)n_shadow, ofs); }
-    if (lane == 0) { atomicAdd(&totals[0], (unsigned long long)n_closest); atomicAdd(&totals[1], (unsigned long long)n_shadow); }
-}
+#include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes
+#include "megakernel.h"            // k_megakernel: one launch per frame
 
 // Primary rays on the wide layout with lane refill (experiment: the rope kernel is VALU-bound on primary rays; measured
 // equal on the full frame, 7 % slower on the primary + shadow workload).
@@ -1544,7 +1197,7 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool prim_rope = !two_level && (!sv.num_wnodes || primary_wide == 0);
             if (prim_rope && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("primary_wide = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
             if (!on_wide && !two_level && sv.num_nodes == 0 && sv.num_tris != 0) { set_error("wide_bounce = 0 walks the rope layout: commit the scene with scene option rope = 1"); return MRT_ERR_STATE; }
-            const bool trace0_pass = planes_pass && fuse_primary != 0 && primary_wide != 1 && !(two_level && primary_wide == 0) && (fuse_primary == 2 || F > 1 || B > 1);
+            const bool trace0_pass = planes_pass && fuse_primary != 0 && primary_wide != 1 && !(two_level && primary_wide == 0) && (fuse_primary == 2 || F > 1 || B > 1 || two_level);      // (two-level scenes always: their own-launch form is the stream kernel, 0.88 ms for one 1080p frame of dragon x 4)
             const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
             const bool trace0_hint = primary_hint && (!two_level || (sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24)));      // two-level: the hint is (packet | instance << 24)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);

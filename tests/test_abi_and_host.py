@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(mrt):
         assert hasattr(raw, name), f"{name} declared in mrt_abi.h but not exported"
     from metal_raytracing_amd import _ffi
     assert declared == set(_ffi.SIGNATURES), "ctypes table and header disagree"
-    assert mrt.lib.mrt_abi_version() == 1
+    assert mrt.lib.mrt_abi_version() == 2
 
 
 def test_struct_layout_matches_shader_types(mrt):

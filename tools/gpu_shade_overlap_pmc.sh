@@ -28,7 +28,7 @@ def kname(n):
     m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", n)
     if not m: return None
     t = [x.strip() for x in (m.group(2) or "<>")[1:-1].split(",")]
-    if m.group(1) == "k_shade" and len(t) == 4 and t[3] in ("1", "2"): return "k_shade<primary>"
+    if m.group(1) == "k_shade" and len(t) >= 4 and t[3] in ("1", "2", "3"): return "k_shade<primary>"
     return m.group(1)
 for mode in ("serial", "driver", "steady"):
     print(f"== {mode}")

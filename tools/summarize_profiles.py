@@ -13,8 +13,8 @@ def kname(n):
     if not m:
         return n.split("(")[0]
     targs = [t.strip() for t in (m.group(2) or "<>")[1:-1].split(",")]
-    if m.group(1) == "k_shade" and len(targs) == 4 and targs[3] in ("1", "2"):
-        return "k_shade_primary"          # k_shade<MATERIALS, CHAIN, PLANES, TRACE0 = 1 | 2>: the primary rays generated, traced (1: rope, 2: 8-wide layout) and shaded in one launch (fuse_primary)
+    if m.group(1) == "k_shade" and len(targs) >= 4 and targs[3] in ("1", "2", "3"):
+        return "k_shade_primary"          # k_shade<MATERIALS, CHAIN, PLANES, TRACE0 = 1 | 2 | 3, PAIRS>: the primary rays generated, traced (1: rope, 2: 8-wide layout, 3: both levels of a two-level scene) and shaded in one launch (fuse_primary)
     return m.group(1)
 
 
