@@ -1,7 +1,7 @@
 set -o pipefail
-O=gpurun_out/r04n; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_instancing.py -q -m gpu -x > $O/pytest_tl.log 2>&1; rc=$?; tail -3 $O/pytest_tl.log; echo "pytest rc=$rc"
-[ $rc -eq 0 ] || { grep -n "^FAILED\|^E " $O/pytest_tl.log | head -20; exit 1; }
-python bench.py --scene dragon4 --sopt instancing=1 --steps 48 --warmup 12 --no-cpu-baseline --no-strict 2> /dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('two-level:', d['value'], 'one frame alone', d['latency']['ms_per_frame'], d['latency']['kernel_ms_serialised'], '3 in flight', d['latency']['reference_like_3_in_flight_ms_per_frame'])" | tee -a $O/latency_two_level.txt
+O=gpurun_out/r04final; mkdir -p $O
+bash tools/collect_profiles.sh r04 > $O/collect_r04.log 2>&1; tail -3 $O/collect_r04.log | cut -c1-200
+for k in 1 2 3; do python bench.py --steps 20 --warmup 5 > $O/bench_driver_$k.json 2> $O/bench_driver_$k.err; python -c "
+import json; d=json.loads(open('$O/bench_driver_$k.json').read().strip().splitlines()[-1]); print('driver', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline']['serialised_pass_launch']['frac'], d['cpu_baseline']['value'], d['parity'])"; done
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; python -c "
+import json; d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]); print('default', d['value'], d['ms_per_step'], d['strict_primary_plus_shadow']['value'], d['ms_per_frame'])"
