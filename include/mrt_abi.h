@@ -338,6 +338,8 @@ int mrt_debug_stream_stats(MRTScene scene, const MRTRay *rays, size_t n, int32_t
 int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int32_t any_hit, MRTIntersection *out);
 /* Diagnostics: fill of the 8-wide nodes: out12[c] = nodes with c children (c = 0..8), [9] internal children, [10] leaf children, [11] triangles. */
 int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
+/* Diagnostics: the 8-wide nodes of a committed scene as they lie in device memory (80 bytes each); out == NULL: only the count.                      */
+int mrt_debug_read_wnodes(MRTScene scene, void *out, size_t nbytes, uint64_t *num_nodes);
 /* Diagnostics: host wall time (ms) of the last mrt_scene_commit of a flattened scene by phase: {upload staging, device allocations + upload enqueue,
  * topology (flatten .. refit, with its read-backs), 8-wide emit, rope emit, validation}.                                                              */
 int mrt_debug_commit_times(MRTScene scene, double *out6);

@@ -198,6 +198,7 @@ SIGNATURES = {
     "mrt_debug_calibrate": (C.c_int, [_P, _SZ, _P]),
     "mrt_debug_wide_histogram": (C.c_int, [_P, _P]),
     "mrt_debug_commit_times": (C.c_int, [_P, _P]),
+    "mrt_debug_read_wnodes": (C.c_int, [_P, _P, _SZ, C.POINTER(C.c_uint64)]),
     "mrt_debug_layout_limits": (C.c_int, [C.c_uint64, C.c_uint64]),
     "mrt_debug_host_sah": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
     "mrt_debug_validate": (C.c_int, [_P]),

@@ -181,6 +181,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "wide") scene->opt.wide = (int)value;
     else if (k == "rope") { REQUIRE(value == 0 || value == 1, "rope must be 0 (the rope layout only for scenes without the 8-wide one) or 1 (always)"); scene->opt.rope = (int)value; }
     else if (k == "presplit") { REQUIRE(value >= 0, "presplit must be >= 0 (0 = off; k: triangles longer than k x the mean extent are split into references)"); scene->opt.presplit = (float)value; }
+    else if (k == "refit_fenced") { REQUIRE(value == 0 || value == 1, "refit_fenced must be 0 or 1"); scene->opt.refit_fenced = (int)value; }
     else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
     else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
@@ -621,6 +622,20 @@ int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12) {
     if (!scene->committed) { mrt::set_error("mrt_debug_wide_histogram: scene not committed"); return MRT_ERR_STATE; }
     int rc = bind_device(scene->ctx); if (rc) return rc;
     return mrt::wide_histogram(scene->dev, scene->ctx->stream, out12);
+    MRT_CATCH
+}
+// the 8-wide nodes of a committed scene as they lie in device memory (tests: two builds of one scene must agree bit for bit)
+int mrt_debug_read_wnodes(MRTScene scene, void *out, size_t nbytes, uint64_t *num_nodes) {
+    MRT_TRY
+    REQUIRE(scene && num_nodes, "mrt_debug_read_wnodes: bad argument");
+    if (!scene->committed) { mrt::set_error("mrt_debug_read_wnodes: scene not committed"); return MRT_ERR_STATE; }
+    *num_nodes = scene->dev.num_wnodes;
+    const size_t have = (size_t)scene->dev.num_wnodes * mrt::WNODE_STRIDE * 16;
+    if (out == nullptr) return MRT_OK;
+    REQUIRE(nbytes == have, "mrt_debug_read_wnodes: nbytes must be num_nodes x 16 x the node stride (80 bytes per node)");
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    MRT_HIP(hipMemcpy(out, scene->dev.wnodes.p, have, hipMemcpyDeviceToHost));
+    return MRT_OK;
     MRT_CATCH
 }
 // host wall time of the last commit of a flattened scene by phase (ms): staging, device allocations, topology, 8-wide emit, rope emit, validation

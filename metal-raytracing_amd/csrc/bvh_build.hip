@@ -386,15 +386,16 @@ __device__ __forceinline__ float box_area(float4 lo, float4 hi) {
 // one node of the optimal 8-wide collapse (see "optimal 8-wide collapse" below): C(p, .) from the two children's entries cl[1..7], cr[1..7]
 __device__ __forceinline__ void wide_dp_node(const float *cl, const float *cr, float *C, uint8_t *D, float area, uint32_t nt, int max_leaf, float c_node, float c_tri) {
     float best = 3.0e38f; int bk = 1;
-    for (int k = 1; k <= 7; k++) { const float c = cl[k] + cr[8 - k]; if (c < best) { best = c; bk = k; } }
+    for (int k = 1; k <= WIDE_N - 1; k++) { const float c = cl[k] + cr[WIDE_N - k]; if (c < best) { best = c; bk = k; } }
     const float c_int = area * c_node + best;
     const float c_leaf = nt <= (uint32_t)max_leaf ? area * (float)nt * c_tri : 3.0e38f;
     D[0] = (uint8_t)bk; D[1] = c_leaf <= c_int ? 1 : 0; C[1] = fminf(c_leaf, c_int); C[0] = c_int;
-    for (int i = 2; i <= 7; i++) {
+    for (int i = 2; i <= WIDE_N - 1; i++) {
         float b = 3.0e38f; int k_ = 1;
         for (int k = 1; k < i; k++) { const float c = cl[k] + cr[i - k]; if (c < b) { b = c; k_ = k; } }
         if (b < C[i - 1]) { C[i] = b; D[i] = (uint8_t)k_; } else { C[i] = C[i - 1]; D[i] = 0; }
     }
+    for (int i = WIDE_N; i <= 7; i++) { C[i] = C[WIDE_N - 1]; D[i] = 0; }          // (entries beyond the node's width — the 6-wide variant — are never read; kept finite)
 }
 
 // Bottom-up pass: one thread per leaf climbs; at every node the thread that arrives second computes it from the two children.  What one thread hands to
@@ -405,43 +406,49 @@ __device__ __forceinline__ void wide_dp_node(const float *cl, const float *cr, f
 // an L1 invalidate, ~3.5 us each, from every climbing thread: 8.8 of the build's 21.8 ms for 885 K triangles; this one takes 0.9 ms.
 typedef unsigned int refit_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t refit_rsrc(const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)0xFFFFFFF0u, 0x00020000); }
-__device__ __forceinline__ float4 refit_ld(__amdgpu_buffer_rsrc_t r, uint32_t index) {
+__device__ __forceinline__ float4 refit_ld_wt(__amdgpu_buffer_rsrc_t r, uint32_t index) {
     const refit_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, index * 16u, 0, 16);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ void refit_st(__amdgpu_buffer_rsrc_t r, uint32_t index, float4 a) {
+__device__ __forceinline__ void refit_st_wt(__amdgpu_buffer_rsrc_t r, uint32_t index, float4 a) {
     refit_u32x4 v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, index * 16u, 0, 16);
 }
 
+// FENCED (scene option refit_fenced = 1): the same pass with the textbook hand-off — plain stores, __threadfence() before the arrival is counted and after it — instead of write-through
+// stores, s_waitcnt and sc1 loads.  8.8 ms instead of 0.3 for 885 K triangles; kept as the reference the fast form is compared with bit for bit (tests/test_build_sizes.py).
+template <bool FENCED>
 __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const float4 *__restrict__ leaf_lo, const float4 *__restrict__ leaf_hi,
                         uint32_t n, uint32_t leaf_base, int max_leaf, float ct, float ci, float4 *__restrict__ aux /* per node {cost, triangles, size, -} */,
                         WideDP dp, int dp_max_leaf, float dp_c_node, float dp_c_tri) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const __amdgpu_buffer_rsrc_t r_lo = refit_rsrc(t.lo), r_hi = refit_rsrc(t.hi), r_aux = refit_rsrc(aux), r_C = refit_rsrc(dp.C);
+    float4 *const p_lo = t.lo, *const p_hi = t.hi, *const p_aux = aux, *const p_C = reinterpret_cast<float4 *>(dp.C);
+#define RST(name, idx, val) do { if (FENCED) p_##name[idx] = (val); else refit_st_wt(r_##name, idx, val); } while (0)
+#define RLD(name, idx) (FENCED ? p_##name[idx] : refit_ld_wt(r_##name, idx))
     uint32_t node = leaf_base + j;
     uint32_t gid = vals[j];
     float4 lo = leaf_lo[gid], hi = leaf_hi[gid];
-    refit_st(r_lo, node, lo); refit_st(r_hi, node, hi);
+    RST(lo, node, lo); RST(hi, node, hi);
     const float leaf_cost = ci * box_area(lo, hi);
-    refit_st(r_aux, node, make_float4(leaf_cost, __uint_as_float(1u), __uint_as_float(1u), 0.0f));
+    RST(aux, node, make_float4(leaf_cost, __uint_as_float(1u), __uint_as_float(1u), 0.0f));
     t.cost[node] = leaf_cost;
     t.ntri[node] = 1; t.size[node] = 1; t.collapsed[node] = 1; t.mask[node] = 0;
     if (dp.C) {
         const float c = dp_c_tri * box_area(lo, hi);
-        refit_st(r_C, 2 * node, make_float4(c, c, c, c)); refit_st(r_C, 2 * node + 1, make_float4(c, c, c, c));
+        RST(C, 2 * node, make_float4(c, c, c, c)); RST(C, 2 * node + 1, make_float4(c, c, c, c));
         for (int i = 0; i < 8; i++) dp.dec[8 * (size_t)node + i] = i == 1 ? 1 : 0;
     }
     uint32_t p = t.parent[node];
     while (p != NONE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this node's stores have left the CU ...
+        if (FENCED) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this node's stores have left the CU ...
         const uint32_t old = __hip_atomic_fetch_add(&t.flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the arrival is counted
         if (old == 0) return;                       // the sibling subtree finishes this node
-        asm volatile("" ::: "memory");              // the children are read after the arrival has been counted, not before
+        if (FENCED) __threadfence(); else asm volatile("" ::: "memory");              // the children are read after the arrival has been counted, not before
         uint32_t l = t.left[p], r = t.right[p];
-        const float4 llo = refit_ld(r_lo, l), lhi = refit_ld(r_hi, l), rlo = refit_ld(r_lo, r), rhi = refit_ld(r_hi, r);
-        const float4 la = refit_ld(r_aux, l), ra = refit_ld(r_aux, r);
+        const float4 llo = RLD(lo, l), lhi = RLD(hi, l), rlo = RLD(lo, r), rhi = RLD(hi, r);
+        const float4 la = RLD(aux, l), ra = RLD(aux, r);
         float4 blo = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
         float4 bhi = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
         float area = box_area(blo, bhi);
@@ -460,25 +467,27 @@ __global__ void k_refit(TreeArrays t, const uint32_t *__restrict__ vals, const f
         for (int o = 0; o < 8; o++) { bool negdir = (o >> ax) & 1; if (negdir != left_greater) m |= 1u << o; }
         const float cost = col ? c_leaf : c_inner;
         const uint32_t size = col ? 1u : 1u + __float_as_uint(la.z) + __float_as_uint(ra.z);
-        refit_st(r_lo, p, blo); refit_st(r_hi, p, bhi);
-        refit_st(r_aux, p, make_float4(cost, __uint_as_float(nt), __uint_as_float(size), 0.0f));
+        RST(lo, p, blo); RST(hi, p, bhi);
+        RST(aux, p, make_float4(cost, __uint_as_float(nt), __uint_as_float(size), 0.0f));
         t.cost[p] = cost;
         t.ntri[p] = nt;
         t.size[p] = size;
         t.collapsed[p] = col ? 1 : 0;
         t.mask[p] = (uint8_t)m;
         if (dp.C) {                                 // same bottom-up pass: the children's entries are complete
-            const float4 l0 = refit_ld(r_C, 2 * l), l1 = refit_ld(r_C, 2 * l + 1), r0 = refit_ld(r_C, 2 * r), r1 = refit_ld(r_C, 2 * r + 1);
+            const float4 l0 = RLD(C, 2 * l), l1 = RLD(C, 2 * l + 1), r0 = RLD(C, 2 * r), r1 = RLD(C, 2 * r + 1);
             const float dl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, dr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             float C[8]; uint8_t D[8];
             wide_dp_node(dl, dr, C, D, area, nt, dp_max_leaf, dp_c_node, dp_c_tri);
-            refit_st(r_C, 2 * p, make_float4(C[0], C[1], C[2], C[3])); refit_st(r_C, 2 * p + 1, make_float4(C[4], C[5], C[6], C[7]));
+            RST(C, 2 * p, make_float4(C[0], C[1], C[2], C[3])); RST(C, 2 * p + 1, make_float4(C[4], C[5], C[6], C[7]));
             for (int i = 0; i < 8; i++) dp.dec[8 * (size_t)p + i] = D[i];
         }
         node = p;
         p = t.parent[p];
     }
 }
+#undef RST
+#undef RLD
 
 // ------------------------------------------------------------------ numbering + emit
 __global__ void k_assign(TreeArrays t, uint32_t nnodes, uint32_t *__restrict__ new_index, uint32_t *__restrict__ leaf_offset, uint32_t *__restrict__ stat /*[0]=max depth,[1]=leaves*/) {
@@ -765,7 +774,7 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
         else {
             // unfold the decisions: (node, roots allowed) pairs, depth first; at most eight children come out
             uint32_t st_n[8]; uint8_t st_i[8]; int sp = 0;
-            { const uint32_t k = dp.dec[8 * (size_t)f + 0]; st_n[sp] = t.right[f]; st_i[sp++] = (uint8_t)(8u - k); st_n[sp] = t.left[f]; st_i[sp++] = (uint8_t)k; }
+            { const uint32_t k = dp.dec[8 * (size_t)f + 0]; st_n[sp] = t.right[f]; st_i[sp++] = (uint8_t)((uint32_t)WIDE_N - k); st_n[sp] = t.left[f]; st_i[sp++] = (uint8_t)k; }
             while (sp > 0) {
                 const uint32_t c = st_n[--sp]; uint32_t b = st_i[sp];
                 while (b > 1u && dp.dec[8 * (size_t)c + b] == 0) b--;
@@ -783,7 +792,7 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
             ch[0] = t.left[f]; ch[1] = t.right[f]; nch = 2;
             isleaf[0] = t.collapsed[ch[0]]; isleaf[1] = t.collapsed[ch[1]];
             // phase 1: open inner children, largest surface area first
-            while (nch < 8) {
+            while (nch < WIDE_N) {
                 int best = -1; float ba = -1.0f;
                 for (int k = 0; k < nch; k++)
                     if (!isleaf[k]) { float a = box_area(t.lo[ch[k]], t.hi[ch[k]]); if (a > ba) { ba = a; best = k; } }
@@ -795,7 +804,7 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
         }
         // phase 2: slots left over are free box tests — split multi-triangle leaves back along the binary tree, so
         // that fewer triangles (one sequential round trip each) are tested behind every box that is hit
-        while (nch < 8) {
+        while (nch < WIDE_N) {
             int best = -1; float ba = -1.0f;
             for (int k = 0; k < nch; k++)
                 if (isleaf[k] && t.ntri[ch[k]] > 1) { float a = box_area(t.lo[ch[k]], t.hi[ch[k]]); if (a > ba) { ba = a; best = k; } }
@@ -843,6 +852,15 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
     const float pl[3] = {nlo.x, nlo.y, nlo.z};
     uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z then qhi x,y,z; 2 dwords (8 bytes) each
     uint32_t meta[2] = {0, 0}, imask = 0, rank_i = 0, off_t = 0;
+#if MRT_WIDE6
+    uint32_t pw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, m6[6] = {0, 0, 0, 0, 0, 0}; int phys = 0;      // plane words and per-child meta of the 64-byte node; physical children in slot order
+    auto put6 = [&](int j, const uint32_t ql[3], const uint32_t qh[3]) {
+        for (int a = 0; a < 3; a++) {
+            if (j < 4) { pw[3 * a] |= ql[a] << (8 * j); pw[3 * a + 2] |= qh[a] << (8 * j); }
+            else { pw[3 * a + 1] |= (ql[a] << (8 * (j - 4))) | (qh[a] << (16 + 8 * (j - 4))); }
+        }
+    };
+#endif
     for (int sl = 0; sl < 8; sl++) {
         int k = child_in_slot[sl];
         uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
@@ -874,14 +892,28 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
             }
         }
         for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
+#if MRT_WIDE6
+        if (k >= 0) { m6[phys] = (uint32_t)sl | ((isleaf[k] ? t.ntri[ch[k]] : 0u) << 3); put6(phys, ql, qh); phys++; }
+#endif
     }
+#if MRT_WIDE6
+    { const uint32_t el[3] = {255, 255, 255}, eh[3] = {0, 0, 0}; for (; phys < 6; phys++) { m6[phys] = 0; put6(phys, el, eh); } }      // unused children: boxes no ray enters
+#endif
     const size_t w = WNODE_STRIDE * (size_t)(base_in + i);
     // exponents are stored unbiased (int8, e - 127): the traversal scales 1/direction with v_ldexp_f32
     wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24)));
+#if MRT_WIDE6
+    wnodes[w + 1] = make_float4(__uint_as_float(((next_base + my_i) & 0xFFFFFFu) | (m6[5] << 24)), __uint_as_float(my_t),
+                                __uint_as_float(m6[0] | (m6[1] << 6) | (m6[2] << 12) | (m6[3] << 18) | (m6[4] << 24)), __uint_as_float(pw[0]));
+    wnodes[w + 2] = make_float4(__uint_as_float(pw[1]), __uint_as_float(pw[2]), __uint_as_float(pw[3]), __uint_as_float(pw[4]));
+    wnodes[w + 3] = make_float4(__uint_as_float(pw[5]), __uint_as_float(pw[6]), __uint_as_float(pw[7]), __uint_as_float(pw[8]));
+    (void)q; (void)meta;
+#else
     wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
     wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+#endif
 }
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -902,7 +934,7 @@ __global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, 
 
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]) {
     memset(out12, 0, 48);
-    if (sc.num_wnodes == 0) return MRT_OK;
+    if (sc.num_wnodes == 0 || MRT_WIDE6) return MRT_OK;          // (the 64-byte node of the 6-wide variant is not decoded here)
     DevBuf<uint32_t> d; MRT_HIP(d.alloc(12));
     MRT_HIP(hipMemsetAsync(d.p, 0, 48, stream));
     hipLaunchKernelGGL(k_wide_histogram, dim3(cdiv(sc.num_wnodes, 256)), dim3(256), 0, stream, sc.wnodes.p, sc.num_wnodes, d.p);
@@ -1249,8 +1281,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     }
     DevBuf<float4> refit_aux;
     MRT_HIP(refit_aux.alloc_in(arena, nnodes));
-    hipLaunchKernelGGL(k_refit, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
-                       dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
+    if (opt.refit_fenced) hipLaunchKernelGGL(k_refit<true>, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
+                                             dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
+    else hipLaunchKernelGGL(k_refit<false>, dim3(cdiv(n, B)), dim3(B), 0, stream, t, vin, leaf_lo_p, leaf_hi_p, n, leaf_base, opt.max_leaf, opt.cost_trav, opt.cost_isect, refit_aux.p,
+                            dp, std::min(opt.max_leaf, 4), opt.wide_cost_node, opt.wide_cost_tri);
     hipLaunchKernelGGL(k_assign, dim3(cdiv(nnodes, 1024)), dim3(1024), 0, stream, t, nnodes, new_index.p, leaf_offset.p, stat.p);
     // the triangle packets in the leaf order of the binary tree (scratch): the source of the 8-wide layout's packets, and of the rope layout's when that one is emitted too
     DevBuf<float4> pk_tmp; MRT_HIP(pk_tmp.alloc_in(arena, 3 * (size_t)n));

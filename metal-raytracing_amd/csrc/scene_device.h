@@ -41,9 +41,20 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 //   f4 2: qlo_x[8] qlo_y[8]      f4 3: qlo_z[8] qhi_x[8]      f4 4: qhi_y[8] qhi_z[8]      (empty slot: qlo=255, qhi=0)
 // Slot bit k set = the child lies on the + side of the node centre along axis k, so children are entered
 // front to back in the order of (slot ^ ray octant).
-#ifndef MRT_WNODE_STRIDE
-#define MRT_WNODE_STRIDE 5
+// -DMRT_WIDE6=1 (A/B variant, flattened scenes only): SIX children per node in 64 bytes = 4 x float4, one half of a 128-byte line, never straddling two:
+//   f4 0: as above (imask stays in slot space: eight virtual slots order the children front to back, at most six are occupied)
+//   f4 1: child_base (24 bits) | meta of child 5 << 24,  tri_base,  meta of children 0..4 (6 bits each),  plane word 0
+//   f4 2, 3: plane words 1..8.   meta of physical child j = slot (3 bits) | triangle count << 3 (3 bits); its packet offset is the sum of the counts before it.
+//   plane words per axis a = x, y, z:  [3a] = lo bytes of children 0..3,  [3a + 1] = lo4 | lo5 << 8 | hi4 << 16 | hi5 << 24,  [3a + 2] = hi bytes of children 0..3
+#ifndef MRT_WIDE6
+#define MRT_WIDE6 0
 #endif
+#ifndef MRT_WNODE_STRIDE
+#define MRT_WNODE_STRIDE (MRT_WIDE6 ? 4 : 5)
+#endif
+constexpr int WIDE_N = MRT_WIDE6 ? 6 : 8;                      // children per wide node
+constexpr int WNODE_N4 = MRT_WIDE6 ? 3 : 4;                    // index of the node's last float4 (the traversal loops name five: the 64-byte node's fifth is its fourth again)
+constexpr uint32_t WNODE_BASE_MASK = MRT_WIDE6 ? 0x00FFFFFFu : 0xFFFFFFFFu;
 constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wide nodes in HBM (5 = packed 80 B; 8 = one 128-B line each)
 #ifndef MRT_WPACKET_STRIDE
 #define MRT_WPACKET_STRIDE 3
@@ -191,6 +202,7 @@ struct BuildOptions {
     int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
     float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
+    int refit_fenced = 0;     // 1: the bottom-up pass of the build with __threadfence() hand-offs instead of write-through stores (the slow reference form; same tree bit for bit)
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
                               // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS

@@ -76,6 +76,50 @@ template <bool SCALED = false>
 MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4, const f3 o,
                             float ix, float iy, float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
                             const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
+#if MRT_WIDE6
+    {   // six children in 64 bytes (scene_device.h): physical child j carries its slot and its triangle count; its packets follow those of the children before it
+        const uint32_t ew = __float_as_uint(n0.w);
+        const uint32_t imask = ew >> 24;
+        if (SCALED) {
+            const float S = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(tmax, 1e-6f, 1e30f) * 1.0000005f);
+            ix *= S; iy *= S; iz *= S;
+        }
+        const float ax = __builtin_ldexpf(ix, (int)(int8_t)(ew & 0xFFu)), ay = __builtin_ldexpf(iy, (int)(int8_t)((ew >> 8) & 0xFFu)), az = __builtin_ldexpf(iz, (int)(int8_t)((ew >> 16) & 0xFFu));
+        const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
+        const uint32_t w[9] = {__float_as_uint(n1.w), __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w),
+                               __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w)};
+        // near / far bytes per axis: children 0..3 from the lo / hi word, children 4, 5 from the two halves of the middle word
+        const uint32_t nrx[2] = {nx ? w[2] : w[0], nx ? w[1] >> 16 : w[1]}, frx[2] = {nx ? w[0] : w[2], nx ? w[1] : w[1] >> 16};
+        const uint32_t nry[2] = {ny ? w[5] : w[3], ny ? w[4] >> 16 : w[4]}, fry[2] = {ny ? w[3] : w[5], ny ? w[4] : w[4] >> 16};
+        const uint32_t nrz[2] = {nz ? w[8] : w[6], nz ? w[7] >> 16 : w[7]}, frz[2] = {nz ? w[6] : w[8], nz ? w[7] : w[7] >> 16};
+        const uint32_t m04 = __float_as_uint(n1.z), m5 = __float_as_uint(n1.x) >> 24;
+        uint32_t nh = 0, th = 0, off = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int wq = j >> 2, k = j & 3;
+            const uint32_t meta6 = j < 5 ? (m04 >> (6 * j)) & 63u : m5 & 63u;
+            const uint32_t slot = meta6 & 7u, cnt = meta6 >> 3;
+            float tn, tf;
+            if (SCALED) {
+                tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(nry[wq], k), ay, by)),
+                           __builtin_amdgcn_fmed3f(__builtin_fmaf(ubyte_f(nrz[wq], k), az, bz), 0.0f, 1.0f));
+                tf = __builtin_amdgcn_fmed3f(fminf(fminf(__builtin_fmaf(ubyte_f(frx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(fry[wq], k), ay, by)),
+                                                   __builtin_fmaf(ubyte_f(frz[wq], k), az, bz)) * 1.0000005f, 0.0f, 1.0f);
+            } else {
+                tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(nry[wq], k), ay, by)),
+                           fmaxf(__builtin_fmaf(ubyte_f(nrz[wq], k), az, bz), tmin));
+                tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(fry[wq], k), ay, by)),
+                                 __builtin_fmaf(ubyte_f(frz[wq], k), az, bz)) * 1.0000005f, tmax);
+            }
+            if (SCALED ? tn < tf : tn <= tf) {
+                nh |= ((imask >> slot) & 1u) << (slot ^ oct);
+                th |= bfm_b32(cnt, off);
+            }
+            off += cnt;
+        }
+        node_hits = nh; tri_hits = th;
+    }
+#else
     const uint32_t ew = __float_as_uint(n0.w);
     const uint32_t imask = ew >> 24;
     if (SCALED) {
@@ -116,6 +160,7 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
         }
     }
     node_hits = nh; tri_hits = th;
+#endif
 }
 
 // stack: depth x WIDE_STACK_LEVEL_BYTES of LDS for the wave (depth = the scene's wide-tree depth, <= WIDE_STACK)
@@ -160,7 +205,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             }
         } else {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[WNODE_N4];
             have_pending = false;
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, tmin, h.t, node_hits, tri_hits);
@@ -176,7 +221,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
                 if (tn > h.t) tc->stale++;
             }
             if ((g_mask >> 8) != 0) { wstack_push(stack, sp, lane, g_base, g_mask); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
@@ -226,7 +271,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
         }
         if (has_tri) {
             float t, U, V, ad;
@@ -241,7 +286,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
             wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
             uint32_t sp = g_mask >> 16;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
         else if (t_rest == 0u) break;        // no node left and this was the last pending triangle
@@ -334,7 +379,7 @@ MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
         }
         if (has_tri) {
             float t, U, V, ad;
@@ -350,7 +395,7 @@ MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const
             uint32_t sp = (g_mask >> 16) & 0xFFu;
             const uint32_t isp = g_mask & 0xFF000000u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
-            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
@@ -705,7 +750,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         if (want_node) {
             MRT_BOUND(pending, s.num_wnodes, 1);
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
         }
         auto consider = [&](const float4 q0, const float4 q1, const float4 q2, const uint32_t pk_index) {
             float t, U, V, ad;
@@ -752,7 +797,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16;
             const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             if (SPEC && t_mask != 0u) { u_base = __float_as_uint(n1.y); u_mask = tri_hits; }      // (u is empty here: the lane asked for a node with t_rest != 0 only then)
             else { t_base = __float_as_uint(n1.y); t_mask = tri_hits; }
         }

@@ -68,3 +68,34 @@ def test_presplit_build_at_the_tail_boundary(mrt, orc, gpu_ctx):
         for f in ("type", "distance", "primitive_id", "u", "v"):
             assert np.array_equal(g[f], o[f]), (f, presplit)
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["dragon", "garden"])
+def test_write_through_refit_builds_the_tree_of_the_fenced_refit(mrt, gpu_ctx, scene_name):
+    """The bottom-up pass of the build hands a node's box, cost and collapse table from one thread to another (possibly on another XCD, whose L2 is not coherent with this one's) through
+    write-through stores, s_waitcnt and sc1 loads instead of __threadfence().  Scene option refit_fenced = 1 selects the fenced form: both must give the same 8-wide nodes — every
+    quantised box, child mask and leaf range — bit for bit, on the 885 K-triangle scene (and a second one), twice."""
+    import ctypes as C
+    sc = mrt.SCENES[scene_name]((64, 64))
+    def nodes(opts):
+        d = mrt.DeviceScene(gpu_ctx, sc, opts)
+        n = C.c_uint64()
+        mrt._ffi.check(mrt.lib.mrt_debug_read_wnodes(d.handle, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 20), np.uint32)
+        mrt._ffi.check(mrt.lib.mrt_debug_read_wnodes(d.handle, mrt._ffi.ptr(out), out.nbytes, C.byref(n)))
+        st = d.stats
+        d.close()
+        return out, (st.bvh_nodes, st.bvh_leaves, st.wide_depth, st.sah_cost)
+    fast, fast_stats = nodes({})
+    for rep in range(2):
+        fenced, fenced_stats = nodes({"refit_fenced": 1})
+        assert fenced_stats == fast_stats
+        assert fenced.shape == fast.shape
+        # nodes of one level are numbered in the order their parents' waves reserve them (an atomic): a run-to-run permutation inside a level.  Compared as sets: everything
+        # of a node but its child / packet base (words 4, 5) — origin, exponents, child mask, leaf ranges, all 48 quantised plane bytes
+        def canon(a):
+            rows = np.ascontiguousarray(a[:, [0, 1, 2, 3] + list(range(6, 20))])
+            return rows[np.lexsort(rows.T[::-1])]
+        assert np.array_equal(canon(fenced), canon(fast))
+    assert fast.shape[0] > 1000

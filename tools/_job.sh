@@ -1,7 +1,9 @@
 set -o pipefail
-O=gpurun_out/r04final; mkdir -p $O
-bash tools/collect_profiles.sh r04 > $O/collect_r04.log 2>&1; tail -3 $O/collect_r04.log | cut -c1-200
-for k in 1 2 3; do python bench.py --steps 20 --warmup 5 > $O/bench_driver_$k.json 2> $O/bench_driver_$k.err; python -c "
-import json; d=json.loads(open('$O/bench_driver_$k.json').read().strip().splitlines()[-1]); print('driver', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline']['serialised_pass_launch']['frac'], d['cpu_baseline']['value'], d['parity'])"; done
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; python -c "
-import json; d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]); print('default', d['value'], d['ms_per_step'], d['strict_primary_plus_shadow']['value'], d['ms_per_frame'])"
+O=gpurun_out/r04w6; mkdir -p $O
+bash tools/gpu_variants_ab.sh wide6 2>&1 | tee $O/wide6_ab.txt
+MRT_LIB_PATH=$PWD/metal-raytracing_amd/variants/libmrt_hip_wide6.so python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-strict 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('wide6: nodes', c['bvh_nodes'], 'depth', c['wide_depth'], 'scene_bytes', c['scene_bytes'], 'serial pass', d['latency']['kernel_ms_serialised_pass'], 'one frame', d['latency']['kernel_ms_serialised'])" | tee -a $O/wide6_ab.txt
+python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-strict 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('head : nodes', c['bvh_nodes'], 'depth', c['wide_depth'], 'scene_bytes', c['scene_bytes'], 'serial pass', d['latency']['kernel_ms_serialised_pass'], 'one frame', d['latency']['kernel_ms_serialised'])" | tee -a $O/wide6_ab.txt
