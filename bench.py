@@ -345,6 +345,8 @@ def main():
             pers = int(r.get_option("persistent"))
             pulls = pers == 1 or (pers == 2 and (2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 1024 or (min(int(r.get_option("lanes_used")), passes) >= 5 and 2 * (r.stats.primary_rays / max(1, r.stats.frames)) * frame_batch >= r.get_option("wave_slots") * 256)))      # renderer.hip render(): the same rule
             kernel_label = ("k_trace_mixed_wide_persist" if pulls else "k_trace_mixed_wide_stream") + ("<two-level>" if two_level else "") + " (bounce + shadow traversal)"
+            if two_level and r.get_option("tl_pairs") != 0 and a.bounces <= 3 and r.get_option("materials") == 0:
+                kernel_label = "k_tl_top_flat / k_tl_top + k_tl_blas (two-level scene, binned: TLAS pass + BLAS pass over (ray, instance) pairs; two launches per bounce, timed together)"
         traffic_p = (prof.get("hbm_traffic_bytes_per_launch", {}).get("k_trace_mixed_wide_persist") or {}).get("bytes_corrected") if prof else None
         out = {
             "metric": "Mrays/sec (primary+shadow) and ms/frame, DragonScene 1920x1080 spp=1" if (a.scene, w, h) == ("dragon", 1920, 1080) else f"Mrays/sec (closest+shadow), {a.scene} {w}x{h} spp=1",
