@@ -315,8 +315,8 @@ int mrt_group_stats(MRTGroupRenderer gr, MRTRenderStats *out);                  
 
 /* ---------------------------------------------------------------- library-internal A/B switches (tests, tools/, bench.py --opt)
  * Not part of the host contract: keys come and go with the experiments that need them; every setting renders the same image bit for bit.
- * Today: "persistent" / "persist_chunk" / "wave_slots" / "stream_even" (how a traversal launch splits its rays over waves), "primary_hint",
- * "primary_wide", "fuse_primary", "wide_bounce", "throughput_chain", "shadow_planes", "tail_accumulate" (DESIGN.md §6).  Public keys are accepted too. */
+ * Today: "persistent" / "persist_chunk" / "wave_slots" / "stream_even" / "xcd_counters" (how a traversal launch splits its rays over waves), "primary_hint",
+ * "primary_wide", "fuse_primary", "wide_bounce", "throughput_chain", "shadow_planes", "tail_accumulate", "tl_pairs" / "tl_pair_cap" (DESIGN.md §6).  Public keys are accepted too. */
 int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value);
 int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value);
 

@@ -245,7 +245,7 @@ __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: ite
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes /* > 0: XCD regions (XcdRegions), the pass's sub-frames */) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         g_wave_iters[4 * blockIdx.x] = st.iters; g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{wt0, wt_tag, wst};
 #endif
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
-    traverse_wide_stream<TWO_LEVEL>(s, SharedCounter{work, n, chunk}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
 // ------------------------------------------------------------------ accumulate (Raytracing.metal:394-403)
 // Also the frame's bookkeeping (block 0, thread 0): per-bounce queue counters {next rays, shadow rays} are
 // folded into the running totals and zeroed for the next frame.
+constexpr size_t WORK_COUNTERS = 128, WORK_COUNTERS_PER_BOUNCE = 8 * XCD_COUNTER_STRIDE / 2;      // in 64-bit words of FrameLane::bounce_counts
 __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 *__restrict__ sample, const float4 *__restrict__ prev, float4 *__restrict__ dst,
                                                    unsigned long long *__restrict__ bounce_counts, unsigned long long *__restrict__ totals, uint32_t primary) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -651,7 +652,8 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
             if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
             shadow += c >> 32;
             bounce_counts[b] = 0;
-            bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
+            bounce_counts[32 + b] = 0;               // work counter of the TLAS pass of this bounce (two-level scenes, binned)
+            for (int x = 0; x < 8; x++) reinterpret_cast<uint32_t *>(bounce_counts + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE)[x * XCD_COUNTER_STRIDE] = 0;      // work counters of the persistent trace launch of this bounce (one per XCD region)
             bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
@@ -695,7 +697,8 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
             if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
             shadow += c >> 32;
             bounce_counts[b] = 0;
-            bounce_counts[32 + b] = 0;               // work counter of the persistent trace launch of this bounce
+            bounce_counts[32 + b] = 0;               // work counter of the TLAS pass of this bounce (two-level scenes, binned)
+            for (int x = 0; x < 8; x++) reinterpret_cast<uint32_t *>(bounce_counts + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE)[x * XCD_COUNTER_STRIDE] = 0;      // work counters of the persistent trace launch of this bounce (one per XCD region)
             bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
@@ -734,6 +737,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
                 if (b + 1 < fp.max_bounces) closest += (uint32_t)c;
                 shadow += c >> 32;
                 g.p[p].counts[b] = 0; g.p[p].counts[32 + b] = 0; g.p[p].counts[65 + b] = 0;
+                for (int x = 0; x < 8; x++) reinterpret_cast<uint32_t *>(g.p[p].counts + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE)[x * XCD_COUNTER_STRIDE] = 0;
             }
         }
         totals[0] += closest; totals[1] += shadow; totals[2] += primary;
@@ -910,7 +914,9 @@ int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t
     for (auto &L : lanes) {
         MRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MRT_HIP(hipEventCreateWithFlags(&L.accumulated, hipEventDisableTiming));
-        MRT_HIP(L.bounce_counts.alloc(97));       // [65, 97): two-level scenes, binned — per bounce {pairs queued (lo 32), work counter of the BLAS pass (hi 32)};  [0, 32): per-bounce queue counts; [32, 64): per-bounce work counters of the persistent trace launches; [64]: the megakernel's pixel counter
+        // per bounce b: [b] queue counts {next rays (lo 32), shadow rays (hi 32)}; [32 + b] work counter of the TLAS pass and [65 + b] {pairs queued, work counter of the BLAS pass} (two-level scenes, binned);
+        // from WORK_COUNTERS on: the eight work counters of the pulling traversal launch, 128 bytes apart (XcdRegions)
+        MRT_HIP(L.bounce_counts.alloc(WORK_COUNTERS + 32 * WORK_COUNTERS_PER_BOUNCE));
         MRT_HIP(hipMemsetAsync(L.bounce_counts.p, 0, L.bounce_counts.bytes(), stream));
     }
     MRT_HIP(totals.alloc(4));
@@ -1276,9 +1282,9 @@ int Renderer::render(int n_frames) {                                   // Render
                     const uint32_t chunk_arg = chunk;
 #endif
                     if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg, lit_b);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + 32 + b), chunk_arg, lit_b);
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
                 }
                 else if (on_wide) {
                     const size_t slots_m = 2 * (size_t)capacity * B;

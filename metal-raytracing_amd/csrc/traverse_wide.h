@@ -461,6 +461,42 @@ struct SharedCounter {
     }
 };
 
+// The dynamic split with one counter per XCD.  256 CUs pulling from ONE word queue up behind it (a word takes ~88 returning atomics per microsecond, and a pull under that load
+// takes 1.4-3 us: MI355X_MICROARCH.md "dequeue": shard the head per XCD above 64 pullers).  Here the queue is cut into eight REGIONS, one per XCD (the workgroups that share
+// blockIdx.x % 8 share an XCD: they are dealt round-robin), each with its own counter on its own cache line.  Region x is the x-th eighth of every sub-frame's share of the queue
+// — a pass's queue is filled sub-frame after sub-frame, in screen-tile order within each, by blocks that reserve their range when they finish — so an XCD walks rays that left
+// one band of the screen (measured: the L2 miss count does not change with it, what is gained is the counter).  The combined queue [bounce rays | shadow rays] is cut the same
+// way in each part.  A wave whose home region is used up goes on with the next one (x + 1, ...): all regions are emptied whatever the number of waves, and every counter only
+// ever grows, so a wave asks at most (chunks + 8) times.  subframes == 0: one region over the whole combined queue (the form above, counting chunks instead of rays).
+constexpr uint32_t XCD_COUNTER_STRIDE = 32;            // words between two regions' counters: 128 bytes
+struct XcdRegions {
+    uint32_t *counters; uint32_t n_next, n, chunk, subframes; uint32_t home; uint32_t tries = 0;
+    MRT_DEV bool operator()(uint32_t &ob, uint32_t &oe) {
+        const uint32_t regions = subframes ? 8u : 1u;
+        const uint32_t C1 = subframes ? (n_next + chunk - 1u) / chunk : (n + chunk - 1u) / chunk, C2 = subframes ? (n - n_next + chunk - 1u) / chunk : 0u;      // chunks of the two parts
+        const uint32_t B = subframes ? subframes : 1u;
+        const uint32_t F1 = (C1 + B - 1u) / B, S1 = (F1 + regions - 1u) / regions, F2 = (C2 + B - 1u) / B, S2 = (F2 + regions - 1u) / regions;      // chunks per sub-frame, and per region of a sub-frame
+        const uint32_t K1 = B * S1, K = K1 + B * S2;       // a region's list: its slices of part 1, sub-frame after sub-frame, then of part 2
+        while (tries < regions) {
+            const uint32_t x = (home + tries) & (regions - 1u);
+            uint32_t k = 0;
+            if ((threadIdx.x & 63) == 0) k = atomicAdd(&counters[x * XCD_COUNTER_STRIDE], 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            if (k >= K) { tries++; continue; }
+            const bool p2 = k >= K1;
+            const uint32_t kk = p2 ? k - K1 : k, S = p2 ? S2 : S1, F = p2 ? F2 : F1, Cp = p2 ? C2 : C1;
+            const uint32_t f = kk / S, lc = x * S + (kk - f * S);
+            if (lc >= F) continue;                            // (rounding: the last region's slice is shorter)
+            const uint32_t c = f * F + lc;
+            if (c >= Cp) continue;                            // (rounding: the last sub-frame's share is shorter)
+            const uint32_t first = subframes && p2 ? n_next : 0u, lim = subframes && !p2 ? n_next : n;
+            ob = first + c * chunk; oe = min(lim, ob + chunk);
+            return true;
+        }
+        return false;
+    }
+};
+
 // Two-level scenes, binned form (renderer option tl_pairs).  The TLAS pass — this loop with a PairQueue — tests instances of at most eight triangles in place and,
 // instead of entering a larger one, appends {ray, instance} to a queue; a second launch walks every pair in object space with the FLATTENED loop (TWO_LEVEL = false, per-ray root:
 // ROOTS), its lanes never changing level, and folds the hits into the rays' results with atomics.  When the queue is full a lane enters the instance in place, as without a queue.
