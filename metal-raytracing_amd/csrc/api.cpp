@@ -118,9 +118,17 @@ int mrt_scene_add_instance(MRTScene scene, int32_t source_mesh_id, const float *
     m.source = src >= 0 ? src : source_mesh_id;                         // instances of an instance share the original's geometry
     memcpy(m.xf, xf, 64);
     m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;
+    const int geometry_of = m.source;
     scene->meshes.push_back(std::move(m));
     scene->committed = false; scene->only_transforms_changed = false;
     if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
+    if (!scene->opt.instancing) {           // a flattened scene stages a copy of the source's geometry per instance: the pinned area grows here (see mrt_mesh_add_submesh)
+        const mrt::HostMesh &g = scene->meshes[geometry_of];
+        size_t bytes = g.positions.size() / 3 * 28 + 4096;
+        for (auto &ix : g.sub_indices) bytes += ix.size() * 4;
+        scene->stage_need += bytes;
+        if (scene->stage_need > scene->dev.stage.cap && bind_device(scene->ctx) == MRT_OK) { if (scene->dev.stage.reserve(std::max(scene->stage_need, 2 * scene->dev.stage.cap)) != hipSuccess) (void)hipGetLastError(); }
+    }
     return MRT_OK;
     MRT_CATCH
 }

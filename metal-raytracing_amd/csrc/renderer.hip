@@ -258,14 +258,13 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         g_wave_iters[4 * blockIdx.x] = st.iters; g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{wt0, wt_tag, wst};
 #endif
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
-    traverse_wide_stream<TWO_LEVEL>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+    auto fetch = [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
             if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
             else if (lit) tag = __float_as_uint(B.w);   // shadow planes: the ray reports to its pixel's byte
-        },
-        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+        };
+    auto emit = [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) {
                 if (!hit) {
                     if (lit) lit[4 * (size_t)j] = 1;          // (lit points at this bounce's byte of pixel 0: four bytes per pixel and frame)
@@ -274,11 +273,15 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
             } else {
                 qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
-        }
+        };
 #ifdef MRT_WAVE_TIMES
-        , wt_tag == 0 ? &wst : nullptr
+    StreamStats *const wss = wt_tag == 0 ? &wst : nullptr;
+#else
+    StreamStats *const wss = nullptr;
 #endif
-        );
+    // two-level scenes keep the one counter (the first of the eight): the per-XCD form measured no gain there and costs the in-loop walk five spilled registers
+    if constexpr (TWO_LEVEL) traverse_wide_stream<true>(s, SharedCounter{work, n, chunk}, stk_dyn, fetch, emit, wss);
+    else traverse_wide_stream<false>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn, fetch, emit, wss);
 }
 
 #include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes

@@ -149,8 +149,9 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
     void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
     hipError_t alloc(size_t count, unsigned flags = 0 /* hipDeviceMallocDefault; hipDeviceMallocUncached for streamed buffers (experiment) */) {
-        release();
         if (count == 0) count = 1;
+        if (p && owned && n == count && !flags) return hipSuccess;          // same size as before (a re-commit, a resize back): keep the allocation, the caller overwrites it
+        release();
         hipError_t e = flags ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), flags) : hipMalloc((void **)&p, count * sizeof(T));
         if (e == hipSuccess) n = count; else p = nullptr;
         return e;
@@ -171,7 +172,14 @@ struct PinnedBuf {
     void *p = nullptr; size_t cap = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipStream_t side = nullptr; hipEvent_t side_done = nullptr;      // a second stream for the part of an upload the build does not wait for (the normals), created when first used
+    ~PinnedBuf() { if (side_done) (void)hipEventDestroy(side_done); if (side) (void)hipStreamDestroy(side); if (p) (void)hipHostFree(p); }
+    hipError_t side_stream() {
+        if (side) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
+        return e;
+    }
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
