@@ -1123,7 +1123,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     auto upload_normals = [&]() -> int {
         if (keep_geometry) return MRT_OK;
         normals_fill.join();
-        MRT_HIP(stg.side_stream());
+        if (!stg.side) { MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream)); return MRT_OK; }
+        if (!stg.side_done) MRT_HIP(hipEventCreateWithFlags(&stg.side_done, hipEventDisableTiming));
         MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stg.side));
         MRT_HIP(hipEventRecord(stg.side_done, stg.side));
         MRT_HIP(hipStreamWaitEvent(stream, stg.side_done, 0));

@@ -172,14 +172,9 @@ struct PinnedBuf {
     void *p = nullptr; size_t cap = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
-    hipStream_t side = nullptr; hipEvent_t side_done = nullptr;      // a second stream for the part of an upload the build does not wait for (the normals), created when first used
-    ~PinnedBuf() { if (side_done) (void)hipEventDestroy(side_done); if (side) (void)hipStreamDestroy(side); if (p) (void)hipHostFree(p); }
-    hipError_t side_stream() {
-        if (side) return hipSuccess;
-        hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
-        return e;
-    }
+    hipStream_t side = nullptr;            // BORROWED (the context's second stream, set by the caller of build_flat; null: none): carries the part of an upload the build does not wait for
+    hipEvent_t side_done = nullptr;        // owned, created when first used
+    ~PinnedBuf() { if (side_done) (void)hipEventDestroy(side_done); if (p) (void)hipHostFree(p); }
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
