@@ -41,7 +41,7 @@ int mrt_context_create(int device_id, MRTContext *out) {
     MRT_HIP(hipSetDevice(device_id));
     MRT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->side = nullptr; }      // (without it the whole upload rides on `stream`)
+     // (without it the whole upload rides on `stream`)
     hipDeviceProp_t prop;
     MRT_HIP(hipGetDeviceProperties(&prop, device_id));
     snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -53,7 +53,6 @@ int mrt_context_destroy(MRTContext ctx) {
     if (!ctx) return MRT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     delete ctx;
     return MRT_OK;
 }
@@ -207,7 +206,6 @@ int mrt_scene_commit(MRTScene scene) {
     MRT_TRY
     REQUIRE(scene, "mrt_scene_commit: scene is NULL");
     int rc = bind_device(scene->ctx); if (rc) return rc;
-    scene->dev.stage.side = scene->ctx->side;          // (borrowed for the commit's uploads)
     if (scene->only_transforms_changed && scene->opt.instancing && scene->dev.num_inst == scene->meshes.size())
         rc = mrt::update_tlas(scene->meshes, scene->ctx->stream, scene->dev);         // instance rows + TLAS; the BLASes stay (the refit of an animated scene)
     else rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev, scene->only_transforms_changed && !scene->opt.instancing);

@@ -6,8 +6,6 @@ struct MRTContext_ {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t side = nullptr;             // the context's second stream: the part of a commit's upload the build does not wait for (bvh_build.hip upload_normals).  Made here, once — a new
-                                            // stream's first use costs ~6 ms (its hardware queue), which belongs to start-up, not to every scene's commit
     char name[256] = {0};
 };
 struct MRTScene_ {

@@ -1066,8 +1066,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     }
     if (I == 0) for (int c = 0; c < 4; c++) h_cols[c] = make_float4(0, 0, 0, 0);
     // the big copies (positions, normals float3 -> float4, indices) as tasks of <= 2 MB for a few threads; the small tables here
-    // what the build reads (positions, indices) is filled first, by a few threads; the normals — read by the renderer only — are filled by one more thread meanwhile and go up on a
-    // second stream while the build's kernels run (DragonScene: 1.65 ms of staging before the first kernel became ~1.0)
+    // what the build reads (positions, indices) is filled first, by a few threads; the normals — read by the renderer only — are filled by one more thread meanwhile and go up behind the
+    // topology's kernels (DragonScene: 1.65 ms of staging before the first kernel became 0.45)
     std::vector<std::function<void()>> tasks, tasks_n; size_t task_bytes = 0;
     constexpr size_t CH = (size_t)1 << 19;        // elements per task (2 MB of floats)
     size_t vb = 0, tb = 0, ib = 0, nr = 0;
@@ -1119,15 +1119,13 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(hipMemcpyAsync(out.geom_base.p, h_gbase, slots * 4, hipMemcpyHostToDevice, stream));
     MRT_HIP(hipMemcpyAsync(out.inst_cols.p, h_cols, n_cols * 16, hipMemcpyHostToDevice, stream));
 
-    // the normals: once their staging is filled, on the second stream; `stream` waits for them before the build's last launches (below), so whoever waits for `stream` has them
+    // the normals go up once their staging is filled, behind the topology's kernels on the same stream.  (A second stream for them — the copy beside the kernels — was built and measured:
+    // made per scene it cost 6 ms per commit, a new stream's first use sets up a hardware queue; made once per context it cost nothing here and 25 % of the renderer's one-frame latency,
+    // 1.85 against 1.51 ms: every kernel of a lone frame ran slower with one more stream in use on the device.  profiles/r04_build_probe.txt)
     auto upload_normals = [&]() -> int {
         if (keep_geometry) return MRT_OK;
         normals_fill.join();
-        if (!stg.side) { MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream)); return MRT_OK; }
-        if (!stg.side_done) MRT_HIP(hipEventCreateWithFlags(&stg.side_done, hipEventDisableTiming));
-        MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stg.side));
-        MRT_HIP(hipEventRecord(stg.side_done, stg.side));
-        MRT_HIP(hipStreamWaitEvent(stream, stg.side_done, 0));
+        MRT_HIP(hipMemcpyAsync(out.normals.p, h_nrm, n_nrm * 16, hipMemcpyHostToDevice, stream));
         return MRT_OK;
     };
     if (T == 0) {       // empty scene: every ray misses
@@ -1314,7 +1312,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     MRT_HIP(hipEventRecord(ev1, stream));
     uint32_t h_sum[12];
     MRT_HIP(hipMemcpyAsync(h_sum, summary.p, sizeof h_sum, hipMemcpyDeviceToHost, stream));
-    if (int rc = upload_normals()) return rc;          // (every kernel of the topology is enqueued by now: the copy runs beside them; the layouts' launches below come after it)
+    if (int rc = upload_normals()) return rc;          // (every kernel of the topology is enqueued by now: the fill has had that long)
     MRT_HIP(hipStreamSynchronize(stream));
     MRT_HIP(hipGetLastError());
     float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));

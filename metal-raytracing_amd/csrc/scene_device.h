@@ -172,9 +172,7 @@ struct PinnedBuf {
     void *p = nullptr; size_t cap = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
-    hipStream_t side = nullptr;            // BORROWED (the context's second stream, set by the caller of build_flat; null: none): carries the part of an upload the build does not wait for
-    hipEvent_t side_done = nullptr;        // owned, created when first used
-    ~PinnedBuf() { if (side_done) (void)hipEventDestroy(side_done); if (p) (void)hipHostFree(p); }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
