@@ -490,7 +490,6 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     REQUIRE(r && key, "mrt_debug_renderer_set_option: bad argument");
     std::string k(key);
     if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
-    else if (k == "hit_stage") { REQUIRE(value == 0 || value == 1, "hit_stage must be 0 or 1"); r->r.hit_stage = (int)value; }
     else if (k == "xcd_counters") { REQUIRE(value == 0 || value == 1, "xcd_counters must be 0 or 1"); r->r.xcd_counters = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
@@ -515,7 +514,6 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     if (k == "persistent") *value = r->r.persistent;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
     else if (k == "xcd_counters") *value = r->r.xcd_counters;
-    else if (k == "hit_stage") *value = r->r.hit_stage;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "stream_even") *value = r->r.stream_even;
     else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;

@@ -60,7 +60,6 @@ struct Renderer {
     bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
     int primary_wide = 2;                // primary rays of a flattened scene: 2 = one ray per lane on the 8-wide layout (inside shade(0) or in their own launch; default), 1 = the 8-wide stream kernel with lane refill (own launch), 0 = the rope walk (scene option rope = 1)
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
-    int hit_stage = 1;                   // bounce + shadow launches: 1 = hit records leave through LDS tiles, a batch of 64 at a time (traverse_wide.h HitStage), 0 = one store per record
     int xcd_counters = 1;                  // pulling traversal launches: 1 = one work counter and one eighth of every sub-frame's rays per XCD (traverse_wide.h XcdRegions), 0 = one counter for all
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)

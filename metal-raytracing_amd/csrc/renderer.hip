@@ -205,11 +205,10 @@ static inline uint32_t stream_rays_per_wave(size_t slots) {
 #ifndef MRT_WIDE_STREAM_WAVES
 #define MRT_WIDE_STREAM_WAVES (MRT_WIDE_SPEC ? 6 : 7)      // the second triangle group costs two registers: 80 instead of 72 (no spills); the frame rate does not depend on 6 or 7 waves per SIMD
 #endif
-template <class Stage> MRT_DEV Stage stage_of(float4 *hits, float4 *tiles) { if constexpr (Stage::on) return Stage{hits, tiles}; else return Stage{}; }
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t rays_per_wave, uint8_t *__restrict__ lit, uint32_t even_waves, uint32_t stage_words /* LDS words in front of the hit tiles (traverse_wide.h HitStage); 0: none */) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t rays_per_wave, uint8_t *__restrict__ lit, uint32_t even_waves) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -218,8 +217,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    using Stage = typename std::conditional<TWO_LEVEL, NoStage, HitStage>::type;          // (the in-loop two-level walk has no registers to spare: its records go out one by one)
-    traverse_wide_stream<TWO_LEVEL, false, false, NoPairs, Stage>(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
+    traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, min(n, begin + rays_per_wave)}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {      // tag = index in the ray's own queue
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -235,7 +233,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
             } else {
                 qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
             }
-        }, nullptr, NoPairs{}, stage_of<Stage>(hits, stage_words ? reinterpret_cast<float4 *>(stk_dyn + stage_words) : nullptr));
+        });
 }
 
 #ifdef MRT_WAVE_TIMES      // diagnostics build (tools/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
@@ -247,7 +245,7 @@ __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: ite
 template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const float4 *__restrict__ scon,
-                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes /* > 0: XCD regions (XcdRegions), the pass's sub-frames */, uint32_t stage_words /* LDS words in front of the hit tiles; 0: none */) {
+                                                                const unsigned long long *__restrict__ counts, float4 *__restrict__ sample, uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes /* > 0: XCD regions (XcdRegions), the pass's sub-frames */) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -282,9 +280,8 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
     StreamStats *const wss = nullptr;
 #endif
     // two-level scenes keep the one counter (the first of the eight): the per-XCD form measured no gain there and costs the in-loop walk five spilled registers
-    if constexpr (TWO_LEVEL) traverse_wide_stream<true>(s, SharedCounter{work, n, chunk}, stk_dyn, fetch, emit, wss);          // (no hit tiles: see k_trace_mixed_wide_stream)
-    else traverse_wide_stream<false, false, false, NoPairs, HitStage>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn, fetch, emit, wss, NoPairs{},
-                                                                      HitStage{hits, stage_words ? reinterpret_cast<float4 *>(stk_dyn + stage_words) : nullptr});
+    if constexpr (TWO_LEVEL) traverse_wide_stream<true>(s, SharedCounter{work, n, chunk}, stk_dyn, fetch, emit, wss);
+    else traverse_wide_stream<false>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn, fetch, emit, wss);
 }
 
 #include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes
@@ -1169,17 +1166,13 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool on_wide = wide_bounce && sv.num_wnodes > 0;          // no 8-wide layout (scene option wide = 0, a tree deeper than WIDE_STACK_MAX): the rope kernels
             // two-level scenes walk TLAS and BLASes with the same kernels (traverse_wide_stream<true>); their LDS also parks the lanes' world rays
             const size_t stack_bytes = (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (two_level ? WIDE_WORLD_RAY_BYTES : 0);
-            // the bounce + shadow launches collect their hit records in LDS tiles behind the stack (traverse_wide.h HitStage; the tile rides in two bits of the tag: queues below 2^29 rays)
-            const bool stage_hits = hit_stage != 0 && on_wide && !two_level && 2 * (size_t)capacity * (size_t)B < ((size_t)1 << 29);
-            const size_t mixed_lds = stack_bytes + (stage_hits ? (size_t)HitStage::K * 64 * sizeof(float4) : 0);
-            const uint32_t stage_words = stage_hits ? (uint32_t)(stack_bytes / 4) : 0u;
-            if (on_wide && persistent != 0 && slots_for_stack != mixed_lds) {       // wave slots of the chip for this kernel at this LDS size
+            if (on_wide && persistent != 0 && slots_for_stack != stack_bytes) {       // wave slots of the chip for this kernel at this LDS size
                 int per_cu = 0, dev = 0; hipDeviceProp_t prop;
                 MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
-                if (two_level) MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<true>, 64, mixed_lds));
-                else MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<false>, 64, mixed_lds));
+                if (two_level) MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<true>, 64, stack_bytes));
+                else MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist<false>, 64, stack_bytes));
                 if (!wave_slots_user) wave_slots = std::max(1, per_cu) * prop.multiProcessorCount;
-                slots_for_stack = mixed_lds;
+                slots_for_stack = stack_bytes;
             }
             // traversal launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, the
             // same clock rocprofv3 reads): plain hipEventRecord pairs on a stream also count the time a launch waits behind the
@@ -1291,17 +1284,17 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
                     const uint32_t chunk_arg = chunk;
 #endif
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), mixed_lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u, stage_words);
-                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), mixed_lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
-                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u, stage_words);
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                                 (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
                 }
                 else if (on_wide) {
                     const size_t slots_m = 2 * (size_t)capacity * B;
                     const uint32_t even = stream_even > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)stream_even / 100)) : 0u;     // stream_even: percent of the wave slots
                     const dim3 grid_s(even ? even : cdiv(slots_m, rpw_m));
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), mixed_lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even, stage_words);
-                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), mixed_lds, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even, stage_words);
+                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
+                    else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }
                 else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<true>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);
                 else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<false>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);

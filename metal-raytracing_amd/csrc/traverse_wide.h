@@ -538,20 +538,6 @@ struct PairQueue {
     }
 };
 
-// Hit records through LDS (the traversal launches of the pipeline).  A lane writes its ray's 16-byte hit record when the ray ends, into hits[ray index]: four records share a 64-byte line and
-// arrive at four different refills, tens of microseconds apart — longer than a line survives in the L2 — so that every record went out as a write of its own (measured: 42-64 bytes of
-// WRITE_SIZE per 16-byte record, a third of the kernel's memory traffic).  With a HitStage the records of a batch of 64 consecutive rays are collected in one of K 1 KB tiles of the wave's LDS
-// and written by the whole wave — 64 lanes x 16 bytes, whole lines — when the batch's last ray ends.  A batch takes the tile the batch K before it had; whatever of that one is still unfinished
-// (a long ray) goes out record by record as before (its tile is written as far as it got).  The ray's tile rides in bits 29, 30 of the lane's tag word: tags stay below 2^29.
-struct NoStage { static constexpr bool on = false; static constexpr uint32_t K = 0, NONE = 3, TAG_MASK = 0x7FFFFFFFu, FREE = 0xFFFFFFFFu, PENDING = 0u; };
-struct HitStage {
-    static constexpr bool on = true;
-    static constexpr uint32_t K = 2, NONE = 3, TAG_MASK = 0x1FFFFFFFu, FREE = 0xFFFFFFFFu, PENDING = 0x7FC0DEADu;      // PENDING: the x word of a tile entry whose ray has not ended (a NaN no hit record holds)
-    float4 *__restrict__ hits;         // the launch's hit records, by ray index
-    float4 *tiles;                     // LDS: K x 64 records of this wave; null: no staging (every record straight to hits[])
-};
-MRT_DEV float4 hit_record(bool hit, const TravHit &h) { return hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); }
-
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -562,8 +548,8 @@ MRT_DEV float4 hit_record(bool hit, const TravHit &h) { return hit ? make_float4
 // SEED (primary rays with a hint, k_trace_primary_wide_stream): `fetch` also returns a candidate hit — a packet (| instance << 24) whose distance it has already put
 // into the ray's limit word — and the walk starts with it as its closest hit so far; TravHit::pk at emit time is the final hit in the same encoding.
 // ROOTS (with TWO_LEVEL = false): `fetch` also returns the node the ray's walk starts at (the root of its instance's BLAS in the shared node array) instead of node 0.
-template <bool TWO_LEVEL = false, bool SEED = false, bool ROOTS = false, class Pairs = NoPairs, class Stage = NoStage, class Chunks, class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr, Pairs pq = Pairs{}, Stage hs = Stage{}) {
+template <bool TWO_LEVEL = false, bool SEED = false, bool ROOTS = false, class Pairs = NoPairs, class Chunks, class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr, Pairs pq = Pairs{}) {
     const uint32_t lane = threadIdx.x & 63;
     float *const wray = reinterpret_cast<float *>(stack);      // [6][64]: o.xyz, d.xyz of the lane's ray in world space (TWO_LEVEL)
     if (TWO_LEVEL) stack += WIDE_WORLD_RAY_BYTES / 4u;
@@ -595,24 +581,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
     // (two-level scenes: tried inside the BLASes, MRT_WIDE_SPEC_TWO_LEVEL — 86 instead of 80 registers and no faster, twice: 6.27 vs 6.38 and 6.65 vs 6.63 Grays/s on dragon x 4; left off there)
     constexpr bool SPEC = (TWO_LEVEL ? MRT_WIDE_SPEC_TWO_LEVEL : MRT_WIDE_SPEC) != 0;
     uint32_t u_base = 0, u_mask = 0;
-    // HitStage (wave-uniform): per tile the first ray index of its batch (FREE: none), the closest-hit rays the batch has — its first st_need entries: the queue is [closest-hit rays | any-hit
-    // rays] — and how many of them have not ended yet
-    uint32_t st_base[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, st_need[2] = {0, 0}, st_left[2] = {0, 0}, st_next = 0;
-    auto stage_flush = [&](uint32_t t, bool complete) {          // the whole wave: tile t to hits[] (complete: every entry is there; else those that are)
-        if constexpr (Stage::on) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (lane < st_need[t]) {
-                const float4 e = hs.tiles[t * 64u + lane];
-                if (complete || __float_as_uint(e.x) != Stage::PENDING) qstore(&hs.hits[st_base[t] + lane], e);
-            }
-            st_base[t] = Stage::FREE;
-        }
-    };
     for (;;) {
         const unsigned long long m_idle = __ballot(!live);
         const uint32_t n_idle = (uint32_t)__popcll(m_idle);
         if (n_idle >= (uint32_t)WIDE_REFILL_AT || m_idle == ~0ull) {
-            uint32_t staged_now = 3u;                        // HitStage: the tile this lane has just put a record into
             if (unreported) {
                 const bool was_any = (tagw >> 31) != 0, was_hit = best_pk != 0xFFFFFFFFu;
                 TravHit h; h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
@@ -631,55 +603,21 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     }
                 }
                 if (SEED) h.pk = was_hit ? (best_pk | (TWO_LEVEL ? (insts >> 16) << 24 : 0u)) : 0xFFFFFFFFu;
-                if constexpr (Stage::on) {
-                    if (was_any) emit(tagw & Stage::TAG_MASK, true, was_hit, h);
-                    else {
-                        const uint32_t tag = tagw & Stage::TAG_MASK, t = (tagw >> 29) & 3u;
-                        const uint32_t tb = t == 0u ? st_base[0] : st_base[1], pos = tag - tb;          // pos < 64 exactly when the ray's batch still holds tile t
-                        if (t < Stage::K && tb != Stage::FREE && pos < 64u) { hs.tiles[t * 64u + pos] = hit_record(was_hit, h); staged_now = t; }
-                        else qstore(&hs.hits[tag], hit_record(was_hit, h));
-                    }
-                } else emit(tagw & 0x7FFFFFFFu, was_any, was_hit, h);
-                unreported = false;
-            }
-            if constexpr (Stage::on) {
-                if (hs.tiles) {
-#pragma unroll
-                    for (uint32_t t = 0; t < Stage::K; t++) {
-                        const unsigned long long m = __ballot(staged_now == t);
-                        if (m != 0ull) { st_left[t] -= (uint32_t)__popcll(m); if (st_left[t] == 0u) stage_flush(t, true); }
-                    }
-                    staged_now = Stage::NONE;
-                }
+                emit(tagw & 0x7FFFFFFFu, was_any, was_hit, h); unreported = false;
             }
             if (batch_used >= batch_n) {                        // prefetch the next (up to) 64 rays (coalesced), all lanes
                 if (cur >= end && more) more = next_chunk(cur, end);
                 batch_n = cur < end ? min(64u, end - cur) : 0u; batch_used = 0;
                 if (Pairs::on) batch_first = cur;
-                uint32_t tag = 0, is_any = 0;
-                if (lane < batch_n) { if constexpr (SEED || ROOTS) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any); }
-                uint32_t tile = 3u;
-                if constexpr (Stage::on) {
-                    // the batch's closest-hit rays get the next tile (their tags are their ray indices cur + lane); what the tile still held goes out as it is
-                    const unsigned long long vb = __ballot(lane < batch_n && is_any == 0u);
-                    if (hs.tiles && vb != 0ull) {
-                        tile = st_next; st_next = st_next + 1u == Stage::K ? 0u : st_next + 1u;
-                        if (st_base[tile] != Stage::FREE) stage_flush(tile, false);
-                        st_base[tile] = cur; st_need[tile] = (uint32_t)__popcll(vb); st_left[tile] = st_need[tile];
-                        hs.tiles[tile * 64u + lane].x = __uint_as_float(Stage::PENDING);
-                    }
+                if (lane < batch_n) {
+                    uint32_t tag = 0, is_any = 0;
+                    if constexpr (SEED || ROOTS) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any);
+                    pB.w = __uint_as_float((tag & 0x7FFFFFFFu) | (is_any << 31));
                 }
-                if (lane < batch_n) pB.w = __uint_as_float((tag & (Stage::on ? Stage::TAG_MASK : 0x7FFFFFFFu)) | (is_any << 31) | ((Stage::on && is_any == 0u) ? tile << 29 : 0u));
                 cur += batch_n;
             }
             const uint32_t avail = batch_n - batch_used;
-            if (avail == 0) {
-                if (m_idle == ~0ull) {
-                    if constexpr (Stage::on) { if (hs.tiles) { for (uint32_t t = 0; t < Stage::K; t++) if (st_base[t] != Stage::FREE) stage_flush(t, false); } }      // (every ray has ended: nothing can be left; kept for the day it can)
-                    break;
-                }
-                draining = true;
-            }
+            if (avail == 0) { if (m_idle == ~0ull) break; draining = true; }
             else {
                 const uint32_t rank = (uint32_t)__popcll(m_idle & lt);
                 const bool take = !live && rank < avail;

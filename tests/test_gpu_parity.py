@@ -359,7 +359,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
-                                     "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter", "hit_records_one_by_one", "hit_tiles_small_ranges"])
+                                     "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
@@ -377,8 +377,6 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "persistent_never": r.set_option("persistent", 0)
     if backend == "one_work_counter": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("xcd_counters", 0)      # (default: one counter and one eighth of every sub-frame's rays per XCD)
     if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
-    if backend == "hit_records_one_by_one": r.set_option("hit_stage", 0)      # (default: a batch's hit records leave through an LDS tile, traverse_wide.h HitStage)
-    if backend == "hit_tiles_small_ranges": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("wave_slots", 96)      # one batch per pull, long drains: tiles recycled under stragglers
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 8: 5 frames = one pass; three: 3 + 2
