@@ -1,6 +1,7 @@
 #!/bin/bash
 # Whose writes does rocprofv3 count for a traversal launch?  WRITE_SIZE per dispatch of serialised 8-frame passes (the configuration of tools/collect_profiles.sh), for the library as it is and
-# for a counters-only variant whose traversal kernels store NOTHING (tools/build_variant.sh skipboth "-DMRT_SKIP_HITS=1 -DMRT_SKIP_LIT=1" on a tree patched as DESIGN.md §6.82 says; the image is garbage).
+# for a counters-only variant whose traversal kernels store NOTHING (tools/build_variant.sh skipboth "-DMRT_SKIP_HITS=1 -DMRT_SKIP_LIT=1" on a tree
+# where the two emit lambdas of renderer.hip read `if (lit) { if (!MRT_SKIP_LIT) lit[...] = 1; }` and `if (!MRT_SKIP_HITS) qstore(&hits[j], ...)`, both macros defaulting to 0; the image is garbage).  DESIGN.md §6.82.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/write_attr; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in head skipboth; do
