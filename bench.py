@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--builder", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
     ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 6, each carrying frame_batch = 8 frames; the reference keeps 3 frames)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 6, each carrying frame_batch frames: 8 at 1080p and above, up to 32 for smaller images; the reference keeps 3 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra max_bounces=1 (primary + shadow only) measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg and the on-chip calibration")
@@ -230,16 +230,16 @@ def main_group(a):
     g.close()
 
 
-def launch_plan(gpus_arg, steps, warmup, shard, env, ndev):
+def launch_plan(gpus_arg, steps, warmup, shard, env, ndev, pixels=1920 * 1080):
     """What one process of a bench run does, from its arguments and environment alone (no GPU touched; tests/test_bench_contract.py checks it against DESIGN.md §7):
     torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK and those win over --gpus; without them --gpus N > 1 means ONE process driving N devices through
     the C ABI's device group.  Tile sharding: the rank's frame_batch and the passes its warm-up and timed draws split into."""
-    from metal_raytracing_amd.distributed import shard_frame_batch, pass_sizes
+    from metal_raytracing_amd.distributed import shard_frame_batch, pass_sizes, auto_frame_batch
     world = int(env.get("WORLD_SIZE", "1")); rank = int(env.get("RANK", "0")); local_rank = int(env.get("LOCAL_RANK", "0"))
     plan = {"world": world, "rank": rank, "mode": "ranks" if world > 1 else ("group" if gpus_arg > 1 else "single"), "gpus": world if world > 1 else gpus_arg,
             "device": local_rank % max(1, ndev)}                                  # more ranks than GPUs: a gloo rehearsal on one box
     n = plan["gpus"]
-    fb = shard_frame_batch(n, warmup + steps) if shard == "tile" else shard_frame_batch(1)
+    fb = shard_frame_batch(n, warmup + steps) if (shard == "tile" and n > 1) else auto_frame_batch(pixels)      # one device (or whole frames per rank): the library's default, by image size
     if plan["mode"] == "group":
         fb = shard_frame_batch(n)                                                 # mrt_group_renderer_create knows no run length; Renderer::render caps every draw itself
     plan.update(frame_batch=fb, warmup_passes=pass_sizes(warmup, fb) if warmup else [], timed_passes=pass_sizes(steps, fb))
@@ -248,7 +248,11 @@ def launch_plan(gpus_arg, steps, warmup, shard, env, ndev):
 
 def main():
     a = parse()
-    plan = launch_plan(a.gpus, a.steps, a.warmup, a.shard, os.environ, torch.cuda.device_count())
+    plan = launch_plan(a.gpus, a.steps, a.warmup, a.shard, os.environ, torch.cuda.device_count(), pixels=a.width * a.height)
+    for kv in a.opt:                                  # an explicit --opt frame_batch=N is what the passes are made of
+        if kv.startswith("frame_batch=") and float(kv.split("=")[1]) > 0 and plan["mode"] == "single":
+            from metal_raytracing_amd.distributed import pass_sizes
+            fb = int(float(kv.split("=")[1])); plan.update(frame_batch=fb, warmup_passes=pass_sizes(a.warmup, fb) if a.warmup else [], timed_passes=pass_sizes(a.steps, fb))
     world, rank, local_rank = plan["world"], plan["rank"], plan["device"]
     a.gpus = plan["gpus"]
     dist = None

@@ -250,7 +250,8 @@ int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
 /* The renderer's knobs.  The reference's own: "max_bounces" (the literal 3 of Raytracing.metal:237; 1..19), "frames_in_flight"
  * (Renderer.maxFramesInFlight, Renderer.swift:33: here passes in flight on separate HIP streams, default 6), "sample_offset" (added to
  * frameIndex for the Halton index only: sample-index sharding).  This implementation's: "frame_batch" (frames carried through the pipeline
- * per pass, default 8, <= 32: larger launches against more queue memory — "lane_bytes" per pass in flight), "megakernel" (1: one launch
+ * per pass, 1..32: larger launches against more queue memory — "lane_bytes" per pass in flight; 0, the default, sizes it by the image: 8 at 1920 x 1080 pixels
+ * per device and above, proportionally more for a smaller image or a shard of one, so that a pass always carries about the same number of pixel-frames; reads back as the value in force), "megakernel" (1: one launch
  * per frame, the lowest latency of a single frame; the default pipeline has the higher throughput), "materials" (1: the materials
  * extension — emission, specular lobe, refraction; max_bounces <= 16; the only key that changes the image).  Read-only through
  * mrt_renderer_get_option: "lanes_used", "lane_bytes".                                                                              */

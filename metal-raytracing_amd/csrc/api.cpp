@@ -460,7 +460,7 @@ int mrt_renderer_set_option(MRTRenderer r, const char *key, double value) {
     if (k == "max_bounces") { REQUIRE(value >= 1 && value <= (r->r.materials ? 16 : 19), "max_bounces must be in [1,19] ([1,16] with materials = 1)"); r->r.max_bounces = (int)value; }
     else if (k == "frames_in_flight") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAMES_IN_FLIGHT, "frames_in_flight must be in [1,16]"); r->r.frames_in_flight = (int)value; }
     else if (k == "sample_offset") { REQUIRE(value >= 0 && value < 4294967296.0, "sample_offset out of range"); r->r.sample_offset = (uint32_t)value; }
-    else if (k == "frame_batch") { REQUIRE(value >= 1 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32]"); r->r.frame_batch = (int)value; }
+    else if (k == "frame_batch") { REQUIRE(value >= 0 && value <= mrt::MAX_FRAME_BATCH, "frame_batch must be in [1,32], or 0 for the default (by image size)"); r->r.frame_batch = (int)value; }
     else if (k == "megakernel") r->r.megakernel = value != 0;
     else if (k == "materials") { REQUIRE(value == 0 || (value == 1 && r->r.max_bounces <= 16), "materials must be 0 or 1 (and max_bounces <= 16: the lobe choice uses Halton dimension 2 + 5 * max_bounces + bounce < 100)"); r->r.materials = value != 0; }
     else { mrt::set_error("mrt_renderer_set_option: unknown key " + k + " (keys: max_bounces, frames_in_flight, sample_offset, frame_batch, megakernel, materials; the library's A/B switches are behind mrt_debug_renderer_set_option)"); return MRT_ERR_INVALID_ARGUMENT; }
@@ -474,7 +474,7 @@ int mrt_renderer_get_option(MRTRenderer r, const char *key, double *value) {
     if (k == "max_bounces") *value = r->r.max_bounces;
     else if (k == "frames_in_flight") *value = r->r.frames_in_flight;
     else if (k == "sample_offset") *value = r->r.sample_offset;
-    else if (k == "frame_batch") *value = r->r.frame_batch;
+    else if (k == "frame_batch") *value = r->r.batch_wanted();          // (what is in force: under the default, 8 at 1080p and above, up to 32 for smaller images and shards)
     else if (k == "megakernel") *value = r->r.megakernel ? 1 : 0;
     else if (k == "materials") *value = r->r.materials ? 1 : 0;
     else if (k == "lanes_used") *value = r->r.lanes_used;

@@ -51,7 +51,9 @@ struct Renderer {
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
     int frames_in_flight = 6;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 6 lanes x 8-frame passes measured best on MI355X (12 x 4 until then)
-    int frame_batch = DEFAULT_FRAME_BATCH;                 // frames carried through the pipeline per pass at most (a draw's frames go in passes of equal size); 1 = one frame per pass
+    int frame_batch = 0;                 // frames carried through the pipeline per pass at most (a draw's frames go in passes of equal size); 1 = one frame per pass; 0 (default) = by image size:
+                                         // DEFAULT_FRAME_BATCH at 1920 x 1080 pixels per device and above, proportionally more for a smaller image or a shard of one (batch_wanted())
+    int batch_wanted() const;            // the option, or what "by image size" comes to for this renderer's pixels
     int lanes_used = 0;                  // lanes the last draw ran on (<= frames_in_flight when device memory is short)
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for

@@ -940,10 +940,20 @@ Renderer::~Renderer() {
     }
 }
 
+// frame_batch = 0: a pass carries about as many pixel-frames as eight 1080p frames, whatever the image — a launch over 256 x 256 pixels x 8 frames is a sixteenth of one the kernels were
+// tuned on and the pipeline is launch-bound there (Cornell 256^2: 6.7 Grays/s in 8-frame passes, 9.8-10.8 in 32-frame ones; 640 x 360: 9.0 -> 10.4; 960 x 540: 10.9 -> 11.5).  The rule a
+// tile-sharded rank follows (distributed.py shard_frame_batch: 8 x world) is the same rule: its pixels are a world-th of the image.
+int Renderer::batch_wanted() const {
+    if (frame_batch > 0) return std::min(frame_batch, MAX_FRAME_BATCH);
+    const size_t owned = std::max<size_t>(1, (size_t)std::max(width, 1) * (size_t)std::max(height, 1) / (size_t)std::max(shard_world, 1));
+    const size_t ref = (size_t)DEFAULT_FRAME_BATCH * 1920 * 1080;
+    return (int)std::min<size_t>(MAX_FRAME_BATCH, std::max<size_t>(DEFAULT_FRAME_BATCH, (ref + owned - 1) / owned));
+}
+
 int Renderer::resize(int w, int h) {                                   // Renderer.swift:353-356 → createTextures :231-275
     width = w; height = h;
     const size_t npix = (size_t)w * h;
-    const int B = std::max(1, std::min(frame_batch, MAX_FRAME_BATCH));
+    const int B = batch_wanted();
     alloc_batch = B;
     MRT_HIP(hint.alloc(npix));
     MRT_HIP(hipMemsetAsync(hint.p, 0xFF, hint.bytes(), stream));
@@ -1067,7 +1077,7 @@ int Renderer::render(int n_frames) {                                   // Render
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
     const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const bool two_level = sv.num_inst > 0;          // instanced scene: TLAS + BLASes walked by the same kernels (<TWO_LEVEL>)
-    if (alloc_batch != std::max(1, std::min(frame_batch, MAX_FRAME_BATCH))) {      // option changed since the buffers were sized
+    if (alloc_batch != batch_wanted()) {      // option (or the shard, under frame_batch = 0) changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
         const uint32_t keep_frame = frame_index; const int keep_cur = cur; const uint64_t keep_rendered = frames_rendered;
         DevBuf<float4> keep; MRT_HIP(keep.alloc(accum[cur].n));

@@ -19,6 +19,13 @@ DEFAULT_FRAME_BATCH = 8      # csrc/renderer.h DEFAULT_FRAME_BATCH: frames a pas
 MAX_FRAME_BATCH = 32         # csrc/renderer.h MAX_FRAME_BATCH
 
 
+def auto_frame_batch(pixels, base=DEFAULT_FRAME_BATCH):
+    """The library's default frames per pass (renderer option frame_batch = 0, csrc/renderer.hip Renderer::batch_wanted): a pass carries about as many pixel-frames as
+    eight 1920 x 1080 frames — 8 at that size and above, proportionally more for a smaller image, at most 32."""
+    ref = base * 1920 * 1080
+    return min(MAX_FRAME_BATCH, max(base, -(-ref // max(1, int(pixels)))))
+
+
 def shard_frame_batch(world, frames_total=None, base=DEFAULT_FRAME_BATCH):
     """Frames per pass of one rank of a `world`-GPU tile-sharded run.  A rank owns 1/world of the pixels of every frame, so it carries
     proportionally more frames per pass to keep its launches large (base x world, at most 32) — but never more than a third of the run's frames (and never
@@ -84,8 +91,7 @@ class ShardedRenderer:
                 # 1/world of the pixels per frame: carry proportionally more frames per pass so that the launches stay large — but a short run
                 # still needs about three passes to overlap (tools/tile_scaling_probe.py, rank 0 of N on one GPU, 20 frames: N = 8 at 32 frames
                 # per pass 4.98, at 8 frames per pass 5.42 Grays/s per rank; 240 frames: 9.73 at 32, 8.66 at 8)
-                base = int(self.renderer.get_option("frame_batch"))          # the library's default (8)
-                self.renderer.set_option("frame_batch", shard_frame_batch(world, frames_total, base))
+                self.renderer.set_option("frame_batch", shard_frame_batch(world, frames_total))
             else:
                 if frames_total is None:
                     raise ValueError("sample sharding needs frames_total (frames per rank)")

@@ -133,7 +133,7 @@ class Renderer:
     @property
     def maxFramesInFlight(self):
         """Renderer.maxFramesInFlight (Renderer.swift:33 keeps 3).  Here: passes in flight on separate HIP streams, each carrying
-        `frame_batch` frames (library defaults 6 x 8); set with set_option("frames_in_flight", n)."""
+        `frame_batch` frames (library defaults: 6 passes in flight x 8 frames at 1080p and above, up to 32 frames per pass for smaller images); set with set_option("frames_in_flight", n)."""
         return int(self.get_option("frames_in_flight"))
 
     def __init__(self, size, scene=None, device=0, seed=1, max_bounces=3, ctx=None, scene_options=None):

@@ -38,6 +38,10 @@ def test_launch_plan_of_every_rank_count_matches_design_section_7():
     assert shard_frame_batch(8, frames_total=25) == 8 and shard_frame_batch(8, frames_total=60) == 20 and shard_frame_batch(2, frames_total=1000) == 16
     assert pass_sizes(20, 8) == [7, 7, 6] and pass_sizes(20, 32) == [7, 7, 6] and pass_sizes(16, 8) == [8, 8] and pass_sizes(1, 8) == [1] and pass_sizes(48, 8) == [8] * 6
     assert pass_sizes(100, 32) == [25] * 4 and pass_sizes(5, 1) == [1] * 5
+    # the library's default frames per pass (frame_batch = 0): by image size, eight 1080p frames' worth of pixel-frames, 8 ... 32
+    from metal_raytracing_amd.distributed import auto_frame_batch
+    assert [auto_frame_batch(w * h) for w, h in ((3840, 2160), (1920, 1080), (1600, 900), (960, 540), (640, 360), (256, 256), (1, 1))] == [8, 8, 12, 32, 32, 32, 32]
+    assert bench.launch_plan(1, 240, 24, "tile", {}, ndev=1, pixels=256 * 256)["timed_passes"] == [30] * 8 and bench.launch_plan(1, 20, 5, "tile", {}, ndev=1, pixels=256 * 256)["timed_passes"] == [7, 7, 6]
 
 
 @pytest.mark.gpu

@@ -90,6 +90,8 @@ def test_frames_completed_never_blocks_and_ends_at_the_total(mrt, gpu_ctx):
     w, h = 640, 360
     r = mrt.Renderer((w, h), mrt.CornellScene((w, h)), ctx=gpu_ctx)
     assert r.framesCompleted == 0
+    assert r.get_option("frame_batch") == 32          # the default, by image size: 640 x 360 is a ninth of 1920 x 1080 (8 there, at most 32)
+    r.set_option("frame_batch", 8)                    # this test counts passes of eight
     r.draw(3, wait=True)
     assert r.framesCompleted == 3 == r.stats.frames
     n = 400

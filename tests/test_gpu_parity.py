@@ -400,12 +400,15 @@ def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
     w, h = 200, 120
     sc = mrt.CornellScene((w, h))
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
-    assert r.get_option("frame_batch") == 8
+    assert r.get_option("frame_batch") == 32   # the default goes by image size (8 at 1920 x 1080 and above, up to 32 below); reads back as the value in force
     r.draw(3, wait=True)                       # one pass of 3
     r.set_option("frame_batch", 2); r.draw(5, wait=True)    # 2 + 2 + 1
     r.set_option("frame_batch", 8); r.draw(3, wait=True)    # one pass of 3
-    assert r.frameIndex == 11
-    ref, cnt = oracle_render(orc, mrt, sc, w, h, 11)
+    assert r.get_option("frame_batch") == 8
+    r.set_option("frame_batch", 0); r.draw(40, wait=True)   # back to the default: 32 here, and a draw's passes take at most a third of it each (14 + 13 + 13)
+    assert r.get_option("frame_batch") == 32
+    assert r.frameIndex == 51
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 51)
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     with pytest.raises(mrt.MRTError):
