@@ -8,7 +8,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 npass = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 def first_of_pass(n):        # the launch a pass starts with: the primary trace, or the shade launch that carries it (fuse_primary)
     m = re.search(r"k_shade<([^>]*)>", n)
-    return "k_trace_primary" in n or (m is not None and len(m.group(1).split(",")) == 5 and m.group(1).split(",")[4].strip() == "true")
+    return "k_trace_primary" in n or (m is not None and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3].strip() in ("1", "2", "3"))      # k_shade<MATERIALS, CHAIN, PLANES, TRACE0, PAIRS>: TRACE0 != 0
 prim = [i for i, r in enumerate(rows) if first_of_pass(r["Kernel_Name"])]
 start = prim[-npass]
 t0 = int(rows[start]["Start_Timestamp"])
