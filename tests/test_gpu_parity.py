@@ -416,6 +416,27 @@ def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
     r.close()
 
 
+@pytest.mark.parametrize("size", [(333, 187), (64, 64), (1000, 3), (257, 129)])
+def test_chunk_pulling_covers_every_ray_whatever_the_rounding(mrt, gpu_ctx, size):
+    """The pulling traversal launches cut the combined queue [bounce rays | shadow rays] into eight regions (one work counter per XCD), each the x-th eighth of every sub-frame's share
+    of each part, rounded up at every level (traverse_wide.h XcdRegions).  Whatever the queue lengths, the chunk size, the frames per pass and the number of waves, every ray must be
+    walked exactly once: image and ray counts equal those of the static split (persistent = 0), which has no regions, no counters and no rounding."""
+    w, h = size
+    sc = mrt.DragonScene((w, h))
+    ref = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    ref.set_option("persistent", 0); ref.set_option("frame_batch", 8)
+    ref.draw(11, wait=True)
+    want, counts = ref.accumulation().copy(), (ref.stats.closest_rays, ref.stats.shadow_rays)
+    ref.close()
+    for chunk, fb, slots, xcd in ((64, 1, 96, 1), (64, 3, 7, 1), (128, 8, 1000, 1), (192, 11, 33, 1), (320, 32, 8, 1), (64, 5, 9, 0), (4096, 8, 64, 1)):
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+        r.set_option("persistent", 1); r.set_option("persist_chunk", chunk); r.set_option("frame_batch", fb); r.set_option("wave_slots", slots); r.set_option("xcd_counters", xcd)
+        r.draw(11, wait=True)
+        assert (r.stats.closest_rays, r.stats.shadow_rays) == counts, (size, chunk, fb, slots, xcd)
+        assert np.array_equal(r.accumulation().view(np.uint32), want.view(np.uint32)), (size, chunk, fb, slots, xcd)
+        r.close()
+
+
 # ---------------------------------------------------------------- more edge cases
 def test_empty_scene_and_tiny_sizes(mrt, orc, gpu_ctx):
     class Empty(mrt.Scene):
