@@ -63,10 +63,12 @@ class Triangles:
     def __len__(self):
         return len(self.v0)
 
-    def intersect(self, o, d, tmax, chunk=2048):
+    def intersect(self, o, d, tmax, chunk=None):
         """All rays against all triangles.  Returns per ray (t, u, v, tri) of the nearest hit with 0 <= t <= tmax
         (tri = -1: miss), and the runner-up distance `t2` (inf if none) so callers can tell near-ties apart."""
         R = len(o)
+        if chunk is None:
+            chunk = int(max(8, min(2048, 8_000_000 // max(1, len(self)))))      # rays per block: a handful of (rays x triangles) float64 temporaries of <= 64 MB each
         best_t = np.full(R, np.inf); best_u = np.zeros(R); best_v = np.zeros(R); best_i = np.full(R, -1, np.int64); second = np.full(R, np.inf)
         ok_tri = self.gdet > 0                                     # degenerate triangles have no interior
         for a in range(0, R, chunk):

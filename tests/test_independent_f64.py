@@ -94,3 +94,109 @@ def test_oracle_image_matches_float64_restatement_on_a_cornell_crop(orc, mrt):
         assert (d[safe] <= 2e-5).mean() >= 0.97, f"{(d[safe] > 2e-5).sum()} of {safe.sum()} safe pixels differ by more than 2e-5 (max {d[safe].max():.3g})"
         assert np.median(d) < 1e-6
         assert ref.max() > 0.5 and (ref.sum(1) > 0).mean() > 0.5       # the crop is lit: the comparison is not vacuous
+
+
+def _crop_against_f64(orc, mrt, sc, W, H, x0, y0, frames=2, side=16):
+    """The oracle's fp32 image of `sc` against tests/f64_reference.render_frame on a side x side block, `frames` accumulated frames; the tolerance rule of the
+    Cornell crop above, scaled with the radiance range.  Returns (f64 radiance of frame 0, margin, oracle scene, triangles) for the callers' own checks."""
+    flat = mrt.flatten_scene(sc)
+    osc = orc.OracleScene(flat, sc.lights)
+    r = orc.OracleRenderer(osc, W, H, seed=1, max_bounces=3, camera=sc.camera)
+    tris = F.Triangles(flat)
+    assert len(tris) == osc.triangles
+    seeds = np.array([orc.seed_hash(1, i) for i in range(W * H)], np.int64).reshape(H, W)
+    pix = [(x, y) for y in range(y0, y0 + side) for x in range(x0, x0 + side)]
+    ys, xs = np.array([p[1] for p in pix]), np.array([p[0] for p in pix])
+    ref, margin, first = None, np.full(len(pix), np.inf), None
+    for f in range(frames):
+        r.render(1)
+        img = r.accumulation().copy()
+        ff, m = F.render_frame(tris, sc.lights, sc.camera, W, H, seeds, f, pix)
+        first = ff if first is None else first
+        ref = ff if f == 0 else (ff + ref * float(f)) / float(f + 1)          # Raytracing.metal:394-401
+        margin = np.minimum(margin, m)
+        got = img[ys, xs, :3].astype(np.float64)
+        assert np.all(img[ys, xs, 3] == 1.0)
+        d = np.abs(got - ref).max(1)
+        safe = margin > 1e-3
+        scale = max(1.0, float(ref.max()))
+        assert safe.mean() > 0.5, safe.mean()
+        assert (d[safe] <= 2e-5 * scale).mean() >= 0.97, f"frame {f}: {(d[safe] > 2e-5 * scale).sum()} of {safe.sum()} safe pixels differ by more than {2e-5 * scale:.1e} (max {d[safe].max():.3g})"
+        assert np.median(d) < 2e-6 * scale
+    return first, margin, tris, pix
+
+
+def _without_light(lights, k):
+    """the same lights (same count: the same light is picked for every sample) with light k's colour zeroed"""
+    import copy
+    out = [copy.copy(l) for l in lights]
+    z = type(lights[k].color)()
+    z.x = z.y = z.z = 0.0
+    out[k].color = z
+    return out
+
+
+def test_oracle_image_matches_float64_on_a_dragonscene_crop_spot_light_rotated_trs_six_submeshes(orc, mrt):
+    """DragonScene (Scene.swift:21-30 lights: area + SPOT; DragonScene.swift:14-22 transforms) with the 871 K-triangle dragon replaced by train.obj at the dragon's own
+    position / ROTATION / scale x 0.3 — a rotated, scaled, translated instance of a SIX-submesh mesh where the dragon stands, in the spot light's cone — on a 16 x 16 crop that
+    holds both trains, the fir and both planes.  Pins the oracle's spot-light branch (Raytracing.metal:292-316), M * n for a rotated TRS (:266-268) and the per-submesh colour
+    lookup (:262-269) against a formulation that shares none of its arithmetic."""
+    W, H = 96, 54
+
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            full = mrt.DragonScene(size).models
+            dr = [mo for mo in full if mo.name == "dragon"][0]
+            self.models = [mo if mo.name != "dragon" else mrt.Model(name="train", position=dr.position, rotation=dr.rotation, scale=0.3 * dr.scale) for mo in full]
+    sc = S((W, H))
+    assert [l.type for l in sc.lights] == [4, 2] and sc.models[1].rotation[1] != 0
+    f0, margin, tris, pix = _crop_against_f64(orc, mrt, sc, W, H, 40, 12)
+    # not vacuous: the spot light carries a visible part of the crop, and the crop sees many submeshes of both trains
+    seeds = np.array([orc.seed_hash(1, i) for i in range(W * H)], np.int64).reshape(H, W)
+    dark, _ = F.render_frame(tris, _without_light(sc.lights, 1), sc.camera, W, H, seeds, 0, pix)
+    assert ((f0 - dark).max(1) > 0.02).mean() > 0.1, ((f0 - dark).max(1) > 0.02).mean()
+    cam = sc.camera
+    f3 = lambda v: np.array([v.x, v.y, v.z], np.float64)
+    px = np.array(pix, np.float64) + 0.5
+    uv = px / np.array([W, H]) * 2 - 1
+    d = uv[:, :1] * f3(cam.right) + uv[:, 1:] * f3(cam.up) + f3(cam.forward); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    _, _, _, ti, _ = tris.intersect(np.broadcast_to(f3(cam.position), d.shape), d, np.full(len(d), np.inf))
+    seen = {tuple(tris.ids[k][:2]) for k in ti if k >= 0}
+    assert len({g for i, g in seen if i == 0}) >= 4 and len({g for i, g in seen if i == 1}) >= 4, seen      # (instance, geometry): >= 4 submeshes of each train
+
+
+def test_oracle_image_matches_float64_on_a_garden_crop_sun_and_spot(orc, mrt):
+    """BASELINE.json configs[3]'s lights — SPOT + SUN (Scene.swift:82-106; metal-raytracing_amd/scene.py GardenScene) — on the garden's floor, back wall, one teapot
+    (15 704 triangles, GENERATED normals, rotation 7.0 rad about y, scale 0.008) and two firs, 16 x 16 crop over the teapot's silhouette and shadow.  Pins the oracle's
+    sun branch (Raytracing.metal:323-327: infinite light distance, no falloff) and the spot branch at another geometry."""
+    W, H = 96, 54
+
+    class S(mrt.Scene):
+        def __init__(self, size):
+            super().__init__(size)
+            g = mrt.GardenScene(size)
+            keep = [("plane", None), ("plane-back", None), ("teapot", (0.8, 0.0, 2.0)), ("treefir", (0.8, 0.0, -1.2)), ("treefir", (-0.8, 0.0, 0.4))]
+            self.models = [mo for mo in g.models if any(mo.name == n and (p is None or tuple(mo.position) == p) for n, p in keep)]
+            self.lights = g.lights
+    sc = S((W, H))
+    assert [l.type for l in sc.lights] == [2, 1] and len(sc.models) == 5
+    f0, margin, tris, pix = _crop_against_f64(orc, mrt, sc, W, H, 50, 7)
+    seeds = np.array([orc.seed_hash(1, i) for i in range(W * H)], np.int64).reshape(H, W)
+    for k in (0, 1):          # each of the two lights carries a visible part of the crop
+        dark, _ = F.render_frame(tris, _without_light(sc.lights, k), sc.camera, W, H, seeds, 0, pix)
+        assert ((f0 - dark).max(1) > 0.02).mean() > 0.1, (k, ((f0 - dark).max(1) > 0.02).mean())
+
+
+def test_oracle_image_matches_float64_on_a_cornell_crop_with_point_and_spot_lights(orc, mrt):
+    """The Cornell box lit by a POINT light (Raytracing.metal:317-322) and a spot light whose cone edge crosses the crop (the comparison `spot > cos(coneAngle)`, :306)."""
+    W = H = 64
+    sc = mrt.CornellScene((W, H))
+    sc.lights = [mrt.Light.pointLight(position=[0.3, 1.6, 0.4], color=[2.0, 1.5, 1.0]),
+                 mrt.Light.spotLight(position=[-0.6, 1.8, 0.8], direction=[0.5, -1.0, -0.6], coneAngle=np.float32(18.0 / 180.0 * np.pi), color=[5, 5, 6])]
+    assert [l.type for l in sc.lights] == [3, 2]
+    f0, margin, tris, pix = _crop_against_f64(orc, mrt, sc, W, H, 24, 20)
+    seeds = np.array([orc.seed_hash(1, i) for i in range(W * H)], np.int64).reshape(H, W)
+    for k in (0, 1):
+        dark, _ = F.render_frame(tris, _without_light(sc.lights, k), sc.camera, W, H, seeds, 0, pix)
+        assert ((f0 - dark).max(1) > 0.02).mean() > 0.1, (k, ((f0 - dark).max(1) > 0.02).mean())
