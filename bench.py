@@ -19,13 +19,15 @@ accumulated locally and ONE RCCL reduce of the RGBA32F radiance buffer assembles
 region.
 
 Prints ONE JSON line on rank 0.  Besides the driver's keys:
-  roofline        dominant kernel (bounce + shadow traversal) of the TIMED region: algorithmic bytes per launch / its average
-                  launch duration (the kernel's own start/stop events on its launching stream) against HBM 8 TB/s; `frame` is
+  roofline        dominant kernel (bounce + shadow traversal) ALONE on the chip at the default pass size: algorithmic bytes of one
+                  8-frame launch / its average launch duration (the kernel's own start/stop events on its launching stream, one
+                  stream, nothing else in flight — measured in this run right after the timed region; profiles/ holds rocprofv3's
+                  view of the same regime) against HBM 8 TB/s.  `under_overlap` is the same kernel's launch duration inside the
+                  timed region, where up to frames_in_flight passes share the chip (a regime, not a kernel time); `frame` is
                   SURVEY §8(d)'s frame-level figure bytes_alg / t_frame.
   latency         SURVEY §8(d)'s ms/frame: device time of all kernels of ONE frame (frames_in_flight = 1, frame_batch = 1,
                   median of 24), the serialised per-kernel times, and the reference's own mode (3 frames in flight).
-  valu_issue      what actually bounds the frame: wave64 VALU instructions per frame (committed SQ_INSTS_VALU pass) against
-                  the v_fma_f32 issue rate CALIBRATED on this chip in this run (mrt_debug_calibrate).
+  calibration     v_fma_f32 issue rate and divergent-gather rate CALIBRATED on this chip in this run (mrt_debug_calibrate).
   cpu_baseline    the CPU oracle on the host cores, one full frame (reported, not the target).
 """
 import argparse
@@ -164,13 +166,14 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     # the default pass size alone on the GPU: one stream, passes of PASS_FRAMES frames (the regime in which the dominant kernel's standalone duration is
     # consistent with ms_per_step; profiles/r03_kernel_stats_serial_pass.csv is rocprofv3's view of the same regime)
     q.set_option("frame_batch", PASS_FRAMES); q.draw(2 * PASS_FRAMES, wait=True)
-    four = {}
-    for _ in range(4):
+    tot = {}
+    for _ in range(5):
         q.draw(2 * PASS_FRAMES, wait=True)   # two passes per call: the grid policy of a long call (half the wave slots per traversal launch), as in the default run and in the rocprofv3 trace
         for k, (ms, n) in q.kernel_times.items():
             if n:
-                four.setdefault(k, []).append(ms / n)
-    out["kernel_ms_serialised_pass"] = {k: round(statistics.median(v), 4) for k, v in four.items()}; out["frames_per_serialised_pass"] = PASS_FRAMES
+                t = tot.setdefault(k, [0.0, 0]); t[0] += ms; t[1] += n
+    # the AVERAGE over all launches of a class (the three traversal launches of a pass carry different ray counts: rocprofv3 --stats averages the same way)
+    out["kernel_ms_serialised_pass"] = {k: round(ms / n, 4) for k, (ms, n) in tot.items()}; out["launches_serialised_pass"] = {k: n for k, (ms, n) in tot.items()}; out["frames_per_serialised_pass"] = PASS_FRAMES
     q.set_option("frame_batch", 1); q.draw(2, wait=True)
     # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
     if q.device_scene.stats.wide_layout and not (opts or {}).get("instancing"):      # (the one-launch mode renders flattened scenes on the 8-wide layout; it refuses others)
@@ -368,21 +371,20 @@ def main():
                        "lane_bytes": int(r.get_option("lane_bytes")), "persistent_traversal": int(r.get_option("persistent")),
                        "ms_per_step_is": "wall time of the timed region / steps with passes of frame_batch frames overlapped on frames_in_flight streams (inverse throughput); the per-frame device time is latency.ms_per_frame",
                        "device": r.ctx.device_name},
+            # filled below from the serialised-pass leg (the kernel alone on the chip); without that leg (--no-latency, N > 1) it holds the figure under overlap and says so
             "roofline": {"bound": "hbm", "kernel": kernel_label,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         # the counters were collected on launches of full passes (PASS_FRAMES frames, tools/collect_profiles.sh); this run's launches carry steps / passes frames: scaled by the ratio
-                         "traffic": (round(traffic_p * (a.steps / passes) / prof.get("pmc_frames_per_dispatch", PASS_FRAMES)) if traffic_p else None) if prof_applies else None,
-                         "traffic_measured": {"bytes_per_launch": traffic_p, "frames_per_launch": prof.get("pmc_frames_per_dispatch", PASS_FRAMES), "frames_per_launch_here": round(a.steps / passes, 3)} if prof_applies else None,
-                         "traffic_source": prof.get("_source") if prof_applies else None, "traffic_note": prof_note,
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
+                         "traffic": None, "traffic_source": None, "traffic_note": prof_note,
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1), "frames_per_launch": round(a.steps / passes, 3),
                          "bytes_per_closest_ray": BYTES_PER_CLOSEST_RAY, "bytes_per_shadow_ray": BYTES_PER_SHADOW_RAY,
                          "avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n,
-                         # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 6 streams, passes of 7 + 7 + 6 frames) and of the serialised frame
-                         "avg_launch_ms_rocprof_driver_command": (round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
-                         "avg_launch_ms_rocprof_serialised_one_frame": (round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None) if prof_applies else None,
-                         "avg_launch_ms_rocprof_serialised_pass": (round((prof.get("kernel_avg_us_serial_pass") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
-                         "avg_launch_ms_note": "kernel start/stop events of the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is the duration under overlap (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone; the serialised duration is latency.kernel_ms_serialised.trace",
-                         "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
+                         "regime": "UNDER OVERLAP (no serialised leg in this run): launches of the timed region, up to frames_in_flight passes sharing the chip — a launch's duration is then mostly time-slicing, not the kernel",
+                         "under_overlap": {"avg_launch_ms": round(avg_ms, 4), "launches_timed": t_n, "frames_per_launch": round(a.steps / passes, 3), "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                                           "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                                           "all_kernels_avg_launch_ms": {k: round(ms / n, 4) for k, (ms, n) in kt.items() if n},
+                                           # the committed rocprofv3 --kernel-trace --stats of the driver's command shape (20 steps, 6 streams, passes of 7 + 7 + 6 frames)
+                                           "avg_launch_ms_rocprof_driver_command": (round((prof.get("kernel_avg_us_driver") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
+                                           "note": "the dominant kernel's own start/stop events inside the timed region: launches of up to frames_in_flight passes overlap on the GPU, so this is a duration under time-slicing (what rocprofv3 --kernel-trace of the same command reports), not the kernel alone"},
                          "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
                                    "note": "SURVEY §8(d): (36 B/pixel + 96 B/closest ray + 72 B/shadow ray + one read of the scene) / t_frame"}},
         }
@@ -400,27 +402,29 @@ def main():
             out["calibration"] = {"v_fma_f32_Ginst_per_s": round(cal[0] / 1e9, 1), "v_pk_fma_f32_Ginst_per_s": round(cal[1] / 1e9, 1), "shader_clock_GHz_under_fma_load": round(cal[4] / 1e9, 3),
                                   "gather16_GBps_128MiB_table": round(cal[2] / 1e9, 1), "gather80_GBps_128MiB_table": round(cal[3] / 1e9, 1),
                                   "note": "only fp32 add/mul/fma and and/or/xor/mov/lshr issue at this rate on gfx950; min/max, conversions, compares, shifts left, bit-field and 24-bit integer ops take ~1.8x as long, rcp/sqrt 3.5x (tools/valu_rates.hip, profiles/r02_valu_rates.json)"}
-            valu = prof.get("valu_wave_insts_per_frame")
-            if valu and prof_applies:
-                rate = valu / (dt / a.steps)
-                out["valu_issue"] = {"wave_insts_per_frame": round(valu), "source": prof.get("_source"), "achieved_Ginst_per_s": round(rate / 1e9, 1),
-                                     "peak_Ginst_per_s_calibrated_v_fma_f32": round(cal[0] / 1e9, 1), "frac": round(rate / cal[0], 4),
-                                     # the instruction mix weighted with the measured issue cost of each class (profiles/r02_summary.json valu_cycles_per_frame):
-                                     # SIMD cycles of VALU issue per frame / (1024 SIMDs x clock x frame time); the chip holds 1.9 GHz under pure v_fma_f32 load
-                                     # and up to 2.4 GHz on lighter mixes, so the two clocks bracket the truth
-                                     "valu_issue_cycles_per_frame": round(prof["valu_cycles_per_frame"]) if prof.get("valu_cycles_per_frame") else None,
-                                     "cycle_weighted_frac_at_2.4GHz": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (2.4e9 * 1024), 4) if prof.get("valu_cycles_per_frame") else None,
-                                     "cycle_weighted_frac_at_fma_load_clock": round(prof["valu_cycles_per_frame"] / (dt / a.steps) / (cal[4] * 1024), 4) if prof.get("valu_cycles_per_frame") and cal[4] else None}
         if world == 1 and not a.no_latency:
             out["latency"] = latency_leg(mrt, r, scene, w, h, a.bounces, opts)
             out["ms_per_frame"] = out["latency"]["ms_per_frame"]      # SURVEY §8(d)'s ms/frame (one frame alone on the GPU), next to ms_per_step (inverse throughput)
             t4 = out["latency"]["kernel_ms_serialised_pass"].get("trace")
             if t4 and fused:
+                # THE roofline figure: the dominant kernel alone on the chip at the default pass size — one stream, passes of PASS_FRAMES frames, its own start/stop events.
+                # Algorithmic bytes of one such launch = this run's device-counted rays per frame x PASS_FRAMES / max_bounces launches per pass.
                 b4 = (BYTES_PER_CLOSEST_RAY * (closest - primary) + BYTES_PER_SHADOW_RAY * shadow) / steps_total * PASS_FRAMES / a.bounces
-                out["roofline"]["serialised_pass_launch"] = {"avg_launch_ms": t4, "frames_per_launch": PASS_FRAMES, "algorithmic_bytes_per_launch": round(b4), "achieved": round(b4 / (t4 * 1e-3) / 1e9, 2),
-                                                                   "frac": round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s",
-                                                                   "kernel_time_per_frame_ms": round(t4 * a.bounces / PASS_FRAMES, 4),
-                                                                   "note": "one stream, 8-frame passes: the dominant kernel alone at the default pass size; kernel_time_per_frame_ms <= ms_per_step is the consistency check"}
+                n4 = out["latency"]["launches_serialised_pass"].get("trace", 0)
+                R = out["roofline"]
+                R.update({"achieved": round(b4 / (t4 * 1e-3) / 1e9, 2), "frac": round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                          "avg_launch_ms": t4, "launches_timed": n4, "frames_per_launch": PASS_FRAMES, "algorithmic_bytes_per_launch": round(b4),
+                          "rays_per_launch": round(((closest - primary) + shadow) / steps_total * PASS_FRAMES / a.bounces, 1),
+                          "kernel_time_per_frame_ms": round(t4 * a.bounces / PASS_FRAMES, 4),
+                          "regime": f"the kernel ALONE: one stream, passes of {PASS_FRAMES} frames (the default pass size), nothing else on the chip; HIP start/stop events of its own launches, taken in this run after the timed region.  kernel_time_per_frame_ms <= ms_per_step is the consistency check; under_overlap has the same kernel inside the timed region",
+                          "avg_launch_ms_rocprof_serialised_pass": (round((prof.get("kernel_avg_us_serial_pass") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
+                          "avg_launch_ms_rocprof_serialised_one_frame": (round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None) if prof_applies else None})
+                if prof_applies and traffic_p and prof.get("pmc_frames_per_dispatch", PASS_FRAMES) == PASS_FRAMES:
+                    # the counters were collected on exactly these launches (serialised passes of PASS_FRAMES frames, tools/collect_profiles.sh): per launch, no scaling
+                    R.update({"traffic": round(traffic_p), "traffic_source": prof.get("_source"),
+                              "counters": {"source": prof.get("_source"), "valu_busy_pct": (prof.get("valu_busy_pct") or {}).get("k_trace_mixed_wide_persist"),
+                                           "valu_lane_utilization_pct": (prof.get("valu_lane_utilization_pct") or {}).get("k_trace_mixed_wide_persist"),
+                                           "note": "rocprofv3 --pmc passes over the same serialised 8-frame launches (VALUBusy, VALUUtilization; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md): measured, per dispatch of this kernel"}})
             # the dominant kernel ALONE: one-frame launches on one stream (the latency leg's own start/stop events), algorithmic bytes of one frame's
             # bounce + shadow rays spread over its max_bounces launches — the kernel-level figure that profiles/r02_kernel_stats_serial.csv reproduces
             t_ser = out["latency"]["kernel_ms_serialised"].get("trace")

@@ -44,6 +44,47 @@ def test_launch_plan_of_every_rank_count_matches_design_section_7():
     assert bench.launch_plan(1, 240, 24, "tile", {}, ndev=1, pixels=256 * 256)["timed_passes"] == [30] * 8 and bench.launch_plan(1, 20, 5, "tile", {}, ndev=1, pixels=256 * 256)["timed_passes"] == [7, 7, 6]
 
 
+def _roofline_identities(d, full_size=False):
+    """What makes `roofline` reproducible: frac x peak x avg_launch_ms IS the algorithmic bytes of one launch; those bytes are this run's device-counted rays per frame
+    x frames per launch / launches per pass at SURVEY §8(d)'s 96 B / 72 B; and (full-size runs, where a launch fills the chip) the kernel's serialised time per frame
+    fits inside the frame's inverse throughput."""
+    r = d["roofline"]
+    assert abs(r["frac"] * r["peak"] * 1e9 * r["avg_launch_ms"] * 1e-3 / r["algorithmic_bytes_per_launch"] - 1.0) < 2e-3, r
+    rays = d["config"]["rays_per_frame"]
+    bounces = 3
+    want = (r["bytes_per_closest_ray"] * (rays["closest"] - rays["primary"]) + r["bytes_per_shadow_ray"] * rays["shadow"]) * r["frames_per_launch"] / bounces
+    assert r["bytes_per_closest_ray"] == 96 and r["bytes_per_shadow_ray"] == 72 and abs(want / r["algorithmic_bytes_per_launch"] - 1.0) < 2e-3, (want, r["algorithmic_bytes_per_launch"])
+    if "ALONE" in r["regime"]:
+        assert abs(r["kernel_time_per_frame_ms"] - r["avg_launch_ms"] * bounces / r["frames_per_launch"]) < 1e-3
+        if full_size:
+            assert r["kernel_time_per_frame_ms"] <= d["ms_per_step"], (r["kernel_time_per_frame_ms"], d["ms_per_step"])
+
+
+def _latest_profile_line(name):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)))
+    return files[-1] if files else None
+
+
+def test_committed_driver_command_line_is_reproducible_from_profiles():
+    """The bench line of the driver's command (`--steps 20 --warmup 5`, full size) kept under profiles/ with the rocprofv3 summaries of the same tree: its roofline
+    obeys the identities above, the kernel's serialised time per frame fits in ms_per_step, and — when the line carries the committed rocprofv3 average of the same
+    serialised 8-frame launches — the live HIP-event figure agrees with it within 5 %."""
+    f = _latest_profile_line("bench_driver_command.json")
+    assert f, "profiles/rNN_bench_driver_command.json missing"
+    d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    if "regime" not in r:
+        pytest.skip(f"{os.path.basename(f)} predates the serialised-pass roofline (round 5)")
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and "1920x1080" in d["metric"]
+    _roofline_identities(d, full_size=True)
+    assert "ALONE" in r["regime"] and "under_overlap" in r and "valu_issue" not in d
+    rp = r.get("avg_launch_ms_rocprof_serialised_pass")
+    if rp:
+        assert abs(r["avg_launch_ms"] / rp - 1.0) < 0.05, (r["avg_launch_ms"], rp)
+        assert r["traffic"] and r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]          # counted HBM bytes of the same launches: never (much) below the algorithmic ones
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--width", "320", "--height", "180", "--cpu-threads", "4"],
@@ -60,7 +101,12 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and "traffic" in r
     assert r["frame"]["frac"] > 0 and r["launches_timed"] > 0 and r["avg_launch_ms"] > 0
-    assert d["config"]["passes_of_timed_draw"] == [6] and r["launches_timed"] == 3 * len(d["config"]["passes_of_timed_draw"])      # the passes bench.py's launch_plan predicts are the ones the library ran (one traversal launch per bounce and pass)
+    _roofline_identities(d)
+    # the headline figure is the kernel ALONE (serialised 8-frame passes: 5 draws x 2 passes x 3 bounces); the timed region's own launches sit in under_overlap
+    assert "ALONE" in r["regime"] and r["frames_per_launch"] == 8 and r["launches_timed"] == 30 and r["avg_launch_ms"] == d["latency"]["kernel_ms_serialised_pass"]["trace"]
+    u = r["under_overlap"]
+    assert d["config"]["passes_of_timed_draw"] == [6] and u["launches_timed"] == 3 * len(d["config"]["passes_of_timed_draw"])      # the passes bench.py's launch_plan predicts are the ones the library ran (one traversal launch per bounce and pass)
+    assert u["avg_launch_ms"] > 0 and abs(u["frac"] - u["achieved"] / r["peak"]) < 1e-4 and "valu_issue" not in d
     assert d["config"]["wide_layout"] == 1 and d["config"]["wide_depth"] >= 1 and d["config"]["scene_commit_wall_ms"] > 0
     lat = d["latency"]
     assert lat["ms_per_frame"] > 0 and lat["kernel_ms_serialised"]["trace"] > 0 and lat["reference_like_3_in_flight_ms_per_frame"] > 0
