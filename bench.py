@@ -152,20 +152,28 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     per pass, Renderer.swift:33)."""
     q = mrt.Renderer((w, h), scene, ctx=r.ctx, seed=1, max_bounces=bounces, scene_options=opts)
     q.set_option("frames_in_flight", 1); q.set_option("frame_batch", 1)
-    q.draw(3, wait=True)
-    per_frame, per_kernel = [], {}
-    for _ in range(frames):
-        q.draw(1, wait=True)
-        per_frame.append(q.stats.ms_gpu_last)
-        for k, (ms, n) in q.kernel_times.items():
-            if n:
-                per_kernel.setdefault(k, []).append(ms / n)
-    out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames,
-           "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU",
+    def one_frame_alone(groups):
+        q.set_option("tile_groups", groups)
+        q.draw(3, wait=True)
+        per_frame, per_kernel = [], {}
+        for _ in range(frames):
+            q.draw(1, wait=True)
+            per_frame.append(q.stats.ms_gpu_last)
+            for k, (ms, n) in q.kernel_times.items():
+                if n:
+                    per_kernel.setdefault(k, []).append(ms / n)
+        return per_frame, per_kernel, int(q.get_option("groups_used"))
+    # the frame as ONE pass on one stream (tile_groups = 1): seven dependent launches, each alone on the chip — the per-kernel times that are kernel times
+    whole, per_kernel, _ = one_frame_alone(1)
+    # the library's default for a lone frame: the pass as tile groups on several lanes (Renderer::tile_groups), one group's shade beside another's traversal
+    per_frame, _, groups = one_frame_alone(0)
+    out = {"ms_per_frame": round(statistics.median(per_frame), 4), "min": round(min(per_frame), 4), "max": round(max(per_frame), 4), "frames": frames, "tile_groups_used": groups,
+           "mode": "frames_in_flight=1 frame_batch=1: begin-to-end device time of one frame, nothing else on the GPU (the pass runs as tile_groups_used groups of tiles on as many HIP streams)",
+           "ms_per_frame_as_one_pass": round(statistics.median(whole), 4),
            "kernel_ms_serialised": {k: round(statistics.median(v), 4) for k, v in per_kernel.items()}}
     # the default pass size alone on the GPU: one stream, passes of PASS_FRAMES frames (the regime in which the dominant kernel's standalone duration is
     # consistent with ms_per_step; profiles/r03_kernel_stats_serial_pass.csv is rocprofv3's view of the same regime)
-    q.set_option("frame_batch", PASS_FRAMES); q.draw(2 * PASS_FRAMES, wait=True)
+    q.set_option("frame_batch", PASS_FRAMES); q.set_option("tile_groups", 1); q.draw(2 * PASS_FRAMES, wait=True)          # (whole passes, one after the other: a kernel alone on the chip)
     tot = {}
     for _ in range(5):
         q.draw(2 * PASS_FRAMES, wait=True)   # two passes per call: the grid policy of a long call (half the wave slots per traversal launch), as in the default run and in the rocprofv3 trace
@@ -174,7 +182,7 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
                 t = tot.setdefault(k, [0.0, 0]); t[0] += ms; t[1] += n
     # the AVERAGE over all launches of a class (the three traversal launches of a pass carry different ray counts: rocprofv3 --stats averages the same way)
     out["kernel_ms_serialised_pass"] = {k: round(ms / n, 4) for k, (ms, n) in tot.items()}; out["launches_serialised_pass"] = {k: n for k, (ms, n) in tot.items()}; out["frames_per_serialised_pass"] = PASS_FRAMES
-    q.set_option("frame_batch", 1); q.draw(2, wait=True)
+    q.set_option("frame_batch", 1); q.set_option("tile_groups", 0); q.draw(2, wait=True)
     # the same single frame as ONE launch (k_megakernel: whole paths per lane, no queues; lowest latency, lower throughput)
     if q.device_scene.stats.wide_layout and not (opts or {}).get("instancing"):      # (the one-launch mode renders flattened scenes on the 8-wide layout; it refuses others)
         q.set_option("megakernel", 1); q.draw(3, wait=True)
@@ -214,8 +222,11 @@ def main_group(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     g.draw(a.steps)                                         # enqueued on every device, returns at once
-    g.gather(to_host=False)                                 # waits for the frames, then the ONE reduce of the RGBA32F buffer into device 0
+    g.wait()                                                # every device's frames done ...
+    t_render = time.perf_counter() - t0
+    g.gather(to_host=False)                                 # ... then the ONE reduce of the RGBA32F buffer into device 0
     dt = time.perf_counter() - t0
+    per_rank = [g.rank_stats(k) for k in range(a.gpus)]     # what the first real SCALE record is diagnosed with: which rank the draw waited for, and what the reduce cost
     st = g.stats
     closest, shadow, primary = st.closest_rays - first.closest_rays, st.shadow_rays - first.shadow_rays, st.primary_rays - first.primary_rays
     mode, note = g.reduce_mode
@@ -226,6 +237,9 @@ def main_group(a):
                       "launch": "one process, C-ABI device group (mrt_group_*)", "shard": "tile", "reduce": note, "reduce_mode": mode,
                       "frame_batch": int(g.rank_option(0, "frame_batch")), "frames_in_flight": int(g.rank_option(0, "frames_in_flight")),
                       "rays_per_frame": {"closest": closest / a.steps, "shadow": shadow / a.steps, "primary": primary / a.steps}},
+           "per_rank": {"ms_gpu_timed_draw": [round(x.ms_gpu_last, 4) for x in per_rank], "rays_timed_plus_warmup": [int(x.closest_rays + x.shadow_rays) for x in per_rank],
+                        "render_wall_ms": round(t_render * 1e3, 4), "gather_wall_ms": round((dt - t_render) * 1e3, 4),
+                        "note": "ms_gpu_timed_draw: begin-to-end device time of the timed draw on each device (its own events); the draw's wall time is the slowest rank's plus the enqueue; gather_wall_ms is the one reduce(sum) of the image"},
            "roofline": None, "cpu_baseline": None}
     if a.dump_accum:
         np.save(a.dump_accum, g.gather())
@@ -303,12 +317,23 @@ def main():
     t0 = time.perf_counter()
     sr.draw(a.steps)                 # all K steps are enqueued at once; the first 512 launches carry their own start/stop events
     r.wait()
+    t_render = time.perf_counter() - t0
     if world > 1:
         sr.gather()
+    t_gather = time.perf_counter() - t0 - t_render
     sync()
     dt = time.perf_counter() - t0
     st = r.stats
     kt = r.kernel_times
+    per_rank = None
+    if world > 1:                    # (outside the timed region) every rank's own device time, wall time to its last frame and time inside the reduce: what a SCALE record is diagnosed with
+        mine = torch.tensor([st.ms_gpu_last, t_render * 1e3, t_gather * 1e3], dtype=torch.float64)
+        if a.dist_backend == "nccl":
+            mine = mine.cuda()
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_gpu_timed_draw": [round(float(x[0]), 4) for x in allr], "render_wall_ms": [round(float(x[1]), 4) for x in allr], "gather_wall_ms": [round(float(x[2]), 4) for x in allr],
+                    "note": "per rank: device time of the timed draw (its own events), wall time until its last frame was done, wall time inside the one reduce of the image (a rank that arrives early waits there for the slowest)"}
     rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
     tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
@@ -388,6 +413,8 @@ def main():
                          "frame": {"bytes_alg_per_frame": round(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
                                    "note": "SURVEY §8(d): (36 B/pixel + 96 B/closest ray + 72 B/shadow ray + one read of the scene) / t_frame"}},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if a.dump_accum:
             np.save(a.dump_accum, sr.buffer.cpu().numpy() if world > 1 else r.accumulation())
         if a.png:

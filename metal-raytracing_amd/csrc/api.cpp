@@ -194,6 +194,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
     else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
+    else if (k == "fat_shade") { REQUIRE(value == 0 || value == 1, "fat_shade must be 0 or 1"); scene->opt.fat_shade = (int)value; }
     else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
     else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
@@ -491,6 +492,9 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     std::string k(key);
     if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
     else if (k == "xcd_counters") { REQUIRE(value == 0 || value == 1, "xcd_counters must be 0 or 1"); r->r.xcd_counters = (int)value; }
+    else if (k == "tile_groups") { REQUIRE(value >= 0 && value <= mrt::MAX_TILE_GROUPS && value == (int)value, "tile_groups must be 0 (by the draw), 1 (never) or 2..4"); r->r.tile_groups = (int)value; }
+    else if (k == "hit_lds") { REQUIRE(value == 0 || value == 1, "hit_lds must be 0 or 1"); r->r.hit_lds = (int)value; }
+    else if (k == "lds_top") { REQUIRE(value >= 0 && value <= 4 && value == (int)value, "lds_top must be 0 (off), 1 (levels 0-1 per wave), 2 (levels 0-2 per 256-thread workgroup), 3 (levels 0-1 per 256-thread workgroup) or 4 (256-thread workgroups, nothing staged)"); r->r.lds_top = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
     else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
@@ -513,6 +517,10 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     std::string k(key);
     if (k == "persistent") *value = r->r.persistent;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
+    else if (k == "hit_lds") *value = r->r.hit_lds;
+    else if (k == "tile_groups") *value = r->r.tile_groups;
+    else if (k == "groups_used") *value = r->r.groups_used;
+    else if (k == "lds_top") *value = r->r.lds_top;
     else if (k == "xcd_counters") *value = r->r.xcd_counters;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "stream_even") *value = r->r.stream_even;

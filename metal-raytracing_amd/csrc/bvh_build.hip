@@ -45,6 +45,16 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t u) {
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 
+// ------------------------------------------------------------------ fat shading records (SceneView::tri_fat)
+__global__ void k_fat_shade(const uint4 *__restrict__ tri_shade, const float4 *__restrict__ normals, uint32_t n, float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 ts = tri_shade[i];
+    const float4 a = normals[ts.x], b = normals[ts.y], c = normals[ts.z];
+    out[3 * (size_t)i + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(ts.w));
+    out[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
+    out[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
 // ------------------------------------------------------------------ flatten
 __global__ void k_flatten(const SubRec *__restrict__ recs, int nrec, const float *__restrict__ pos,
                           const uint32_t *__restrict__ indices, const float4 *__restrict__ inst_cols, uint32_t T,
@@ -932,6 +942,16 @@ __global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, 
 
 }  // namespace
 
+int build_fat_shade(DeviceScene &out, const BuildOptions &opt, hipStream_t stream) {
+    const size_t T = out.stats.triangles;
+    if (!opt.fat_shade || T == 0) { out.tri_fat.release(); return MRT_OK; }
+    MRT_HIP(out.tri_fat.alloc(3 * T));
+    hipLaunchKernelGGL(k_fat_shade, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, stream, out.tri_shade.p, out.normals.p, (uint32_t)T, out.tri_fat.p);
+    out.stats.scene_bytes += (uint64_t)T * 48;
+    return MRT_OK;
+}
+
+
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]) {
     memset(out12, 0, 48);
     if (sc.num_wnodes == 0 || MRT_WIDE6) return MRT_OK;          // (the 64-byte node of the 6-wide variant is not decoded here)
@@ -945,7 +965,7 @@ int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]
 
 SceneView DeviceScene::view() const {
     SceneView v{};
-    v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
+    v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p; v.tri_fat = tri_fat.n > 1 ? tri_fat.p : nullptr;
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / WPK) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
@@ -1129,6 +1149,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         return MRT_OK;
     };
     if (T == 0) {       // empty scene: every ray misses
+        out.tri_fat.release();
         if (int rc = upload_normals()) return rc;
         MRT_HIP(out.nodes.alloc(8)); out.packets_offset = 4;
         MRT_HIP(hipStreamSynchronize(stream));
@@ -1374,6 +1395,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
         out.stats.build_ms += wms;
         out.wide_depth = depth;
+        { uint32_t acc = 0; for (int L = 0; L < 4; L++) { acc += (uint32_t)L < WIDE_LV_MAX ? h_lv[L] : 0u; out.wide_level_end[L] = acc; } }
         if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
@@ -1402,7 +1424,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.stats.scene_bytes += (uint64_t)h_size * 64 + (uint64_t)n * 48;
     }
     out.commit_ms[4] = since(tw4);
-    return MRT_OK;
+    return build_fat_shade(out, opt, stream);          // (behind the normals' upload on the same stream)
 }
 
 }  // namespace mrt

@@ -23,9 +23,15 @@ struct FrameLane {
     // shadow planes (default path): the light's contribution of bounces 1 and 2 per sample (bounce 0 uses `sample`) and one byte per sample and bounce "the shadow ray got through"
     DevBuf<float4> f_con[2];
     DevBuf<uint8_t> f_lit;               // [sub-frame][pixel][bounce]: one 32-bit word per sample
+    DevBuf<float4> hituv;                // two-level scenes, binned walk: per bounce ray {u, v, global triangle id, t} of the hit that last touched its key (traverse_wide.h MRT_TL_FAT)
     DevBuf<uint4> pairs;                 // two-level scenes, binned walk (tl_pairs): {ray, instance, bound, report tag} queued by the TLAS pass for the BLAS pass; allocated at the first such pass
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
+constexpr int MAX_TILE_GROUPS = 4;
+// One tile group of a pass: the renderer's own shard (rank of world) cut once more by local tile index — group g of G takes the shard's tiles g, g + G, ... — which is
+// exactly shard (g * world + rank) of (G * world).  A short draw (fewer passes than lanes) runs every pass as G such groups on G lanes: the groups are disjoint sets of
+// pixels writing the same accumulation target, so one group's shade launches overlap another's traversal launches and no launch waits for another group (Renderer::tile_groups).
+struct TileGroup { int rank = 0, world = 1, tiles_local = 0; uint32_t capacity = 0; uint64_t owned = 0; const uint32_t *seeds = nullptr; };
 constexpr int MAX_FRAME_BATCH = 32;
 constexpr int DEFAULT_FRAME_BATCH = 8;
 
@@ -54,6 +60,11 @@ struct Renderer {
     int frame_batch = 0;                 // frames carried through the pipeline per pass at most (a draw's frames go in passes of equal size); 1 = one frame per pass; 0 (default) = by image size:
                                          // DEFAULT_FRAME_BATCH at 1920 x 1080 pixels per device and above, proportionally more for a smaller image or a shard of one (batch_wanted())
     int batch_wanted() const;            // the option, or what "by image size" comes to for this renderer's pixels
+    int tile_groups = 0;                 // a pass as G tile groups on G lanes: 0 = by the draw (G > 1 only when it has fewer passes than lanes), 1 = never, 2..4 = that many whenever the lanes are there
+    int groups_used = 1;                 // G of the last draw
+    TileGroup tgroups[MAX_TILE_GROUPS];  // valid for tgroups_for groups at batch tgroups_batch (0 = not built)
+    DevBuf<uint32_t> seeds_g[MAX_TILE_GROUPS]; int tgroups_for = 0, tgroups_batch = 0;
+    int ensure_tile_groups(int G);
     int lanes_used = 0;                  // lanes the last draw ran on (<= frames_in_flight when device memory is short)
     int lanes_ready = 0;                 // lanes [0, lanes_ready) hold queues and sample buffers
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
@@ -63,6 +74,9 @@ struct Renderer {
     int primary_wide = 2;                // primary rays of a flattened scene: 2 = one ray per lane on the 8-wide layout (inside shade(0) or in their own launch; default), 1 = the 8-wide stream kernel with lane refill (own launch), 0 = the rope walk (scene option rope = 1)
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int xcd_counters = 1;                  // pulling traversal launches: 1 = one work counter and one eighth of every sub-frame's rays per XCD (traverse_wide.h XcdRegions), 0 = one counter for all
+    int hit_lds = 1;                     // pulling traversal launches of flattened scenes: a lane's closest hit keeps U, V, |det| and id in LDS; a finished ray is reported without re-testing its triangle (traverse_wide.h StreamExt)
+    int lds_top = 0;                     // the same launches read the top of the 8-wide tree from LDS: 1 = levels 0..1, a copy per wave (64-thread workgroups); 2 = levels 0..2, one copy per 256-thread workgroup; 3 = levels 0..1 per 256-thread workgroup; 4 = 256-thread workgroups, nothing staged (A/B of the workgroup shape alone)
+    int wave_slots_x = 0; int slots_x_key = -1;      // wave slots of the variant kernel those two options select, and what they were computed for
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it

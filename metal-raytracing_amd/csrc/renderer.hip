@@ -284,6 +284,38 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
     else traverse_wide_stream<false>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn, fetch, emit, wss);
 }
 
+// The pulling launch of flattened scenes with LDS extras (traverse_wide.h StreamExt; renderer options hit_lds, lds_top).  WAVES waves per workgroup share one copy of the
+// top of the tree (TOP: wnodes[0 .. top_n), loaded by the workgroup at its start — a persistent grid pays that once per wave slot); every wave has its own hit words
+// (HIT: 1 KB) and stack.  LDS layout: [top_n nodes][per wave: hit words | stack].  Shadow planes only (`lit`): the default path of the pipeline.
+template <int WAVES, bool HIT, bool TOP>
+__global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist_x(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                                uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes, uint32_t top_n, uint32_t stack_words) {
+    extern __shared__ uint32_t lds_dyn[];
+    const uint32_t wv = WAVES == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: the wave's LDS base is a scalar
+    if (TOP) {
+        float4 *const dst = reinterpret_cast<float4 *>(lds_dyn);
+        for (uint32_t i = threadIdx.x; i < top_n * WNODE_STRIDE; i += 64u * WAVES) dst[i] = s.wnodes[i];
+        __syncthreads();
+    }
+    uint32_t *const mine = lds_dyn + (TOP ? top_n * WNODE_STRIDE * 4u : 0u) + wv * ((HIT ? 256u : 0u) + stack_words);
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if ((blockIdx.x * WAVES + wv) * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once (after the workgroup's barrier)
+    auto fetch = [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
+            else tag = __float_as_uint(B.w);          // shadow planes: the ray reports to its pixel's byte
+        };
+    auto emit = [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
+            else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
+        };
+    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n};
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? 256u : 0u), fetch, emit, nullptr, NoPairs{}, ext);
+}
+
 #include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes
 #include "megakernel.h"            // k_megakernel: one launch per frame
 
@@ -453,7 +485,9 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
     }
     else if (active && PAIRS) {
         const unsigned long long key = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + i);
-        if (key != ~0ull) {
+        const float4 uv = (MRT_TL_HITUV && key != ~0ull) ? qload(&thr[i]) : make_float4(0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f);      // (PAIRS: `thr` is the lane's hit-barycentrics array, written by the pass that set the key)
+        if (key != ~0ull && MRT_TL_HITUV && __float_as_uint(uv.z) == (uint32_t)key) H = make_float4(__uint_as_float((uint32_t)(key >> 32)), uv.x, uv.y, uv.z);      // left by the winning hit itself
+        else if (key != ~0ull) {          // (another pair of the same ray wrote its barycentrics last — rare — or the round-4 form: test the winner again)
             const uint32_t g = (uint32_t)key;
             const InstanceDev &I = s.inst[instance_of_gid(s, g)];
             const uint32_t pk = s.tri_packet[I.ts_base + (g - I.gid_base)];
@@ -487,16 +521,29 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
             A.w = __builtin_inff();
         } else { A = qload(&rayA[i]); B = qload(&rayB[i]); C = qload(&thr[i]); }
         pix = __float_as_uint(B.w);
-        uint4 ts; uint32_t inst, geom, vb = 0;
+        uint32_t inst, geom, rec = gid, vb = 0;
         if (s.num_inst) {           // two-level scene: the shading record belongs to the BLAS, the instance is found from the global triangle id
             inst = instance_of_gid(s, gid);
             const InstanceDev &I = s.inst[inst];
-            ts = s.tri_shade[I.ts_base + (gid - I.gid_base)]; vb = I.vbase; geom = ts.w & 0xFFFFu;
-        } else { ts = s.tri_shade[gid]; inst = ts.w >> 16; geom = ts.w & 0xFFFFu; }
+            rec = I.ts_base + (gid - I.gid_base); vb = I.vbase;
+        } else inst = 0;
         float bu = H.y, bv = H.z;
         P = mk3(A) + mk3(B) * H.x;                                       // :261
         float bw = 1.0f - bu - bv;                                       // :63-64
-        f3 n_obj = (bu * mk3(s.normals[vb + ts.y]) + bv * mk3(s.normals[vb + ts.z])) + bw * mk3(s.normals[vb + ts.x]);   // :66-72
+        f3 n_obj;
+        if (s.tri_fat) {            // the record's three normals sit beside its instance / geometry word: one gather (scene option fat_shade)
+            const float4 *__restrict__ fr = s.tri_fat + 3 * (size_t)rec;
+            const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
+            const uint32_t tw = __float_as_uint(f0.w);
+            if (!s.num_inst) inst = tw >> 16;
+            geom = tw & 0xFFFFu;
+            n_obj = (bu * mk3(f1) + bv * mk3(f2)) + bw * mk3(f0);       // :66-72
+        } else {
+            const uint4 ts = s.tri_shade[rec];
+            if (!s.num_inst) inst = ts.w >> 16;
+            geom = ts.w & 0xFFFFu;
+            n_obj = (bu * mk3(s.normals[vb + ts.y]) + bv * mk3(s.normals[vb + ts.z])) + bw * mk3(s.normals[vb + ts.x]);   // :66-72
+        }
         f3 c0 = mk3(s.inst_cols[inst * 4 + 0]), c1 = mk3(s.inst_cols[inst * 4 + 1]), c2 = mk3(s.inst_cols[inst * 4 + 2]);
         f3 n_w = mk3((c0.x * n_obj.x + c1.x * n_obj.y) + c2.x * n_obj.z,
                      (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
@@ -659,7 +706,7 @@ __global__ void __launch_bounds__(64) k_accumulate(FrameParams fp, const float4 
             for (int x = 0; x < 8; x++) reinterpret_cast<uint32_t *>(bounce_counts + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE)[x * XCD_COUNTER_STRIDE] = 0;      // work counters of the persistent trace launch of this bounce (one per XCD region)
             bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
-        totals[0] += closest; totals[1] += shadow; totals[2] += primary;
+        atomicAdd(&totals[0], closest); atomicAdd(&totals[1], shadow); atomicAdd(&totals[2], (unsigned long long)primary);      // (the tile groups of a pass accumulate side by side)
     }
     uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     int x, y;
@@ -704,7 +751,7 @@ __global__ void __launch_bounds__(64) k_accumulate_planes(FrameParams fp, const 
             for (int x = 0; x < 8; x++) reinterpret_cast<uint32_t *>(bounce_counts + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE)[x * XCD_COUNTER_STRIDE] = 0;      // work counters of the persistent trace launch of this bounce (one per XCD region)
             bounce_counts[65 + b] = 0;               // two-level scenes, binned: {pairs queued (lo), work counter of the BLAS pass (hi)}
         }
-        totals[0] += closest; totals[1] += shadow; totals[2] += primary;
+        atomicAdd(&totals[0], closest); atomicAdd(&totals[1], shadow); atomicAdd(&totals[2], (unsigned long long)primary);
     }
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     int x, y;
@@ -842,6 +889,16 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     const uint32_t end = min(n, begin + per_wave);
     StreamStats ss{0, 0, 0, 0, 0, 0};
     uint32_t sink = 0;
+#if defined(MRT_STATS_PROBE) && MRT_STATS_PROBE == 1
+    {   // BFS numbering, children contiguous: level L + 1 starts where level L ends and holds the internal children (imask bits) of level L's nodes
+        uint32_t lo = 0, hi = 1;
+        for (int L = 0; L < 3; L++) {
+            uint32_t kids = 0;
+            for (uint32_t i = lo; i < hi; i++) kids += (uint32_t)__popc(__float_as_uint(s.wnodes[WNODE_STRIDE * (size_t)i].w) >> 24);
+            lo = hi; hi += kids; ss.level_end[L] = hi;
+        }
+    }
+#endif
     traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, end}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
@@ -851,6 +908,9 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
     if ((threadIdx.x & 63) == 0) {
         uint32_t *o = out + 8 * (size_t)blockIdx.x;
         o[0] = ss.iters; o[1] = ss.live_sum; o[2] = ss.node_sum; o[3] = ss.tri_sum; o[4] = ss.refills; o[5] = ss.refill_lanes; o[6] = sink; o[7] = end - begin;
+#ifdef MRT_STATS_PROBE
+        o[4] = ss.probe[0]; o[5] = ss.probe[1]; o[6] = ss.probe[2];
+#endif
     }
 }
 
@@ -1005,6 +1065,7 @@ int Renderer::alloc_queues() {
         FrameParams sp{}; sp.width = width; sp.height = height; sp.shard_rank = shard_rank; sp.shard_world = shard_world; sp.tiles_x = tiles_x; sp.tiles_local = tiles_local; sp.capacity = capacity;
         if (capacity) hipLaunchKernelGGL(k_seed_slots, dim3(cdiv(capacity, 256), B), dim3(256), 0, stream, seeds.p, sp, seed);
     }
+    tgroups_for = 0;            // the tile groups' seed tables follow the shard and the image size: rebuilt at the next draw that uses groups
     // lanes get their buffers when first used (alloc_lane): 16 lanes x 4-frame queues would pin 23 GB at 1080p, 94 GB at 4K
     lanes_ready = 0;
     for (auto &L : lanes) release_lane(L);
@@ -1027,12 +1088,12 @@ size_t Renderer::lane_bytes() const {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
     const size_t planes_bytes = shadow_planes ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const bool need_scon = need_thr || !shadow_planes;
-    const size_t pairs_bytes = (scene && scene->num_inst && scene->num_wnodes && tl_pairs && shadow_planes && !need_thr) ? 2 * qcap * sizeof(uint4) : 0;      // two-level scenes: the (ray, instance) queue of the binned walk
+    const size_t pairs_bytes = (scene && scene->num_inst && scene->num_wnodes && tl_pairs && shadow_planes && !need_thr) ? (2 * PairQueue::WORDS + (MRT_TL_HITUV ? 1 : 0)) * qcap * sizeof(uint4) : 0;      // two-level scenes: the (ray, instance) queue of the binned walk
     return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + planes_bytes + pairs_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); L.f_con[k].release(); }
-    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release(); L.pairs.release();
+    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release(); L.pairs.release(); L.hituv.release();
 }
 int Renderer::alloc_planes(FrameLane &L) {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
@@ -1049,6 +1110,30 @@ int Renderer::alloc_lane(FrameLane &L) {
     MRT_HIP(L.sample.alloc((size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch)));
     MRT_HIP(hipMemsetAsync(L.sample.p, 0, L.sample.bytes(), stream));
     if (shadow_planes && !need_thr) { if (int rc = alloc_planes(L)) return rc; }
+    return MRT_OK;
+}
+
+// The G tile groups of this renderer's shard (renderer.h TileGroup) and their seed tables, built on the main stream (every lane forks from it at the next draw).
+int Renderer::ensure_tile_groups(int G) {
+    const int Bq = std::max(1, alloc_batch);
+    if (tgroups_for == G && tgroups_batch == Bq) return MRT_OK;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8, tiles = tiles_x * tiles_y;
+    for (int g = 0; g < G; g++) {
+        TileGroup &T = tgroups[g];
+        T.rank = g * shard_world + shard_rank; T.world = G * shard_world;
+        T.tiles_local = std::max(0, (tiles - T.rank + T.world - 1) / T.world);
+        T.capacity = (uint32_t)T.tiles_local * 64u;
+        T.owned = 0;
+        for (int lt = 0; lt < T.tiles_local; lt++) {
+            const int tile = lt * T.world + T.rank, ty = tile / tiles_x, tx = tile % tiles_x;
+            T.owned += (uint64_t)std::min(8, width - tx * 8) * (uint64_t)std::min(8, height - ty * 8);
+        }
+        MRT_HIP(seeds_g[g].alloc((size_t)std::max<uint32_t>(T.capacity, 1u) * Bq));
+        FrameParams sp{}; sp.width = width; sp.height = height; sp.shard_rank = T.rank; sp.shard_world = T.world; sp.tiles_x = tiles_x; sp.tiles_local = T.tiles_local; sp.capacity = T.capacity;
+        if (T.capacity) hipLaunchKernelGGL(k_seed_slots, dim3(cdiv(T.capacity, 256), Bq), dim3(256), 0, stream, seeds_g[g].p, sp, seed);
+        T.seeds = seeds_g[g].p;
+    }
+    tgroups_for = G; tgroups_batch = Bq;
     return MRT_OK;
 }
 
@@ -1075,7 +1160,6 @@ int Renderer::render(int n_frames) {                                   // Render
     fp.shard_rank = shard_rank; fp.shard_world = shard_world;
     fp.tiles_x = (width + 7) / 8; fp.tiles_local = tiles_local; fp.max_bounces = max_bounces;
     const uint32_t grid = std::max<uint32_t>(1u, (uint32_t)tiles_local);
-    const uint32_t grid_shade = std::max<uint32_t>(1u, cdiv(capacity, SHADE_THREADS));
     const bool two_level = sv.num_inst > 0;          // instanced scene: TLAS + BLASes walked by the same kernels (<TWO_LEVEL>)
     if (alloc_batch != batch_wanted()) {      // option (or the shard, under frame_batch = 0) changed since the buffers were sized
         MRT_HIP(hipStreamSynchronize(stream));
@@ -1095,6 +1179,21 @@ int Renderer::render(int n_frames) {                                   // Render
     // the first draw sizes the lanes in use.  A lane's queues take ~163 B x pixels x frame_batch (1080p, 8-frame passes: 2.7 GB); when the
     // device cannot hold all the lanes asked for, the renderer runs on the ones it got (>= 1) instead of failing in the middle of a draw
     int F = std::max(1, std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT));
+    // tile groups: a pass as G groups of tiles on G lanes (renderer.h TileGroup); the one-launch-per-frame mode has no passes to split.
+    int G = 1;
+    {
+        const int cap0 = alloc_batch > DEFAULT_FRAME_BATCH ? std::min(alloc_batch, std::max(DEFAULT_FRAME_BATCH, (n_frames + 2) / 3)) : alloc_batch;
+        const int np0 = (n_frames + std::max(1, cap0) - 1) / std::max(1, cap0), in_flight = std::max(1, std::min(F, np0));
+        if (!megakernel && tile_groups != 1 && tiles_local >= 64) {
+            const int lanes_target = std::max(F, 6);
+            // by the draw (0): only passes of ONE frame — the launch-bound regimes: a frame alone 1.53 -> 1.42 ms as two or three groups (four: 1.53), three one-frame passes in flight
+            // 0.85-0.91 -> 0.82-0.83 ms per frame as two groups each; a pass of seven or eight frames is better left whole (the driver's 20 frames as 3 x 2 groups: -4 %; profiles/r05_tile_groups.txt)
+            G = tile_groups >= 2 ? tile_groups : cap0 > 1 ? 1 : in_flight == 1 ? 3 : in_flight <= 3 ? 2 : 1;
+            (void)lanes_target;
+            G = std::max(1, std::min(G, std::min(MAX_FRAMES_IN_FLIGHT / in_flight, tiles_local / 32)));
+        }
+        if (G > 1) F = in_flight * G;          // lanes this draw runs on: G per pass in flight
+    }
     for (; lanes_ready < F; lanes_ready++) {
         const size_t need = lane_bytes();
         size_t free_b = 0, total_b = 0;
@@ -1104,7 +1203,10 @@ int Renderer::render(int n_frames) {                                   // Render
         if (rc == MRT_ERR_OUT_OF_MEMORY) { set_error("not enough device memory for one pass in flight: " + std::to_string(need >> 20) + " MiB of ray queues needed (" + std::to_string(width) + "x" + std::to_string(height) + ", frame_batch " + std::to_string(alloc_batch) + "); lower frame_batch"); return rc; }
         if (rc) return rc;
     }
-    F = std::min(F, lanes_ready); lanes_used = F;
+    if (G > 1 && lanes_ready < F) { G = 1; F = std::max(1, std::min(std::min(frames_in_flight, MAX_FRAMES_IN_FLIGHT), lanes_ready)); }      // not enough memory for the groups' lanes: the plain form
+    F = std::min(F, lanes_ready); lanes_used = F; groups_used = G;
+    if (G > 1) { if (int rc = ensure_tile_groups(G)) return rc; }
+    const int Fp = G > 1 ? F / G : F;          // passes in flight
     ext_used = 0;
     MRT_HIP(hipEventRecord(ev_begin, stream));
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
@@ -1131,18 +1233,28 @@ int Renderer::render(int n_frames) {                                   // Render
     hipEvent_t last_acc = nullptr;
     int pass = 0;
     const int n_passes = (n_frames + batch_max - 1) / batch_max;
-    const int tail_from = tail_accumulate ? n_passes - std::min(F, n_passes) : n_passes;      // passes from here on (each on a lane of its own) are accumulated together after the join
+    const int tail_from = (tail_accumulate && G == 1) ? n_passes - std::min(F, n_passes) : n_passes;      // passes from here on (each on a lane of its own) are accumulated together after the join (tile groups: every group accumulates its own pixels as it ends — nothing to serialise)
+    hipEvent_t last_acc_g[MAX_TILE_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    const TileGroup self_group{shard_rank, shard_world, tiles_local, capacity, owned_pixels, seeds.p};
     AccGroup tail{}; tail.n = 0;
     for (int f = 0; f < n_frames; pass++) {
         // the draw's frames in passes of equal size (20 frames at frame_batch 8: 7 + 7 + 6, not 8 + 8 + 4 — the passes of a short draw run side by side and end together)
         int B = std::min(batch_max, (n_frames - f + (n_passes - pass) - 1) / std::max(1, n_passes - pass));
         f += B;
         fp.batch = B;
-        FrameLane &L = lanes[pass % F];
+        for (int g = 0; g < G; g++) {
+        const TileGroup &TG = G > 1 ? tgroups[g] : self_group;
+        if (G > 1 && TG.capacity == 0) continue;
+        FrameLane &L = lanes[G > 1 ? (pass % Fp) * G + g : pass % F];
         hipStream_t st = L.stream;
         unsigned long long *bc = L.bounce_counts.p;                     // [bounce] {next rays (lo), shadow rays (hi)}, zero at frame start
         fp.frameIndex = frame_index;                                    // updateUniforms :216-229 (first frame of the batch)
         fp.sampleIndex = frame_index + sample_offset;
+        // this group's tiles (G = 1: the renderer's own shard)
+        fp.shard_rank = TG.rank; fp.shard_world = TG.world; fp.tiles_local = TG.tiles_local; fp.capacity = TG.capacity;
+        const uint32_t capacity = TG.capacity, grid = std::max<uint32_t>(1u, (uint32_t)TG.tiles_local), grid_shade = std::max<uint32_t>(1u, cdiv(TG.capacity, SHADE_THREADS));
+        const uint64_t owned_pixels = TG.owned;
+        const uint32_t *const seeds_p = TG.seeds;
         bool used_planes = false;
         if (mega) {
             // one launch per frame on the pass's stream; frames are sequential (a path's last act is the running average with the previous target)
@@ -1161,7 +1273,7 @@ int Renderer::render(int n_frames) {                                   // Render
                 EvPair *ev = nullptr;
                 if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_TRACE; ev = &ev_ext[ext_used++]; }
                 const uint32_t waves = (uint32_t)std::min<size_t>(std::max<size_t>(1, cdiv(capacity, 64)), (size_t)mega_slots);
-                launch_timed(ev, k_megakernel, dim3(waves), dim3(64), stack_bytes, st, sv, fp, seeds.p, accum[cur].p, accum[1 - cur].p, work, totals.p, (uint32_t)owned_pixels);
+                launch_timed(ev, k_megakernel, dim3(waves), dim3(64), stack_bytes, st, sv, fp, seeds_p, accum[cur].p, accum[1 - cur].p, work, totals.p, (uint32_t)owned_pixels);
                 cur = 1 - cur;
             }
             MRT_HIP(hipEventRecord(L.accumulated, st));
@@ -1191,7 +1303,7 @@ int Renderer::render(int n_frames) {                                   // Render
             fp.bounce = 0;
             fp.chain = (throughput_chain && !materials && max_bounces <= 3 && (uint64_t)scene->stats.instances * (uint64_t)std::max(1, scene->stats.max_submeshes) <= 65536ull) ? 1 : 0;
             if (!fp.chain && !L.thr[0].p) {           // this draw needs the throughput queues after all (materials, more than three bounces, a very large resource table)
-                const size_t qcap = (size_t)capacity * (size_t)std::max(1, alloc_batch);
+                const size_t qcap = (size_t)this->capacity * (size_t)std::max(1, alloc_batch);          // (a lane's buffers are sized for the renderer's whole shard, whatever tile group uses it now)
                 for (int k = 0; k < 2; k++) MRT_HIP(L.thr[k].alloc(qcap));
             }
             const uint32_t rpw_p = stream_rays_per_wave((size_t)capacity * B), rpw_m = stream_rays_per_wave(2 * (size_t)capacity * B);
@@ -1205,8 +1317,9 @@ int Renderer::render(int n_frames) {                                   // Render
             used_planes = planes_pass;
             // two-level scenes: the binned walk (TLAS pass + BLAS pass over (ray, instance) pairs) for the bounce / shadow rays of planes passes
             const bool pairs_pass = two_level && planes_pass && tl_pairs != 0 && sv.tri_packet != nullptr;
-            const size_t pair_cap = 2 * (size_t)capacity * (size_t)std::max(1, alloc_batch);          // one pair per virtual ray of the combined queue; a push beyond it walks its instance in place
-            if (pairs_pass && !L.pairs.p) MRT_HIP(L.pairs.alloc(std::max<size_t>(pair_cap, 1)));
+            const size_t pair_cap = 2 * (size_t)this->capacity * (size_t)std::max(1, alloc_batch);          // one pair per virtual ray of the combined queue; a push beyond it walks its instance in place
+            if (pairs_pass && !L.pairs.p) MRT_HIP(L.pairs.alloc(std::max<size_t>(PairQueue::WORDS * pair_cap, 1)));
+            if (pairs_pass && MRT_TL_HITUV && !L.hituv.p) MRT_HIP(L.hituv.alloc(std::max<size_t>((size_t)this->capacity * (size_t)std::max(1, alloc_batch), 1)));      // a hit's barycentrics beside its key
             const uint32_t pair_cap_used = (uint32_t)std::min<size_t>(tl_pair_cap > 0 ? std::min<size_t>((size_t)tl_pair_cap, pair_cap) : pair_cap, 0xFFFFFFFFu);
             // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
@@ -1220,21 +1333,21 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
             const bool trace0_hint = primary_hint && (!two_level || (sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24)));      // two-level: the hint is (packet | instance << 24)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
-            if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)capacity * (size_t)std::max(1, alloc_batch)));
+            if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)this->capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
             else if (two_level && on_wide) {
                 // the hint of two-level scenes is (packet | instance << 24): scenes of at most 255 instances and 2^24 packets
                 const bool seeded = primary_hint && sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24);
-                if (seeded) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
-                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
+                if (seeded) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds_p, L.hits.p, dirs, capacity, rpw_p, hint.p);
+                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<true, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds_p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
             else if (primary_wide == 1 && sv.num_wnodes && !two_level) {
-                if (primary_hint) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, hint.p);
-                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds.p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
+                if (primary_hint) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, true>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds_p, L.hits.p, dirs, capacity, rpw_p, hint.p);
+                else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary_wide_stream<false, false>, dim3(cdiv(capacity, rpw_p), B), dim3(64), stack_bytes, st, sv, fp, seeds_p, L.hits.p, dirs, capacity, rpw_p, (uint32_t *)nullptr);
             }
-            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, (uint32_t *)nullptr);
-            else if (!prim_rope) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false, true>, dim3(grid, B), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
-            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds.p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
+            else if (two_level) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<true>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds_p, L.hits.p, dirs, (uint32_t *)nullptr);
+            else if (!prim_rope) launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false, true>, dim3(grid, B), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, fp, seeds_p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
+            else launch_timed(timed(MRT_KERNEL_PRIMARY), k_trace_primary<false>, dim3(grid, B), dim3(64), 0, st, sv, fp, seeds_p, L.hits.p, dirs, primary_hint ? hint.p : (uint32_t *)nullptr);
             int q = 0;                                                  // shade(b) writes next rays into queue q
             for (int b = 0; b < max_bounces; b++) {
                 fp.bounce = b;
@@ -1251,14 +1364,14 @@ int Renderer::render(int n_frames) {                                   // Render
                                               : fp.chain ? k_shade<false, true> : k_shade<false, false>;
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
-                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES : 0, st, sv, fp, seeds.p, L.rayA[1 - q].p, L.rayB[1 - q].p, L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && trace0_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 // [r3] smaller launches pull as well when five or more passes are in flight (6 lanes x one-frame passes: 9.33 against 8.76 Grays/s; a rank of eight over 240 frames
                 // in 8-frame passes: 9.43 against 8.56); with one to three passes in flight they do better on the even static split (one frame alone 1.51 against 1.76 ms, 3 x 1 frame
                 // 7.63 against 7.20 Grays/s, a rank of eight over the driver's 20 frames 6.65 against 5.73): stream_even below
-                const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || (std::min(F, n_passes) >= 5 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 256)));      // (below 256 slots per wave slot — Cornell 256^2 in 8-frame passes — the even split: 6.46 against 5.40 Grays/s)
+                const bool pull = persistent == 1 || (persistent == 2 && (2 * (size_t)capacity * B >= (size_t)wave_slots * 1024 || (std::min(F, G > 1 ? Fp * G : n_passes) >= 5 && 2 * (size_t)capacity * B >= (size_t)wave_slots * 256)));      // (below 256 slots per wave slot — Cornell 256^2 in 8-frame passes — the even split: 6.46 against 5.40 Grays/s)
                 if (ablate & 2) {}
                 else if (pairs_pass) {
                     const size_t slots = 2 * (size_t)capacity * B;
@@ -1270,13 +1383,13 @@ int Renderer::render(int n_frames) {                                   // Render
                     // few instances: the TLAS pass without a tree (every lane visits every instance: nothing diverges); many: the stream walk of the 8-wide TLAS
                     if (sv.num_inst <= TL_FLAT_MAX_INSTANCES && tl_pairs != 2)
                         launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top_flat, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, 64), 2 * grid_slots))), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                     (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
+                                     (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4), L.hituv.p);
                     else
                     launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top, dim3(waves), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                 (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
+                                 (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4), L.hituv.p);
                     // the pairs' count is on the device: the launch has the wave slots it may use and the surplus leaves at once
                     launch_timed(timed(MRT_KERNEL_TRACE), k_tl_blas, dim3((uint32_t)grid_slots), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used);
+                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used, L.hituv.p);
                 }
                 else if (on_wide && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
@@ -1294,7 +1407,32 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
                     const uint32_t chunk_arg = chunk;
 #endif
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
+                    if (!two_level && planes_pass && (hit_lds || lds_top)) {
+                        // the variant with LDS extras: its own workgroup shape, LDS size and wave slots
+                        const int WV = lds_top >= 2 ? 4 : 1;
+                        const bool TOPX = lds_top >= 1 && lds_top <= 3;
+                        const uint32_t top_n = !TOPX ? 0u : lds_top == 2 ? scene->wide_level_end[2] : scene->wide_level_end[1];
+                        const uint32_t stack_words = (uint32_t)(stack_bytes / 4);
+                        const size_t lds_x = (size_t)top_n * WNODE_STRIDE * 16 + (size_t)WV * ((hit_lds ? 1024 : 0) + stack_bytes);
+                        using KX = void (*)(SceneView, const float4 *, const float4 *, float4 *, const float4 *, const float4 *, const unsigned long long *, uint32_t *, uint32_t, uint8_t *, uint32_t, uint32_t, uint32_t);
+                        const KX kx = WV == 4 ? (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, true, true> : (KX)k_trace_mixed_wide_persist_x<4, true, false>) : (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, false, true> : (KX)k_trace_mixed_wide_persist_x<4, false, false>))
+                                              : (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<1, true, true> : (KX)k_trace_mixed_wide_persist_x<1, true, false>) : (KX)k_trace_mixed_wide_persist_x<1, false, true>);
+                        const int key = (int)(lds_x & 0xFFFFFF) * 64 + hit_lds * 8 + lds_top;
+                        if (slots_x_key != key) {
+                            int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+                            MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
+                            MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kx, 64 * WV, lds_x));
+                            if (per_cu < 1) { set_error("lds_top / hit_lds: the traversal kernel does not fit a compute unit with " + std::to_string(lds_x) + " bytes of LDS"); return MRT_ERR_UNSUPPORTED; }
+                            wave_slots_x = per_cu * WV * prop.multiProcessorCount; slots_x_key = key;
+                        }
+                        const size_t ws = wave_slots_user ? (size_t)wave_slots : (size_t)wave_slots_x;
+                        const uint32_t chunk_x = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / (ws * 4) / 64 * 64));
+                        const size_t grid_slots_x = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? std::max<size_t>(1, ws / 2) : ws;
+                        const uint32_t waves_x = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk_x), grid_slots_x));
+                        launch_timed(timed(MRT_KERNEL_TRACE), kx, dim3((waves_x + WV - 1) / WV), dim3(64 * WV), lds_x, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p,
+                                     (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_x, lit_b, xcd_counters ? (uint32_t)B : 0u, top_n, stack_words);
+                    }
+                    else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
                                  (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<false>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
                                  (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
@@ -1320,7 +1458,8 @@ int Renderer::render(int n_frames) {                                   // Render
             frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
             continue;
         }
-        if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
+        if (G > 1) { if (last_acc_g[g] && last_acc_g[g] != L.accumulated) MRT_HIP(hipStreamWaitEvent(st, last_acc_g[g], 0)); }      // this group's pixels of the previous target: written by the same group of the pass before
+        else if (last_acc) MRT_HIP(hipStreamWaitEvent(st, last_acc, 0));
         {
             EvPair *ev = nullptr;
             if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }
@@ -1329,13 +1468,17 @@ int Renderer::render(int n_frames) {                                   // Render
             else launch_timed(ev, k_accumulate, dim3(grid), dim3(64), 0, st, fp, L.sample.p, accum[cur].p, accum[1 - cur].p, bc, totals.p, (uint32_t)(owned_pixels * (uint64_t)B));
         }
         MRT_HIP(hipEventRecord(L.accumulated, st));
+        if (G > 1) { last_acc_g[g] = L.accumulated; continue; }
         last_acc = L.accumulated;
         cur = 1 - cur;                                                  // ping-pong swap :332-334 (once per batch: the batch's frames are applied in one kernel)
         frame_index += (uint32_t)B; frames_rendered += (uint64_t)B;
         if (int rc = note_pass(st)) return rc;
+        }       // tile groups of the pass
+        if (G > 1) { cur = 1 - cur; frame_index += (uint32_t)B; frames_rendered += (uint64_t)B; }      // every group read accum[cur] and wrote accum[1 - cur] at its own pixels
     }
     // join: the main stream continues after every lane has drained
-    for (int k = 0; k < std::min(F, pass); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
+    for (int k = 0; k < (G > 1 ? std::min(Fp, pass) * G : std::min(F, pass)); k++) MRT_HIP(hipStreamWaitEvent(stream, lanes[k].accumulated, 0));
+    if (G > 1) { if (int rc = note_pass(stream)) return rc; }      // (tile groups: completion is reported per draw)
     if (tail.n > 0) {
         EvPair *ev = nullptr;
         if (ext_used < (int)ev_ext.size()) { ev_ext[ext_used].kind = MRT_KERNEL_ACCUMULATE; ev = &ev_ext[ext_used++]; }

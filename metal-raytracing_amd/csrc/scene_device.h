@@ -96,6 +96,8 @@ struct SceneView {           // passed by value to kernels
     const float4 *packets;       // 3 x float4 per triangle, leaf order
     const uint4 *tri_shade;      // per gid
     const float4 *normals;       // object space, concatenated over meshes (float3 stride 16, Mesh.swift:27-29)
+    const float4 *tri_fat;       // per shading record 3 x float4 {n0.xyz | tri_shade.w}, {n1.xyz | -}, {n2.xyz | -}: the record's three vertex normals beside its instance / geometry word, so that
+                                 // shading follows ONE gather from the hit instead of tri_shade -> three normals (scene option fat_shade; nullptr = not built)
     const float4 *base_color;    // per resource slot = instance*max_sub + geometry (Renderer.swift:139)
     const float4 *materials;     // per resource slot, 3 x float4: baseColor | dissolve, specular | specularExponent, emission | refractionIndex (materials extension)
     const float4 *inst_cols;     // 3 x float4 per instance: columns 0..2 of the 4x3 transform
@@ -201,8 +203,10 @@ struct BuildOptions {
     int wide = 1;             // build the 8-wide compressed layout: every ray of the pipeline walks it
     int rope = 0;             // 1: also emit the rope layout (binary nodes with escape links + its own copy of the packets); 0: only when the scene cannot have the 8-wide layout
     int wide_collapse = 1;    // 8-wide layout: 0 = greedy collapse of the binary tree (largest child first), 1 = SAH-optimal collapse by dynamic programming (k_wide_dp)
-    float wide_cost_node = 1.0f, wide_cost_tri = 0.3f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test
+    float wide_cost_node = 1.0f, wide_cost_tri = 0.5f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test — ~250 against ~125 VALU instructions in the stream loop; 0.3 until round 5
+                                                            // (0.45 ... 1.0 measured +1 ... +2 % on DragonScene, 0.5 against 0.3: garden 4K +1 %, dragon x 4 +3 ... +4 %, hostile +1.5 %, Cornell 256^2 +8 ... +13 %; profiles/r05_wide_cost_tri.txt)
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
+    int fat_shade = 0;        // 1: also keep, per triangle, its three vertex normals beside its instance / geometry word (48 B; SceneView::tri_fat): k_shade then needs one dependent gather per hit instead of two.  Measured (profiles/r05_lds_top_ab.txt): the shade launches alone 0.772 against 0.777 ms, the frame within noise — off by default (it would add 42 MB to DragonScene's 70)
     int refit_fenced = 0;     // 1: the bottom-up pass of the build with __threadfence() hand-offs instead of write-through stores (the slow reference form; same tree bit for bit)
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
@@ -212,10 +216,12 @@ struct BuildOptions {
 struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
+    uint32_t wide_level_end[4] = {0, 0, 0, 0};   // flattened scenes: nodes of the 8-wide tree in levels 0..k (BFS numbering: wnodes[0 .. wide_level_end[k]) ARE those levels) — what the traversal stages in LDS (renderer option lds_top)
     uint32_t num_packets = 0;        // triangle packets per layout = build references (stats.triangles, or more when long triangles were pre-split)
     uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;
+    DevBuf<float4> tri_fat;          // 3 x float4 per shading record (SceneView::tri_fat); empty when scene option fat_shade = 0
     DevBuf<uint32_t> geom_base;
     DevBuf<LightDev> lights;
     int light_count = 0;
@@ -239,6 +245,7 @@ struct DeviceScene {
 void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
+int build_fat_shade(DeviceScene &out, const BuildOptions &opt, hipStream_t stream);      // tri_fat from tri_shade + normals (flattened scenes and single BLASes: vertex ids are absolute in `normals`)
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
 void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);

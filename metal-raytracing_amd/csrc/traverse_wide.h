@@ -434,6 +434,10 @@ constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 struct StreamStats {
     uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes;
+#ifdef MRT_STATS_PROBE      // diagnostics builds (tools/build_variant.sh; tools/r05/): = 1 node fetches by tree level, = 2 pending triangles per iteration (what pooling triangle tests across lanes could use)
+    uint32_t level_end[3] = {0, 0, 0};      // = 1: first node index beyond levels 0..1, 0..2, 0..3 (BFS numbering); the three counters below: fetches of nodes before each
+    uint32_t probe[3] = {0, 0, 0};          // = 2: pending triangles summed over lanes and iterations | lanes with two or more pending | iterations in which fewer than 16 lanes test a triangle
+#endif
 #ifdef MRT_WAVE_TIMES
     uint32_t drain_iters = 0, drain_live = 0, maxdt = 0; unsigned long long prev = 0ull, drain_t0 = 0ull;
 #endif
@@ -500,15 +504,23 @@ struct XcdRegions {
 // Two-level scenes, binned form (renderer option tl_pairs).  The TLAS pass — this loop with a PairQueue — tests instances of at most eight triangles in place and,
 // instead of entering a larger one, appends {ray, instance} to a queue; a second launch walks every pair in object space with the FLATTENED loop (TWO_LEVEL = false, per-ray root:
 // ROOTS), its lanes never changing level, and folds the hits into the rays' results with atomics.  When the queue is full a lane enters the instance in place, as without a queue.
+#ifndef MRT_TL_FAT
+#define MRT_TL_FAT 0      // two-level scenes, binned walk, A/B (tools/build_variant.sh): 1 = a pair carries its ray in the instance's OBJECT space (48 B, written and read coalesced) instead of {ray, instance} (16 B + two scattered ray
+                          // records, the instance row and the transform again in the BLAS pass).  Measured on dragon x 4: 8.0-8.2 against 8.3-8.4 Grays/s — the TLAS pass's 32 more bytes per pair cost more than the BLAS pass's gathers (profiles/r05_two_level_ab.txt)
+#endif
+#ifndef MRT_TL_HITUV
+#define MRT_TL_HITUV 1    // a hit found by the TLAS or the BLAS pass leaves {u, v, global triangle id, t} beside its ray's key; k_shade<.., PAIRS> takes the barycentrics when the id matches the key's instead of testing the winning triangle again
+#endif
 struct NoPairs { static constexpr bool on = false; };
 struct PairQueue {
     static constexpr bool on = true;
+    static constexpr uint32_t WORDS = MRT_TL_FAT ? 3u : 1u;      // float4 per pair: {object-space origin | bound} {object-space direction | report tag} {ray, instance, BLAS root, -} — or {ray, instance, bound, report tag}
     static constexpr uint32_t BLOCK = 256;            // pair slots a wave reserves at a time: ONE atomic on the queue's counter per 256 pairs (a counter word sustains ~88 returning
                                                       // atomics per microsecond; one per wave and iteration — the first form — made the TLAS pass five times slower than the walk it replaces)
     uint4 *__restrict__ pairs; uint32_t *__restrict__ count; uint32_t cap;
     uint32_t *cursor;                                 // LDS, two words of this wave: {next free slot, end of the wave's block}; both 0 at the start
     // called by the lanes that reached a large instance in this iteration (a divergent branch: the ballot sees exactly them); true = the pair is stored
-    MRT_DEV bool push(uint32_t ray_index, uint32_t inst, float tmax, uint32_t tagw) const {
+    MRT_DEV bool push(uint32_t ray_index, uint32_t inst, float tmax, uint32_t tagw, const f3 oo = mk3(0, 0, 0), const f3 dd = mk3(0, 0, 1), uint32_t root = 0) const {
         const unsigned long long m = __ballot(1);
         const int leader = __ffsll((long long)m) - 1;
         const uint32_t lane = threadIdx.x & 63, n = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -527,17 +539,45 @@ struct PairQueue {
         if (rank < fits) slot = cur + rank;
         else if (fresh != 0xFFFFFFFFu) slot = fresh + (rank - fits);
         else return false;
+#if MRT_TL_FAT
+        float4 *const rec = reinterpret_cast<float4 *>(pairs) + 3 * (size_t)slot;      // (written once, read once by the next launch)
+        qstore(rec, make_float4(oo.x, oo.y, oo.z, tmax)); qstore(rec + 1, make_float4(dd.x, dd.y, dd.z, __uint_as_float(tagw))); qstore(rec + 2, make_float4(__uint_as_float(ray_index), __uint_as_float(inst), __uint_as_float(root), 0.0f));
+#else
         qstore(reinterpret_cast<float4 *>(&pairs[slot]), make_float4(__uint_as_float(ray_index), __uint_as_float(inst), tmax, __uint_as_float(tagw)));      // (written once, read once by the next launch)
+#endif
         return true;
     }
     // the whole wave, when it has no rays left: the unused rest of its block becomes pairs that name no ray (the BLAS pass skips them)
     MRT_DEV void close() const {
         const uint32_t lane = threadIdx.x & 63, cur = cursor[0], end = cursor[1];
-        for (uint32_t k = cur + lane; k < end; k += 64) qstore(reinterpret_cast<float4 *>(&pairs[k]), make_float4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f));
+        for (uint32_t k = cur + lane; k < end; k += 64) qstore(reinterpret_cast<float4 *>(pairs) + (size_t)WORDS * k + (WORDS - 1u), make_float4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f));
         cursor[0] = end;
     }
 };
 
+// Optional LDS extras of the stream walk (flattened scenes; renderer options hit_lds / lds_top):
+//   hit_lds   the lane's closest hit so far keeps its U, V, |det| and triangle id in four words of LDS, written when a closer hit is found, so that a finished ray is
+//             reported from LDS instead of fetching the winning packet again and re-running its triangle test at refill time (a dependent round trip and ~100 VALU
+//             instructions at a quarter of the lanes, three to four times per 64 rays);
+//   top_lds   the first top_n nodes of wnodes — BFS numbering: the top levels of the tree — are read from a copy in LDS (the workgroup's, loaded at kernel start)
+//             instead of through the vector memory path.  BASELINE.json's "LDS-staged BVH nodelets".
+// a float4 read from an address KNOWN to be in LDS, through an LDS pointer by type (ds_read_b128): with a generic pointer the compiler merges an "LDS or global" choice into one flat load
+MRT_DEV float4 lds_f4(const float4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const float4 lds_t;
+    const lds_t *q = (const lds_t *)p;
+    return make_float4(q->x, q->y, q->z, q->w);
+#else
+    return *p;
+#endif
+}
+struct NoExt { static constexpr bool hit_lds = false, top_lds = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; };      // (members never read: every use sits behind one of the two flags)
+template <bool HIT, bool TOP> struct StreamExt {
+    static constexpr bool hit_lds = HIT, top_lds = TOP;
+    float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far
+    const float4 *top;      // TOP: wnodes[0 .. top_n) in LDS
+    uint32_t top_n;
+};
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -548,8 +588,9 @@ struct PairQueue {
 // SEED (primary rays with a hint, k_trace_primary_wide_stream): `fetch` also returns a candidate hit — a packet (| instance << 24) whose distance it has already put
 // into the ray's limit word — and the walk starts with it as its closest hit so far; TravHit::pk at emit time is the final hit in the same encoding.
 // ROOTS (with TWO_LEVEL = false): `fetch` also returns the node the ray's walk starts at (the root of its instance's BLAS in the shared node array) instead of node 0.
-template <bool TWO_LEVEL = false, bool SEED = false, bool ROOTS = false, class Pairs = NoPairs, class Chunks, class RayFetch, class Emit>
-MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr, Pairs pq = Pairs{}) {
+template <bool TWO_LEVEL = false, bool SEED = false, bool ROOTS = false, class Pairs = NoPairs, class Ext = NoExt, class Chunks, class RayFetch, class Emit>
+MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_t *stack, RayFetch fetch, Emit emit, StreamStats *ss = nullptr, Pairs pq = Pairs{}, Ext ext = Ext{}) {
+    static_assert(!Ext::hit_lds || (!TWO_LEVEL && !SEED), "hit_lds: flattened scenes, rays without a seed hit");
     const uint32_t lane = threadIdx.x & 63;
     float *const wray = reinterpret_cast<float *>(stack);      // [6][64]: o.xyz, d.xyz of the lane's ray in world space (TWO_LEVEL)
     if (TWO_LEVEL) stack += WIDE_WORLD_RAY_BYTES / 4u;
@@ -588,7 +629,10 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             if (unreported) {
                 const bool was_any = (tagw >> 31) != 0, was_hit = best_pk != 0xFFFFFFFFu;
                 TravHit h; h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
-                if (!was_any && was_hit) {      // id and barycentrics of the winning triangle: recomputed here (same arithmetic) instead of living in 4 registers
+                if constexpr (Ext::hit_lds) {
+                    if (!was_any && was_hit) { h.U = ext.hit[lane]; h.V = ext.hit[64u + lane]; h.ad = ext.hit[128u + lane]; h.gid = __float_as_uint(ext.hit[192u + lane]); }      // kept since the hit was found
+                }
+                else if (!was_any && was_hit) {      // id and barycentrics of the winning triangle: recomputed here (same arithmetic) instead of living in 4 registers
                     const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
                     const float4 q0 = pk[0];
                     float t_;
@@ -712,7 +756,15 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     MRT_BOUND(tl_slot, s.num_wtlas, 3);
                     uint32_t id = s.wtlas_index[tl_slot];
                     MRT_BOUND(id, s.num_inst, 4);
-                    if (s.inst[id].ntri > 8u && !pq_refused) { if (!pq.push(qi, id, best_t, tagw)) { pq_refused = true; keep |= 1u << k; } }      // refused (the queue is full): this lane walks its large instances in place from here on
+                    if (s.inst[id].ntri > 8u && !pq_refused) {
+#if MRT_TL_FAT
+                        const InstanceDev &I_ = s.inst[id];
+                        const bool pushed = pq.push(qi, id, best_t, tagw, to_object_point(I_, o), to_object_dir(I_, d), I_.wroot);
+#else
+                        const bool pushed = pq.push(qi, id, best_t, tagw);
+#endif
+                        if (!pushed) { pq_refused = true; keep |= 1u << k; }      // refused (the queue is full): this lane walks its large instances in place from here on
+                    }
                     else keep |= 1u << k;
                 }
                 t_mask = keep;
@@ -767,6 +819,16 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
         if (ss) { ss->tri_sum += (uint32_t)__popcll(__ballot(has_tri)); ss->node_sum += (uint32_t)__popcll(__ballot(want_node)); }
+#if defined(MRT_STATS_PROBE) && MRT_STATS_PROBE == 1
+        if (ss) for (int k = 0; k < 3; k++) ss->probe[k] += (uint32_t)__popcll(__ballot(want_node && pending < ss->level_end[k]));
+#elif defined(MRT_STATS_PROBE) && MRT_STATS_PROBE == 2
+        if (ss) {
+            const uint32_t pend = live ? (uint32_t)__popc(t_mask) + (SPEC ? (uint32_t)__popc(u_mask) : 0u) : 0u;
+            uint32_t tot = pend;
+            for (int o_ = 32; o_ > 0; o_ >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o_);
+            ss->probe[0] += tot; ss->probe[1] += (uint32_t)__popcll(__ballot(pend >= 2u)); ss->probe[2] += __popcll(__ballot(has_tri)) < 16 ? 1u : 0u;
+        }
+#endif
 #ifdef MRT_STATS_BOTH      // diagnostics build (tools/two_level_probe.py): in place of the refill counters, lane-iterations that do a triangle AND a node / that enter an instance
         if (ss) { ss->refills += (uint32_t)__popcll(__ballot(has_tri && want_node)); ss->refill_lanes += (uint32_t)__popcll(__ballot(TWO_LEVEL && has_inst)); }
 #endif
@@ -785,8 +847,13 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
         if (want_node) {
             MRT_BOUND(pending, s.num_wnodes, 1);
-            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
+            if (Ext::top_lds && pending < ext.top_n) {          // a node of the top levels: from the workgroup's copy in LDS
+                const float4 *nd = ext.top + WNODE_STRIDE * pending;
+                n0 = lds_f4(nd); n1 = lds_f4(nd + 1); n2 = lds_f4(nd + 2); n3 = lds_f4(nd + 3); n4 = lds_f4(nd + WNODE_N4);
+            } else {
+                const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
+                n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
+            }
         }
         auto consider = [&](const float4 q0, const float4 q1, const float4 q2, const uint32_t pk_index) {
             float t, U, V, ad;
@@ -796,24 +863,32 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     bool better = t < best_t || best_pk == 0xFFFFFFFFu;
                     if (!better) {                                      // t == best_t: ties go to the lowest (global) id (rare)
                         if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + __float_as_uint(q0.w) < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
+                        else if (Ext::hit_lds) better = __float_as_uint(q0.w) < __float_as_uint(ext.hit[192u + lane]);
                         else better = __float_as_uint(q0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
                     }
-                    if (better) { best_t = t; best_pk = pk_index; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
+                    if (better) {
+                        best_t = t; best_pk = pk_index; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16);
+                        if (Ext::hit_lds) { ext.hit[lane] = U; ext.hit[64u + lane] = V; ext.hit[128u + lane] = ad; ext.hit[192u + lane] = q0.w; }
+                    }
                 }
             }
         };
         if (has_tri) consider(r0, r1, r2, tri_pk);
         if (owner >= 0) {                                        // wave-uniform
             float h_t = 0.0f; bool h_hit = false;
-            if (helping) { float U_, V_, ad_; h_hit = tri_test(r0, r1, r2, o, d, 0.0f, best_t, h_t, U_, V_, ad_); }
+            float U_ = 0.0f, V_ = 0.0f, ad_ = 1.0f;
+            if (helping) h_hit = tri_test(r0, r1, r2, o, d, 0.0f, best_t, h_t, U_, V_, ad_);
             // the closest of the helpers' hits (ties: lowest id — all of them are triangles of the owner's current BLAS, so local ids compare)
-            float bt = __builtin_inff(); uint32_t bpk = 0xFFFFFFFFu, bgid = 0xFFFFFFFFu;
+            float bt = __builtin_inff(); uint32_t bpk = 0xFFFFFFFFu, bgid = 0xFFFFFFFFu; int bl = 0;
             for (unsigned long long m = __ballot(h_hit); m != 0ull; m &= m - 1ull) {
                 const int l = __ffsll((long long)m) - 1;
                 const float t_ = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(h_t), l));
                 const uint32_t g_ = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r0.w), l), p_ = (uint32_t)__builtin_amdgcn_readlane((int)tri_pk, l);
-                if (t_ < bt || (t_ == bt && g_ < bgid)) { bt = t_; bgid = g_; bpk = p_; }
+                if (t_ < bt || (t_ == bt && g_ < bgid)) { bt = t_; bgid = g_; bpk = p_; bl = l; }
             }
+            // hit_lds: the winning helper's U, V, |det| travel to the owner with its distance
+            const float wU = Ext::hit_lds ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(U_), bl)) : 0.0f, wV = Ext::hit_lds ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(V_), bl)) : 0.0f,
+                        wA = Ext::hit_lds ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ad_), bl)) : 1.0f;
             // (the owner may have run out of nodes in this very iteration — it then waits for its report with these hits folded in)
             if ((int)lane == owner && bpk != 0xFFFFFFFFu) {
                 if ((tagw >> 31) != 0) { best_pk = bpk; live = false; unreported = true; }
@@ -821,9 +896,13 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     bool better = bt < best_t || best_pk == 0xFFFFFFFFu;
                     if (!better && bt == best_t) {
                         if (TWO_LEVEL) better = s.inst[insts & 0xFFFFu].gid_base + bgid < s.inst[insts >> 16].gid_base + __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
+                        else if (Ext::hit_lds) better = bgid < __float_as_uint(ext.hit[192u + lane]);
                         else better = bgid < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);
                     }
-                    if (better) { best_t = bt; best_pk = bpk; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16); }
+                    if (better) {
+                        best_t = bt; best_pk = bpk; if (TWO_LEVEL) insts = (insts & 0xFFFFu) | (insts << 16);
+                        if (Ext::hit_lds) { ext.hit[lane] = wU; ext.hit[64u + lane] = wV; ext.hit[128u + lane] = wA; ext.hit[192u + lane] = __uint_as_float(bgid); }
+                    }
                 }
             }
         }

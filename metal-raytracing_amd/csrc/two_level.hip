@@ -475,7 +475,9 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.bpackets_offset = 4 * nodes_total;
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(ts_total, 1)));
     MRT_HIP(out.normals.alloc(std::max<size_t>(V_total, 1)));
+    if (opt.fat_shade && ts_total) MRT_HIP(out.tri_fat.alloc(3 * ts_total)); else out.tri_fat.release();      // a BLAS's fat shading records (its own vertex ids resolved by build_flat), concatenated like tri_shade
     for (size_t b = 0; b < B; b++) {
+        if (out.tri_fat.n > 1 && blas[b].stats.triangles) MRT_HIP(hipMemcpyAsync(out.tri_fat.p + 3 * (size_t)ts_base[b], blas[b].tri_fat.p, (size_t)blas[b].stats.triangles * 48, hipMemcpyDeviceToDevice, stream));
         const size_t nn = blas[b].rope_nodes, nt = blas[b].stats.triangles, nv = meshes[blas_src[b]].positions.size() / 3;
         if (nn) MRT_HIP(hipMemcpyAsync(out.bnodes.p + 4 * (size_t)node_base[b], blas[b].nodes.p, nn * 64, hipMemcpyDeviceToDevice, stream));
         if (nt) MRT_HIP(hipMemcpyAsync(out.bnodes.p + out.bpackets_offset + 3 * (size_t)packet_base[b], blas[b].nodes.p + blas[b].packets_offset, nt * 48, hipMemcpyDeviceToDevice, stream));
@@ -537,7 +539,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
-    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
+    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (out.tri_fat.n > 1 ? (uint64_t)ts_total * 48 : 0) + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
     out.validated_blas = false;            // the BLAS part of wnodes is new: update_tlas checks all of it this time
     return update_tlas(meshes, stream, out);
 }

@@ -347,6 +347,13 @@ class GroupRenderer:
     def wait(self):
         check(lib.mrt_group_wait(self.handle))
 
+    def rank_stats(self, rank):
+        """One device's own counters and the device time of its last draw (mrt_renderer_stats of that rank's renderer): what a scaling record is diagnosed with."""
+        r = C.c_void_p(); s = RenderStats()
+        check(lib.mrt_group_renderer_rank(self.handle, int(rank), C.byref(r)))
+        check(lib.mrt_renderer_stats(r, C.byref(s)))
+        return s
+
     @property
     def framesCompleted(self):
         v = C.c_uint64()

@@ -133,6 +133,8 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_one_rank_image(tmp_path):
     assert p2.returncode == 0, p2.stderr[-3000:]
     d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0
+    pr = d["per_rank"]           # every rank's device time and its time in the reduce: what the first real SCALE record will be diagnosed with
+    assert len(pr["ms_gpu_timed_draw"]) == 2 and min(pr["ms_gpu_timed_draw"]) > 0 and len(pr["gather_wall_ms"]) == 2 and max(pr["render_wall_ms"]) * 1e-3 <= d["ms_per_step"] * d["steps"] * 1e-3 + 1e-3
     d1 = json.loads([l for l in p1.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d1["config"]["rays_per_frame"] == d["config"]["rays_per_frame"]          # ray-count conservation across the shards
     a, b = np.load(one), np.load(two)
@@ -154,6 +156,7 @@ def test_bench_group_path_assembles_the_one_rank_image(tmp_path):
     d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
     d1 = json.loads([l for l in p1.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0 and "device group" in d["config"]["launch"]
+    assert len(d["per_rank"]["ms_gpu_timed_draw"]) == 2 and min(d["per_rank"]["ms_gpu_timed_draw"]) > 0 and d["per_rank"]["gather_wall_ms"] >= 0
     assert d1["config"]["rays_per_frame"] == d["config"]["rays_per_frame"]
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a, b)

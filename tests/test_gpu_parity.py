@@ -359,14 +359,15 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
-                                     "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter"])
+                                     "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
+                                     "fat_shading_records", "no_hit_lds", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
     inside shade(0), bounce and shadow rays on the rope kernels (scene option rope = 1), and any pass shape / number of passes in flight."""
     w, h = 256, 144
     sc = mrt.DragonScene((w, h))
-    sopt = {"wide": 0} if backend.startswith("rope_only") else {"rope": 1} if backend in ("rope_bounce", "rope_primary_in_shade") else None
+    sopt = {"wide": 0} if backend.startswith("rope_only") else {"rope": 1} if backend in ("rope_bounce", "rope_primary_in_shade") else {"fat_shade": 1} if backend == "fat_shading_records" else None      # (fat_shade = 1: a 48-byte shading record per triangle holds its three normals: one gather per hit instead of tri_shade -> three normals)
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
     assert r.device_scene.stats.wide_layout == (0 if backend.startswith("rope_only") else 1)
     if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
@@ -377,6 +378,13 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "persistent_never": r.set_option("persistent", 0)
     if backend == "one_work_counter": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("xcd_counters", 0)      # (default: one counter and one eighth of every sub-frame's rays per XCD)
     if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
+    # the pulling launch with LDS extras (traverse_wide.h StreamExt): a finished ray reported from LDS; the top of the tree staged in LDS, per wave or per 256-thread workgroup
+    if backend == "no_hit_lds": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("hit_lds", 0)      # the pulling launch without LDS extras (round 4's kernel)
+    if backend in ("lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"):
+        r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
+        r.set_option("hit_lds", 1 if backend.startswith("hit_lds") else 0)          # (hit_lds = 1 is the default: these switch it off beside lds_top)
+        r.set_option("lds_top", {"hit_lds": 0, "lds_top_per_wave": 1, "lds_top_workgroup": 2, "lds_top_workgroup_two_levels": 3, "workgroup_of_four_waves": 4, "hit_lds_lds_top_small_grid": 2}[backend])
+        if backend == "hit_lds_lds_top_small_grid": r.set_option("wave_slots", 96)      # few waves: a long drain phase, where idle lanes test a straggler's triangles and hand their hit to its owner
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 8: 5 frames = one pass; three: 3 + 2
@@ -391,6 +399,32 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
         assert np.array_equal(g["primitive_id"], o["primitive_id"]) and np.array_equal(g["distance"].view(np.uint32), o["distance"].view(np.uint32))
         rays[:, 7] = 1.5
         assert np.array_equal(r.device_scene.intersect_any(rays), osc.intersect_any(rays))
+    r.close()
+
+
+@pytest.mark.parametrize("groups,size", [(2, (256, 144)), (3, (333, 187)), (4, (256, 144)), (0, (256, 144)), (4, (200, 64))])
+def test_tile_groups_render_the_same_image(mrt, orc, gpu_ctx, groups, size):
+    """A short draw runs every pass as G groups of tiles on G lanes (renderer option tile_groups; renderer.h TileGroup): disjoint pixels, one accumulation target.  One frame
+    alone, a draw of several one-frame passes, a batched pass, a draw after the group count changed and a long draw that falls back to whole passes must give the oracle's
+    image and ray counts whatever G — also at ragged sizes and when a group gets few tiles."""
+    w, h = size
+    sc = mrt.DragonScene((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    r.set_option("tile_groups", groups)
+    r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 1)
+    r.draw(1, wait=True)                                             # one frame alone: G groups on G lanes
+    if groups >= 2 and w * h >= 256 * 144: assert r.get_option("groups_used") == groups
+    if groups == 0: assert r.get_option("groups_used") == 3          # by the draw: a one-frame pass alone on the chip runs as three groups
+    r.set_option("frames_in_flight", 2); r.draw(3, wait=True)        # passes of one frame, two in flight, each in groups
+    r.set_option("frame_batch", 4); r.set_option("frames_in_flight", 6); r.draw(6, wait=True)      # 3 + 3 frames
+    r.set_option("tile_groups", 2 if groups != 2 else 3); r.draw(2, wait=True)                     # another group count: other tiles per lane, new seed tables
+    r.set_option("tile_groups", groups); r.draw(1, wait=True)
+    r.set_option("tile_groups", 0); r.set_option("frame_batch", 1); r.draw(13, wait=True)          # more passes than lanes: whole passes (G = 1)
+    assert r.get_option("groups_used") == 1
+    assert r.frameIndex == 26
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 26)
+    assert_parity(r.accumulation(), ref)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     r.close()
 
 

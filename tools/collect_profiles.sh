@@ -16,9 +16,9 @@ COMMON="--no-cpu-baseline --no-strict --no-latency"
 [ -x $R/tools/valu_rates ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $R/tools/valu_rates $R/tools/valu_rates.hip || echo "valu_rates did not build: step 4 will be skipped"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -- python3 $R/bench.py --steps 20 --warmup 8 $COMMON > $OUT/bench_driver_under_rocprof.json 2> $OUT/trace_driver.err || { echo "trace driver failed"; tail -5 $OUT/trace_driver.err; exit 1; }; echo "trace driver ok"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --steps 20 --warmup 4 $COMMON --opt frames_in_flight=1 --opt frame_batch=1 > $OUT/bench_serial_under_rocprof.json 2> $OUT/trace_serial.err || { echo "trace serial failed"; tail -5 $OUT/trace_serial.err; exit 1; }; echo "trace serial ok"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial_pass -- python3 $R/bench.py --steps 32 --warmup 8 $COMMON --opt frames_in_flight=1 --opt frame_batch=8 > $OUT/bench_serial_pass_under_rocprof.json 2> $OUT/trace_serial_pass.err || { echo "trace serial pass failed"; tail -5 $OUT/trace_serial_pass.err; exit 1; }; echo "trace serial pass ok"
-PMC="--steps 16 --warmup 8 $COMMON --opt frames_in_flight=1 --opt frame_batch=8"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 $R/bench.py --steps 20 --warmup 4 $COMMON --opt frames_in_flight=1 --opt frame_batch=1 --opt tile_groups=1 > $OUT/bench_serial_under_rocprof.json 2> $OUT/trace_serial.err || { echo "trace serial failed"; tail -5 $OUT/trace_serial.err; exit 1; }; echo "trace serial ok"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial_pass -- python3 $R/bench.py --steps 32 --warmup 8 $COMMON --opt frames_in_flight=1 --opt frame_batch=8 --opt tile_groups=1 > $OUT/bench_serial_pass_under_rocprof.json 2> $OUT/trace_serial_pass.err || { echo "trace serial pass failed"; tail -5 $OUT/trace_serial_pass.err; exit 1; }; echo "trace serial pass ok"
+PMC="--steps 16 --warmup 8 $COMMON --opt frames_in_flight=1 --opt frame_batch=8 --opt tile_groups=1"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SALU" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \

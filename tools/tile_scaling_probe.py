@@ -18,6 +18,7 @@ ap.add_argument("--scene", default="dragon", choices=sorted(mrt.SCENES)); ap.add
 ap.add_argument("--bounces", type=int, default=3)
 ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
 ap.add_argument("--sopt", action="append", default=[], help="scene option key=value (repeatable), e.g. instancing=1")
+ap.add_argument("--all-ranks", action="store_true", help="time EVERY rank r of N (not rank 0 alone): the draw of a real N-GPU run waits for the slowest; prints max / mean over the ranks")
 a = ap.parse_args()
 w, h = a.width, a.height
 scene = mrt.SCENES[a.scene]((w, h))
@@ -28,8 +29,10 @@ print(f"# {a.scene} {w}x{h}, {a.bounces} bounces, {a.steps} timed frames after {
 for world in [int(x) for x in a.worlds.split(",")]:
     batches = ["auto"] if a.batches == "auto" else [int(x) for x in a.batches.split(",")]
     for fb in batches:
+      per_rank = []
+      for rank in (range(world) if (a.all_ranks and world > 1) else [0]):
         r = mrt.Renderer((w, h), scene, ctx=ctx, seed=1, max_bounces=a.bounces, scene_options=sopts)
-        if world > 1: r.set_shard(0, world)
+        if world > 1: r.set_shard(rank, world)
         if fb == "auto":
             d = int(r.get_option("frame_batch"))
             fb_used = d if world == 1 else min(min(32, d * world), max(d, (a.warmup + a.steps) // 3))      # distributed.py ShardedRenderer
@@ -44,8 +47,14 @@ for world in [int(x) for x in a.worlds.split(",")]:
             t0 = time.perf_counter(); r.draw(a.steps); r.wait(); dt = time.perf_counter() - t0
             st = r.stats
             rate = (st.closest_rays + st.shadow_rays) / dt / 1e6
-            if best is None or rate > best: best, best_dt = rate, dt
+            if best is None or rate > best: best, best_dt, best_rays = rate, dt, st.closest_rays + st.shadow_rays
         if world == 1: base = max(base or 0.0, best)
         if base is None: base = float('nan')
-        print(f"world {world} frame_batch {fb_used:2d}: rank time {best_dt * 1e3:7.2f} ms  rank rate {best:8.1f} Mrays/s  x{world} = {best * world:8.1f}  efficiency vs best 1-GPU {best * world / base:5.2f}", flush=True)
+        per_rank.append((rank, best_dt, best, best_rays))
+        if not (a.all_ranks and world > 1):
+            print(f"world {world} frame_batch {fb_used:2d}: rank time {best_dt * 1e3:7.2f} ms  rank rate {best:8.1f} Mrays/s  x{world} = {best * world:8.1f}  efficiency vs best 1-GPU {best * world / base:5.2f}", flush=True)
         r.close()
+      if a.all_ranks and world > 1:
+        ts = [x[1] for x in per_rank]; rays = sum(x[3] for x in per_rank)
+        print(f"world {world} frame_batch {fb_used:2d}: rank times " + " ".join(f"{t * 1e3:.2f}" for t in ts) + f" ms   max {max(ts) * 1e3:.2f}  mean {sum(ts) / len(ts) * 1e3:.2f}  max/mean {max(ts) / (sum(ts) / len(ts)):.3f}"
+              f"   all ranks' rays / slowest rank's time = {rays / max(ts) / 1e6:8.1f} Mrays/s  efficiency vs best 1-GPU {rays / max(ts) / 1e6 / base:5.2f}", flush=True)
