@@ -316,6 +316,30 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
     traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? 256u : 0u), fetch, emit, nullptr, NoPairs{}, ext);
 }
 
+// The static split of small launches (k_trace_mixed_wide_stream) with the hit words in LDS (renderer option hit_lds): flattened scenes, shadow planes.
+__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_stream_x(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                                uint32_t rays_per_wave, uint8_t *__restrict__ lit, uint32_t even_waves) {
+    extern __shared__ uint32_t lds_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
+    const uint32_t begin = blockIdx.x * rays_per_wave;
+    if (begin >= n) return;
+    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u};
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, OneRange{begin, min(n, begin + rays_per_wave)}, lds_dyn + 256u,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
+            else tag = __float_as_uint(B.w);          // shadow planes: the ray reports to its pixel's byte
+        },
+        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
+            else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
+        }, nullptr, NoPairs{}, ext);
+}
+
 #include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes
 #include "megakernel.h"            // k_megakernel: one launch per frame
 
@@ -1441,7 +1465,8 @@ int Renderer::render(int n_frames) {                                   // Render
                     const size_t slots_m = 2 * (size_t)capacity * B;
                     const uint32_t even = stream_even > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)stream_even / 100)) : 0u;     // stream_even: percent of the wave slots
                     const dim3 grid_s(even ? even : cdiv(slots_m, rpw_m));
-                    if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
+                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + 1024, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m, lit_b, even);
+                    else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }
                 else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed<true>, dim3(grid_mixed), dim3(64), 0, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p);

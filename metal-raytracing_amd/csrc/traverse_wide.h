@@ -509,7 +509,8 @@ struct XcdRegions {
                           // records, the instance row and the transform again in the BLAS pass).  Measured on dragon x 4: 8.0-8.2 against 8.3-8.4 Grays/s — the TLAS pass's 32 more bytes per pair cost more than the BLAS pass's gathers (profiles/r05_two_level_ab.txt)
 #endif
 #ifndef MRT_TL_HITUV
-#define MRT_TL_HITUV 1    // a hit found by the TLAS or the BLAS pass leaves {u, v, global triangle id, t} beside its ray's key; k_shade<.., PAIRS> takes the barycentrics when the id matches the key's instead of testing the winning triangle again
+#define MRT_TL_HITUV 0    // a hit found by the TLAS or the BLAS pass leaves {u, v, global triangle id, t} beside its ray's key; k_shade<.., PAIRS> takes the barycentrics when the id matches the key's instead of testing the winning triangle again.
+                          // Measured on dragon x 4 (thin pairs both ways): 8.2-8.3 against 8.4-8.5 Grays/s — the scattered 16-byte store per hit in the BLAS pass costs more (its launches 1.02 against 0.93 ms) than the re-test saves k_shade (1.02 against 1.04 ms)
 #endif
 struct NoPairs { static constexpr bool on = false; };
 struct PairQueue {
