@@ -30,6 +30,7 @@
 #include "traverse.h"
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
+#include "traverse_wide_pool.h"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -314,6 +315,30 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
         };
     StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n};
     traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? 256u : 0u), fetch, emit, nullptr, NoPairs{}, ext);
+}
+
+// The pulling launch of flattened scenes with the triangle tests pooled across the lanes of a wave (traverse_wide_pool.h; renderer option pool).  Shadow planes only.
+#ifndef MRT_POOL_WAVES
+#define MRT_POOL_WAVES 5          // waves per SIMD the kernel is compiled for: its LDS (4 KB of pool + the stack per wave) admits 19 waves per CU at DragonScene's depth
+#endif
+__global__ void __launch_bounds__(64, MRT_POOL_WAVES) k_trace_mixed_wide_pool(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
+                                                                uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes) {
+    extern __shared__ uint32_t lds_dyn[];
+    const unsigned long long c = *counts;
+    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+    if (blockIdx.x * chunk >= n) return;
+    traverse_wide_pool(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, lds_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
+            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
+            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
+            else tag = __float_as_uint(B.w);          // shadow planes: the ray reports to its pixel's byte
+        },
+        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
+            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
+            else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
+        });
 }
 
 // The static split of small launches (k_trace_mixed_wide_stream) with the hit words in LDS (renderer option hit_lds): flattened scenes, shadow planes.
@@ -923,6 +948,15 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
         }
     }
 #endif
+#ifdef MRT_STATS_POOL      // diagnostics build: the pooled walk (traverse_wide_pool.h) behind the same statistics (the host adds POOL_WORDS * 4 bytes of LDS)
+    if constexpr (!TWO_LEVEL) traverse_wide_pool(s, OneRange{begin, end}, stk_dyn,
+        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
+            MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
+            A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
+        },
+        [&](uint32_t, bool, bool hit, const TravHit &) { sink += hit ? 1u : 0u; }, &ss);
+    else
+#endif
     traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, end}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
@@ -1431,7 +1465,23 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
                     const uint32_t chunk_arg = chunk;
 #endif
-                    if (!two_level && planes_pass && (hit_lds || lds_top)) {
+                    if (!two_level && planes_pass && pool) {
+                        const size_t lds_p = (size_t)POOL_WORDS * 4 + stack_bytes;
+                        if (slots_x_key != -2 - (int)(lds_p & 0xFFFFF)) {
+                            int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+                            MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
+                            MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_pool, 64, lds_p));
+                            if (per_cu < 1) { set_error("pool: the traversal kernel does not fit a compute unit with " + std::to_string(lds_p) + " bytes of LDS"); return MRT_ERR_UNSUPPORTED; }
+                            wave_slots_x = per_cu * prop.multiProcessorCount; slots_x_key = -2 - (int)(lds_p & 0xFFFFF);
+                        }
+                        const size_t ws = wave_slots_user ? (size_t)wave_slots : (size_t)wave_slots_x;
+                        const uint32_t chunk_x = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / (ws * 4) / 64 * 64));
+                        const size_t grid_slots_x = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? std::max<size_t>(1, ws / 2) : ws;
+                        const uint32_t waves_x = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk_x), grid_slots_x));
+                        launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_pool, dim3(waves_x), dim3(64), lds_p, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p,
+                                     (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_x, lit_b, xcd_counters ? (uint32_t)B : 0u);
+                    }
+                    else if (!two_level && planes_pass && (hit_lds || lds_top)) {
                         // the variant with LDS extras: its own workgroup shape, LDS size and wave slots
                         const int WV = lds_top >= 2 ? 4 : 1;
                         const bool TOPX = lds_top >= 1 && lds_top <= 3;
@@ -1647,7 +1697,11 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * nwaves));
     MRT_HIP(hipMemsetAsync(d_o.p, 0, 32 * nwaves, stream));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
+#ifdef MRT_STATS_POOL
+    const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : (size_t)POOL_WORDS * 4);
+#else
     const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : 0);
+#endif
     if (sc.num_inst) hipLaunchKernelGGL(k_query_stream_stats<true>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     else hipLaunchKernelGGL(k_query_stream_stats<false>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));

@@ -360,7 +360,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
-                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"])
+                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
@@ -380,6 +380,11 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
     # the pulling launch with LDS extras (traverse_wide.h StreamExt): a finished ray reported from LDS; the top of the tree staged in LDS, per wave or per 256-thread workgroup
     if backend == "no_hit_lds": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("hit_lds", 0)      # the pulling launch without LDS extras (round 4's kernel)
+    # triangle tests pooled across the lanes of a wave (traverse_wide_pool.h): the pulling launch; a few waves (long drains: the ring runs nearly empty); one-frame passes on three lanes
+    if backend.startswith("pooled_triangle_tests"):
+        r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("pool", 1)
+        if backend.endswith("small_grid"): r.set_option("wave_slots", 96)
+        if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 3)
     if backend == "no_hit_lds_static_split": r.set_option("persistent", 0); r.set_option("hit_lds", 0)              # the static split without them (persistent_never runs it with them: the default)
     if backend in ("lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"):
         r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
