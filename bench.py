@@ -195,6 +195,17 @@ def latency_leg(mrt, r, scene, w, h, bounces, opts, frames=24):
     q.draw(6, wait=True)
     t0 = time.perf_counter(); q.draw(30, wait=True); dt = time.perf_counter() - t0
     out["reference_like_3_in_flight_ms_per_frame"] = round(dt * 1e3 / 30, 4)
+    # last (the option cannot be taken back): the serialised passes again with the pulling launches on ALL the wave slots — a long call runs them on half, so that the other passes'
+    # launches find free slots; alone on the chip the kernel is faster on all of them.  roofline.whole_chip
+    q.set_option("frames_in_flight", 1); q.set_option("frame_batch", PASS_FRAMES); q.set_option("tile_groups", 1); q.set_option("wave_slots", q.get_option("wave_slots"))
+    q.draw(2 * PASS_FRAMES, wait=True)
+    tot = {}
+    for _ in range(5):
+        q.draw(2 * PASS_FRAMES, wait=True)
+        for k, (ms, n) in q.kernel_times.items():
+            if n:
+                t = tot.setdefault(k, [0.0, 0]); t[0] += ms; t[1] += n
+    out["kernel_ms_serialised_pass_whole_chip"] = {k: round(ms / n, 4) for k, (ms, n) in tot.items()}; out["wave_slots"] = int(q.get_option("wave_slots"))
     q.close()
     return out
 
@@ -446,6 +457,10 @@ def main():
                           "regime": f"the kernel ALONE: one stream, passes of {PASS_FRAMES} frames (the default pass size), nothing else on the chip; HIP start/stop events of its own launches, taken in this run after the timed region.  kernel_time_per_frame_ms <= ms_per_step is the consistency check; under_overlap has the same kernel inside the timed region",
                           "avg_launch_ms_rocprof_serialised_pass": (round((prof.get("kernel_avg_us_serial_pass") or {}).get("k_trace_mixed_wide_persist", 0.0) / 1e3, 4) or None) if prof_applies else None,
                           "avg_launch_ms_rocprof_serialised_one_frame": (round((prof.get("kernel_avg_us_serial") or {}).get("k_trace_mixed_wide_stream", 0.0) / 1e3, 4) or None) if prof_applies else None})
+                tw = out["latency"].get("kernel_ms_serialised_pass_whole_chip", {}).get("trace")
+                if tw:
+                    R["whole_chip"] = {"avg_launch_ms": tw, "achieved": round(b4 / (tw * 1e-3) / 1e9, 2), "frac": round(b4 / (tw * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "unit": "GB/s", "waves": out["latency"]["wave_slots"],
+                                       "note": "the same serialised 8-frame launches on ALL the wave slots of the chip (renderer option wave_slots set): the kernel alone with nothing to leave room for.  The headline figure above keeps the launch shape of the timed region — a long call runs its pulling launches on half the slots so that the other passes' launches overlap (+2...+5 % on the frame) — which is also the shape of the committed rocprofv3 traces"}
                 if prof_applies and traffic_p and prof.get("pmc_frames_per_dispatch", PASS_FRAMES) == PASS_FRAMES:
                     # the counters were collected on exactly these launches (serialised passes of PASS_FRAMES frames, tools/collect_profiles.sh): per launch, no scaling
                     R.update({"traffic": round(traffic_p), "traffic_source": prof.get("_source"),
