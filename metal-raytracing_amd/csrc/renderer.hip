@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
         });
 }
 
-#ifdef MRT_WAVE_TIMES      // diagnostics build (tools/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
+#ifdef MRT_WAVE_TIMES      // diagnostics build (tools/archive/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
 __device__ unsigned long long g_wave_times[2 * 8192];
 __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: iterations | drain iterations + longest iteration << 12 | live lanes summed over the drain iterations | drain start tick
 #endif
@@ -1271,7 +1271,7 @@ int Renderer::render(int n_frames) {                                   // Render
     MRT_HIP(hipEventRecord(ev_fork, stream));
     for (int k = 0; k < F; k++) MRT_HIP(hipStreamWaitEvent(lanes[k].stream, ev_fork, 0));
 #ifdef MRT_DIAGNOSTICS
-    // measuring aid of the diagnostics build only (tools/build_variant.sh diag "-DMRT_DIAGNOSTICS"; tools/gpu_stage_ablation.sh): MRT_ABLATE=1 skips the primary launches, =2 the
+    // measuring aid of the diagnostics build only (tools/build_variant.sh diag "-DMRT_DIAGNOSTICS"; tools/archive/gpu_stage_ablation.sh): MRT_ABLATE=1 skips the primary launches, =2 the
     // bounce / shadow traversal launches — the other kernels then run on the stale but well-formed queues of an earlier pass, so their load is realistic and the frame time shows
     // what the skipped stage costs under overlap.  Images are garbage; the release library does not read the variable.
     static const int ablate = getenv("MRT_ABLATE") ? atoi(getenv("MRT_ABLATE")) : 0;

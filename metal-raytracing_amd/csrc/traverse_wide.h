@@ -434,7 +434,7 @@ constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 struct StreamStats {
     uint32_t iters, live_sum, node_sum, tri_sum, refills, refill_lanes;
-#ifdef MRT_STATS_PROBE      // diagnostics builds (tools/build_variant.sh; tools/r05/): = 1 node fetches by tree level, = 2 pending triangles per iteration (what pooling triangle tests across lanes could use)
+#ifdef MRT_STATS_PROBE      // diagnostics builds (tools/build_variant.sh; tools/stream_level_probe.py): = 1 node fetches by tree level, = 2 pending triangles per iteration (what pooling triangle tests across lanes could use)
     uint32_t level_end[3] = {0, 0, 0};      // = 1: first node index beyond levels 0..1, 0..2, 0..3 (BFS numbering); the three counters below: fetches of nodes before each
     uint32_t probe[3] = {0, 0, 0};          // = 2: pending triangles summed over lanes and iterations | lanes with two or more pending | iterations in which fewer than 16 lanes test a triangle
 #endif
@@ -722,7 +722,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             }
         }
         const bool in_blas = TWO_LEVEL && (g_mask >> 24) != 0u;
-        // Drain phase (rocprofv3 / tools/wave_times.py: the last 30 % of a launch run on < 2 % of the waves, each walking one or two grazing rays
+        // Drain phase (rocprofv3 / tools/archive/wave_times.py: the last 30 % of a launch run on < 2 % of the waves, each walking one or two grazing rays
         // that test 100-200 triangles one per iteration).  The finished lanes help: the pending triangles of ONE such ray are tested by idle
         // lanes in this same iteration — lane k (or k + 32) takes triangle t_base + k with the owner's ray — and folded back into the owner.
         bool helping = false; int owner = -1; uint32_t help_pk = 0;
@@ -830,7 +830,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             ss->probe[0] += tot; ss->probe[1] += (uint32_t)__popcll(__ballot(pend >= 2u)); ss->probe[2] += __popcll(__ballot(has_tri)) < 16 ? 1u : 0u;
         }
 #endif
-#ifdef MRT_STATS_BOTH      // diagnostics build (tools/two_level_probe.py): in place of the refill counters, lane-iterations that do a triangle AND a node / that enter an instance
+#ifdef MRT_STATS_BOTH      // diagnostics build (tools/archive/two_level_probe.py): in place of the refill counters, lane-iterations that do a triangle AND a node / that enter an instance
         if (ss) { ss->refills += (uint32_t)__popcll(__ballot(has_tri && want_node)); ss->refill_lanes += (uint32_t)__popcll(__ballot(TWO_LEVEL && has_inst)); }
 #endif
         float4 r0, r1, r2, n0, n1, n2, n3, n4;        // loaded under has_tri / want_node and used under the same predicates;

@@ -4,7 +4,7 @@
 #pragma once
 
 // In the one-loop walk of a two-level scene (k_trace_mixed_wide_persist<true>) the lanes of a wave are out of step — node / triangle / level change — and dragon x 4 costs
-// 17.1 wave-iterations per 64 bounce rays where the flattened scene costs 13.5 (tools/two_level_binning_probe.py).  Here the bounce / shadow rays of a shade pass take two launches:
+// 17.1 wave-iterations per 64 bounce rays where the flattened scene costs 13.5 (tools/archive/two_level_binning_probe.py).  Here the bounce / shadow rays of a shade pass take two launches:
 //   k_tl_top    the same loop, but an instance of more than eight triangles is not entered: {ray, instance} goes to a queue (ballot-compacted; a wave reserves 256 slots per atomic: PairQueue).
 //               What a ray finds at the TLAS level (walls, floor: tested in place) becomes its result so far: a 64-bit key (t bits << 32 | global triangle id), ~0 = nothing;
 //               a shadow ray not occluded so far sets its pixel's byte.

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r05_fifth; mkdir -p $O; cd $R
 V=$R/metal-raytracing_amd/variants
-MRT_LIB_PATH=$V/libmrt_hip_probe1.so timeout -k 10 200 python3 tools/r05/stream_probe.py 1 > $O/probe1.txt 2>&1; grep -v amdgpu.ids $O/probe1.txt
+MRT_LIB_PATH=$V/libmrt_hip_probe1.so timeout -k 10 200 python3 tools/stream_level_probe.py 1 > $O/probe1.txt 2>&1; grep -v amdgpu.ids $O/probe1.txt
 echo "== instancing tests on head (thin pairs + hit uv)"; timeout -k 10 400 python3 -m pytest tests/test_instancing.py -m gpu -x -q 2>&1 | tail -2
 b() { timeout -k 10 200 python3 bench.py --steps ${STEPS:-240} --warmup ${WARM:-24} --no-cpu-baseline --no-latency --no-strict $1 2> $O/last.err | python3 -c "
 import json,sys

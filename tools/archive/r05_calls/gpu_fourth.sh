@@ -5,7 +5,7 @@ timeout -k 10 800 python3 -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=
 [ $rc -eq 0 ] || { grep -E "Error|error|assert|FAILED" $O/pytest.log | head -20; exit 1; }
 V=$R/metal-raytracing_amd/variants
 echo "== tests on the thin-pairs variant"; MRT_LIB_PATH=$V/libmrt_hip_tlthin.so timeout -k 10 400 python3 -m pytest tests/test_instancing.py -m gpu -x -q 2>&1 | tail -2
-timeout -k 10 400 python3 tools/r05/latency_groups.py > $O/latency_groups.txt 2>&1; grep -v amdgpu.ids $O/latency_groups.txt
+timeout -k 10 400 python3 tools/latency_groups.py > $O/latency_groups.txt 2>&1; grep -v amdgpu.ids $O/latency_groups.txt
 b() { timeout -k 10 200 python3 bench.py --steps ${STEPS:-240} --warmup ${WARM:-24} --no-cpu-baseline --no-latency --no-strict $1 2> $O/last.err | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   value', d['value'], 'ms/step', d['ms_per_step'], 'kernels', d['roofline']['under_overlap']['all_kernels_avg_launch_ms'])" || tail -3 $O/last.err; }

@@ -5,7 +5,7 @@
   the driver's command on one GPU (20 frames after 5): Mrays/s"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import metal_raytracing_amd as mrt
 w, h = 1920, 1080

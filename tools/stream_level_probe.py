@@ -1,9 +1,9 @@
 """Round-5 probes of the stream walk on DragonScene's bounce-like and shadow rays (tools/stream_lane_use.py's rays), through diagnostics builds of the library:
   MRT_LIB_PATH=.../libmrt_hip_probe1.so (-DMRT_STATS_PROBE=1)  node fetches by tree level: what an LDS copy of the top levels would serve
   MRT_LIB_PATH=.../libmrt_hip_probe2.so (-DMRT_STATS_PROBE=2)  pending triangles per iteration: what pooling triangle tests across lanes could use
-usage: tools/r05/stream_probe.py 1|2 [per_wave]"""
+usage: tools/stream_level_probe.py 1|2 [per_wave]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import metal_raytracing_amd as mrt
 mode = int(sys.argv[1]); pw = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
