@@ -270,7 +270,8 @@ int mrt_renderer_wait(MRTRenderer r);
 /* The same completion as a poll (the reference's handler is told per command buffer, Renderer.swift:285-287): frames, counted
  * as MRTRenderStats.frames is, whose accumulation has finished on the device.  Never blocks.  Granularity: a pass of `frame_batch`
  * frames; the LAST passes of a draw call (one per pass in flight, i.e. every pass of a short call such as 20 frames) are accumulated
- * together when the call's last traversal launch has finished, so their frames are reported together at the end of the call.          */
+ * together when the call's last traversal launch has finished, so their frames are reported together at the end of the call.  A call
+ * whose passes carry ONE frame each runs every pass as groups of tiles on several streams and reports its frames at the end of the call.  */
 int mrt_renderer_frames_completed(MRTRenderer r, uint64_t *frames);
 /* accumulationTargets[0] after the swap (Renderer.swift:332-334): w*h RGBA32F, row 0 = bottom of
  * the image as the kernel writes it (Raytracing.metal:206-207; the blit flips, Shaders.metal:35). */
