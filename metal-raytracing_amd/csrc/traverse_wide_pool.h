@@ -10,7 +10,7 @@
 // nothing else is left to do); a lane with nodes left visits one in EVERY iteration, with the limit its key holds by then.
 //
 // Per wave in LDS (POOL_WORDS 32-bit words in front of the stack): key[64] (u64: t bits << 32 | id; id = ~0: nothing yet), U / V / |det| [3][64] of the hit that holds the
-// key, the rays {o.xyz, -} {d.xyz, -} [64][2] float4, the ring [POOL_Q].  The ring is first in, first out and its head and tail are wave-uniform counters: a lane's ray is
+// key, the rays o.xyz d.xyz [6][64], the ring [POOL_Q].  The ring is first in, first out and its head and tail are wave-uniform counters: a lane's ray is
 // finished when it has no node left, nothing left to put into the ring and the head has passed its last entry; its slot is then reported and refilled as in the stream walk.
 #pragma once
 #include "traverse_wide.h"
@@ -34,7 +34,7 @@ namespace {
 #define MRT_POOL_REFILL_AT MRT_WIDE_REFILL_AT      // idle lanes at which the wave reports and refills
 #endif
 constexpr uint32_t POOL_Q = MRT_POOL_Q;
-constexpr uint32_t POOL_WORDS = 128 + 192 + 512 + POOL_Q;          // key, U V |det|, rays (two float4 per lane), ring
+constexpr uint32_t POOL_WORDS = 128 + 192 + 384 + POOL_Q;          // key, U V |det|, rays, ring
 static_assert((POOL_Q & (POOL_Q - 1)) == 0 && POOL_Q >= 128, "the ring's size must be a power of two and hold two triangle halves");
 
 template <class Chunks, class RayFetch, class Emit>
@@ -46,9 +46,9 @@ MRT_DEV void traverse_wide_pool(const SceneView &s, Chunks next_chunk, uint32_t 
     lds_u64 *const key = (lds_u64 *)lds;
     lds_u32 *const key32 = (lds_u32 *)lds;            // [2 * lane] = id, [2 * lane + 1] = t bits
     lds_f32 *const huv = (lds_f32 *)lds + 128;
-    typedef MRT_LDS float4 lds_f4t;
-    lds_f4t *const rays = (lds_f4t *)((lds_u32 *)lds + 320);          // [lane][2]: {o.xyz, -} {d.xyz, -}: two ds_read_b128 per tester
-    lds_u32 *const ring = (lds_u32 *)lds + 832;
+    lds_f32 *const rays = (lds_f32 *)lds + 320;          // [6][64]: o.x o.y o.z d.x d.y d.z by lane — six ds_read_b32 per tester, free of bank conflicts whatever the owners (two float4 per lane read with
+                                                          // ds_read_b128 put owners 8 apart on the same banks: SQ_LDS_BANK_CONFLICT was a third of the kernel's LDS cycles, profiles/r05_pool_ab.txt)
+    lds_u32 *const ring = (lds_u32 *)lds + 704;
     uint32_t *const stack = lds + POOL_WORDS;
     uint32_t q_head = 0, q_tail = 0;                  // wave-uniform, only ever grow; entry k lives in ring[k & (POOL_Q - 1)]
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -94,7 +94,7 @@ MRT_DEV void traverse_wide_pool(const SceneView &s, Chunks next_chunk, uint32_t 
                     nx = bx_ < 0.0f; ny = by_ < 0.0f; nz = bz_ < 0.0f; oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                     tagw = __float_as_uint(bw_);
                     g_base = 0u; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0; last_end = q_head;
-                    { lds_f4t *const rr = rays + 2u * lane; rr[0].x = ax_; rr[0].y = ay_; rr[0].z = az_; rr[0].w = 0.0f; rr[1].x = bx_; rr[1].y = by_; rr[1].z = bz_; rr[1].w = 0.0f; }
+                    rays[lane] = ax_; rays[64u + lane] = ay_; rays[128u + lane] = az_; rays[192u + lane] = bx_; rays[256u + lane] = by_; rays[320u + lane] = bz_;
                     key32[2 * lane] = 0xFFFFFFFFu; key32[2 * lane + 1] = __float_as_uint(aw_);          // nothing yet; the ray's own limit (+inf for a bounce ray)
                     live = true;
                 }
@@ -148,8 +148,7 @@ MRT_DEV void traverse_wide_pool(const SceneView &s, Chunks next_chunk, uint32_t 
         }
         // ---- the triangle half: entry against its owner's ray; a hit is folded into the owner's key (minimum t, ties to the lowest id)
         if (tester) {
-            const lds_f4t *const rr = rays + 2u * owner;
-            const f3 oo = mk3(rr[0].x, rr[0].y, rr[0].z), dd = mk3(rr[1].x, rr[1].y, rr[1].z);
+            const f3 oo = mk3(rays[owner], rays[64u + owner], rays[128u + owner]), dd = mk3(rays[192u + owner], rays[256u + owner], rays[320u + owner]);
             const float lim = __uint_as_float(key32[2 * owner + 1]);
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, oo, dd, 0.0f, lim, t, U, V, ad)) {

@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = next((s for s in ("k_trace_primary", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_raygen", "k_extend", "k_shade", "k_shadow", "k_accumulate") if s in n), None)
+        k = next((s for s in ("k_trace_primary", "k_trace_mixed_wide_pool", "k_trace_mixed_wide_persist", "k_trace_mixed_wide_stream", "k_trace_mixed_wide", "k_trace_mixed", "k_tl_top", "k_tl_blas", "k_shade", "k_accumulate") if s in n), None)
         if not k: continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
