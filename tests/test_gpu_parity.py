@@ -253,6 +253,24 @@ def test_shards_sum_to_full_frame(mrt, orc, gpu_ctx):
     assert np.array_equal(acc, f) and rays == 2 * w * h
 
 
+def test_shards_in_tile_groups_sum_to_full_frame(mrt, orc, gpu_ctx):
+    """A sharded renderer whose passes carry one frame runs them as tile groups (group g of G of rank r of N = shard g N + r of G N): every rank's image is its shard of the
+    oracle's, the shards sum to the full frame and the ray counts add up — also when a rank owns so few tiles that groups are refused (tiles_local < 64)."""
+    for (w, h), world in (((512, 288), 3), ((96, 64), 3)):
+        sc = mrt.CornellScene((w, h))
+        full = mrt.Renderer((w, h), sc, ctx=gpu_ctx); full.draw(3, wait=True); f = full.accumulation(); full.close()
+        acc = np.zeros_like(f); rays = 0
+        for rank in range(world):
+            r = mrt.Renderer((w, h), sc, ctx=gpu_ctx); r.set_shard(rank, world); r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 1)
+            r.draw(1, wait=True); r.draw(2, wait=True)
+            assert r.get_option("groups_used") == (3 if w == 512 else 1)
+            a = r.accumulation()
+            oa, _ = oracle_render(orc, mrt, sc, w, h, 3, shard=(rank, world))
+            assert np.array_equal(a, oa)
+            acc += a; rays += r.stats.primary_rays; r.close()
+        assert np.array_equal(acc, f) and rays == 3 * w * h
+
+
 def test_tonemap_matches_oracle(mrt, orc, gpu_ctx):
     sc = mrt.CornellScene((64, 48))
     r = mrt.Renderer((64, 48), sc, ctx=gpu_ctx); r.draw(3, wait=True)
