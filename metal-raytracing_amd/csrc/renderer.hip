@@ -31,6 +31,7 @@
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
 #include "traverse_wide_pool.h"
+#include "traverse_wide_tile.h"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -57,6 +58,7 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // (16 bits each, in the tmax word — always +inf for a bounce ray, and every traversal kernel takes it as such) instead of a 16-byte throughput record; the next
     // shade multiplies the same base colours in the same order (Raytracing.metal:339), so the floats are the ones the record would have held
     int32_t chain;
+    int32_t tile_walk;              // k_shade<.., TRACE0 = 2>: the tile's primary rays walk the top of the tree together (traverse_wide_tile.h); the launch then carries TILE_FRONT_WORDS more words of LDS per wave
     uint32_t wide_stack_words;      // k_shade<.., TRACE0 = 2>: 32-bit words of LDS stack per wave (the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES / 4)
 };
 
@@ -470,7 +472,35 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
         if (active && !PLANES) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
     }
     float4 H = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)), Bprim = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-    if (TRACE0) {
+    if (TRACE0 == 2 && fp.tile_walk) {          // (wave-uniform) the tile's rays walk the top of the tree together: every lane takes part, also those outside the image
+        extern __shared__ uint32_t shade_stk[];          // SHADE_WAVES x (wide-tree depth x WIDE_STACK_LEVEL_BYTES) + SHADE_WAVES x TILE_FRONT_WORDS words
+        const uint32_t wv_ = threadIdx.x >> 6;
+        uint32_t *const stk = shade_stk + wv_ * fp.wide_stack_words, *const front = shade_stk + SHADE_WAVES * fp.wide_stack_words + wv_ * TILE_FRONT_WORDS;
+        f3 dir = mk3(0.0f, 0.0f, 1.0f);
+        const f3 org = mk3(fp.cam_pos);                  // :214 — the same for every ray
+        uint32_t pixel = 0, guess = 0xFFFFFFFFu, seed = 0xFFFFFFFFu; float t0 = __builtin_inff();
+        if (active) {
+            f3 org_;
+            primary_ray(fp, seeds, spix, px_x, px_y, org_, dir);
+            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
+            if (hint != nullptr) {
+                pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+                guess = hint[pixel];
+                if (guess < s.num_wpackets) {
+                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
+                    float t, U, V, ad;
+                    if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+                }
+            }
+        }
+        TravHit h;
+        const bool hit = traverse_wide_tile<true>(s, active, org, dir, t0, seed, h, stk, fp.wide_stack_words, front);
+        if (active) {
+            if (hint != nullptr && h.pk != guess) hint[pixel] = h.pk;
+            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
+        }
+    }
+    else if (TRACE0) {
         if (active) {                        // k_trace_primary<false>, statement by statement
             f3 org, dir;
             primary_ray(fp, seeds, spix, px_x, px_y, org, dir);
@@ -1391,6 +1421,7 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
             const bool trace0_hint = primary_hint && (!two_level || (sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24)));      // two-level: the hint is (packet | instance << 24)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
+            fp.tile_walk = tile_walk ? 1 : 0;
             if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)this->capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
             else if (two_level && on_wide) {
@@ -1422,7 +1453,7 @@ int Renderer::render(int n_frames) {                                   // Render
                                               : fp.chain ? k_shade<false, true> : k_shade<false, false>;
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
-                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * scene->wide_depth * WIDE_STACK_LEVEL_BYTES : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (tile_walk ? TILE_FRONT_WORDS * 4 : 0)) : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && trace0_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)

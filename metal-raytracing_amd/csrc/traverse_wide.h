@@ -231,14 +231,17 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 // One ray per lane on the 8-wide layout, closest hit, the stream loop's iteration (node and triangle fetched in one round trip, scaled box test) without
 // refill: for COHERENT rays — the primary rays of an 8x8 tile, traced inside k_shade<.., TRACE0 = 2> — whose lanes stay in step by themselves.
 // SEED: `seed_pk` is a packet the caller has already tested (distance in tmax); the walk starts with it as its closest hit.  h.pk = packet of the final hit.
-template <bool SEED>
-MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */) {
+// ROOTS (traverse_wide_tile.h): the walk starts not at node 0 but at the nodes of `front` — nroots pairs {node, lower bound of the distance at which any ray of the tile enters it (float bits)},
+// nearest first — taking the next one whenever its own stack runs empty and skipping those that lie beyond its closest hit.
+template <bool SEED, bool ROOTS = false>
+MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */, const uint32_t *front = nullptr, uint32_t nroots = 0) {
     const uint32_t lane = threadIdx.x & 63;
     const float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
     const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     float best_t = tmax; uint32_t best_pk = SEED ? seed_pk : 0xFFFFFFFFu;
-    uint32_t g_base = 0, g_mask = s.num_wnodes != 0 ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
+    uint32_t g_base = 0, g_mask = (!ROOTS && s.num_wnodes != 0) ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
+    uint32_t cursor = 0;                 // ROOTS: next entry of `front`
     for (;;) {
         const bool has_tri = t_mask != 0;
         const uint32_t t_rest = t_mask & (t_mask - 1u);
@@ -247,7 +250,14 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
         if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
                 const uint32_t sp = g_mask >> 16;
-                if (sp == 0) { want_node = false; if (!has_tri) break; }
+                if (sp == 0) {
+                    bool got = false;
+                    if (ROOTS) while (cursor < nroots) {          // the next subtree of the tile's front that this ray can still reach
+                        const uint32_t r = front[2u * cursor]; const float enter = __uint_as_float(front[2u * cursor + 1u]); cursor++;
+                        if (enter <= best_t) { g_base = r; g_mask = 0x100u; got = true; break; }
+                    }
+                    if (!got) { want_node = false; if (!has_tri) break; }
+                }
                 else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
             }
             if (want_node) {
