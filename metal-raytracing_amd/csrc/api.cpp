@@ -493,6 +493,7 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     if (k == "persistent") { REQUIRE(value == 0 || value == 1 || value == 2, "persistent must be 0 (never), 1 (always) or 2 (by launch size)"); r->r.persistent = (int)value; }
     else if (k == "xcd_counters") { REQUIRE(value == 0 || value == 1, "xcd_counters must be 0 or 1"); r->r.xcd_counters = (int)value; }
     else if (k == "tile_groups") { REQUIRE(value >= 0 && value <= mrt::MAX_TILE_GROUPS && value == (int)value, "tile_groups must be 0 (by the draw), 1 (never) or 2..4"); r->r.tile_groups = (int)value; }
+    else if (k == "shade_pack") { REQUIRE(value == 0 || value == 1, "shade_pack must be 0 or 1"); r->r.shade_pack = (int)value; }
     else if (k == "tile_walk") { REQUIRE(value == 0 || value == 1, "tile_walk must be 0 or 1"); r->r.tile_walk = (int)value; }
     else if (k == "pool") { REQUIRE(value == 0 || value == 1, "pool must be 0 or 1"); r->r.pool = (int)value; }
     else if (k == "hit_lds") { REQUIRE(value == 0 || value == 1, "hit_lds must be 0 or 1"); r->r.hit_lds = (int)value; }
@@ -522,6 +523,7 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     else if (k == "hit_lds") *value = r->r.hit_lds;
     else if (k == "pool") *value = r->r.pool;
     else if (k == "tile_walk") *value = r->r.tile_walk;
+    else if (k == "shade_pack") *value = r->r.shade_pack;
     else if (k == "tile_groups") *value = r->r.tile_groups;
     else if (k == "groups_used") *value = r->r.groups_used;
     else if (k == "lds_top") *value = r->r.lds_top;

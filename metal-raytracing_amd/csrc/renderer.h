@@ -75,6 +75,7 @@ struct Renderer {
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int xcd_counters = 1;                  // pulling traversal launches: 1 = one work counter and one eighth of every sub-frame's rays per XCD (traverse_wide.h XcdRegions), 0 = one counter for all
     int hit_lds = 1;                     // pulling traversal launches of flattened scenes: a lane's closest hit keeps U, V, |det| and id in LDS; a finished ray is reported without re-testing its triangle (traverse_wide.h StreamExt)
+    int shade_pack = 1;                  // k_shade of bounces >= 1 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
     int tile_walk = 0;                   // flattened scenes, primary rays inside shade(0): the 64 rays of a tile walk the top levels of the 8-wide tree together (traverse_wide_tile.h)
     int pool = 0;                        // pulling traversal launches of flattened scenes: triangle tests pooled across the lanes of a wave (traverse_wide_pool.h)
     int lds_top = 0;                     // the same launches read the top of the 8-wide tree from LDS: 1 = levels 0..1, a copy per wave (64-thread workgroups); 2 = levels 0..2, one copy per 256-thread workgroup; 3 = levels 0..1 per 256-thread workgroup; 4 = 256-thread workgroups, nothing staged (A/B of the workgroup shape alone)

@@ -58,6 +58,7 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // (16 bits each, in the tmax word — always +inf for a bounce ray, and every traversal kernel takes it as such) instead of a 16-byte throughput record; the next
     // shade multiplies the same base colours in the same order (Raytracing.metal:339), so the floats are the ones the record would have held
     int32_t chain;
+    uint32_t pack_range;            // k_shade<.., PACK>: queue entries per workgroup (a multiple of the workgroup size; the host sizes it by the launch: SHADE_PACK_RANGE for large queues, less for small ones so that the grid still fills the chip)
     int32_t tile_walk;              // k_shade<.., TRACE0 = 2>: the tile's primary rays walk the top of the tree together (traverse_wide_tile.h); the launch then carries TILE_FRONT_WORDS more words of LDS per wave
     uint32_t wide_stack_words;      // k_shade<.., TRACE0 = 2>: 32-bit words of LDS stack per wave (the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES / 4)
 };
@@ -446,7 +447,11 @@ constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 
 // ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0, bool PAIRS = false>      // TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills); PAIRS (two-level scenes, bounces >= 1, renderer option tl_pairs): `hits` holds 64-bit keys (t bits << 32 | global triangle id, ~0 = miss) left by k_tl_top / k_tl_blas instead of hit records — the barycentrics come from re-testing the winning triangle in its instance's object space
+#ifndef MRT_SHADE_PACK_RANGE
+#define MRT_SHADE_PACK_RANGE 4096
+#endif
+constexpr uint32_t SHADE_PACK_RANGE = MRT_SHADE_PACK_RANGE;      // k_shade<.., PACK>: queue entries per workgroup, at most (FrameParams::pack_range)
+template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0, bool PAIRS = false, bool PACK = false>      // PACK (bounces >= 1, renderer option shade_pack): half the entries of a bounce queue are rays that missed — their lanes sit out the whole kernel (41 % of the lanes per VALU instruction, profiles/r05_summary.json).  A workgroup then takes SHADE_PACK_RANGE consecutive entries, compacts the HITS into a ring in LDS 256 entries at a time and shades 256 of them per round, every lane busy; TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills); PAIRS (two-level scenes, bounces >= 1, renderer option tl_pairs): `hits` holds 64-bit keys (t bits << 32 | global triangle id, ~0 = miss) left by k_tl_top / k_tl_blas instead of hit records — the barycentrics come from re-testing the winning triangle in its instance's object space
 __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
                                               const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
                                               const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
@@ -562,11 +567,11 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
             if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
         }
     }
-    else if (active && PAIRS) {
-        const unsigned long long key = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + i);
+    // PAIRS: a 64-bit key {t bits, global triangle id} left by the TLAS / BLAS passes becomes a hit record
+    auto pairs_hit = [&](const uint32_t i, const unsigned long long key) -> float4 {
         const float4 uv = (MRT_TL_HITUV && key != ~0ull) ? qload(&thr[i]) : make_float4(0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f);      // (PAIRS: `thr` is the lane's hit-barycentrics array, written by the pass that set the key)
-        if (key != ~0ull && MRT_TL_HITUV && __float_as_uint(uv.z) == (uint32_t)key) H = make_float4(__uint_as_float((uint32_t)(key >> 32)), uv.x, uv.y, uv.z);      // left by the winning hit itself
-        else if (key != ~0ull) {          // (another pair of the same ray wrote its barycentrics last — rare — or the round-4 form: test the winner again)
+        if (key != ~0ull && MRT_TL_HITUV && __float_as_uint(uv.z) == (uint32_t)key) return make_float4(__uint_as_float((uint32_t)(key >> 32)), uv.x, uv.y, uv.z);      // left by the winning hit itself
+        if (key != ~0ull) {          // (another pair of the same ray wrote its barycentrics last — rare — or the round-4 form: test the winner again)
             const uint32_t g = (uint32_t)key;
             const InstanceDev &I = s.inst[instance_of_gid(s, g)];
             const uint32_t pk = s.tri_packet[I.ts_base + (g - I.gid_base)];
@@ -574,10 +579,15 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
             const float4 *__restrict__ q = s.wpackets + WPK * (size_t)pk;
             float t_, U, V, ad;
             (void)tri_test(q[0], q[1], q[2], to_object_point(I, mk3(Aw)), to_object_dir(I, mk3(Bw)), 0.0f, __builtin_inff(), t_, U, V, ad);      // the traversal's own test of the winner: the same U, V, |det|
-            H = make_float4(__uint_as_float((uint32_t)(key >> 32)), U / ad, V / ad, __uint_as_float(g));
+            return make_float4(__uint_as_float((uint32_t)(key >> 32)), U / ad, V / ad, __uint_as_float(g));
         }
-    }
-    else if (active) H = qload(&hits[i]);
+        return make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    };
+    if (TRACE0) {}
+    else if (active && PAIRS && !PACK) H = pairs_hit(i, __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + i));
+    else if (active && !PACK) H = qload(&hits[i]);
+    // everything after the hit record: one entry per thread (i, its hit, whether there is one) — called once, or per round of a packing workgroup
+    auto shade_entry = [&](const uint32_t i, const float4 H, bool active) {
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
     bool want_shadow = false, want_next = false;
@@ -766,6 +776,47 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
         qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
         if (!CHAIN) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
     }
+    };          // shade_entry
+    if constexpr (PACK) {
+        __shared__ uint32_t p_idx[2 * SHADE_THREADS], p_w[SHADE_WAVES];
+        __shared__ float4 p_hit[2 * SHADE_THREADS];
+        const float4 miss = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        const uint32_t begin = blockIdx.x * fp.pack_range, end = min(n, begin + fp.pack_range);
+        const uint32_t lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+        uint32_t head = 0, tail = 0, cur = begin;                  // the ring's positions only ever grow; entry k lives in slot k & (2 * SHADE_THREADS - 1); all three are workgroup-uniform
+        for (;;) {
+            const uint32_t pending = tail - head;
+            if (pending < (uint32_t)SHADE_THREADS && cur < end) {          // room for 256 more: the next 256 entries' hits join the ring
+                const uint32_t e = cur + threadIdx.x;
+                float4 He = miss;
+                if (PAIRS) {          // the entry's key: kept as two words of the record, turned into a hit record in the round that shades it
+                    const unsigned long long key = e < end ? __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + e) : ~0ull;
+                    He = make_float4(__uint_as_float((uint32_t)key), __uint_as_float((uint32_t)(key >> 32)), 0.0f, __uint_as_float(key != ~0ull ? 0u : 0xFFFFFFFFu));
+                }
+                else if (e < end) He = qload(&hits[e]);
+                const bool a = __float_as_uint(He.w) != 0xFFFFFFFFu;
+                const unsigned long long m = __ballot(a);
+                if (lane_ == 0) p_w[wv_] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t off = 0, tot = 0;
+                for (int k = 0; k < SHADE_WAVES; k++) { const uint32_t c = p_w[k]; if ((uint32_t)k < wv_) off += c; tot += c; }
+                if (a) { const uint32_t pos = (tail + off + (uint32_t)__popcll(m & ((1ull << lane_) - 1ull))) & (2u * SHADE_THREADS - 1u); p_idx[pos] = e; p_hit[pos] = He; }
+                __syncthreads();
+                tail += tot; cur += SHADE_THREADS;
+                continue;
+            }
+            if (pending == 0u) break;
+            const uint32_t take = min(pending, (uint32_t)SHADE_THREADS);
+            const bool act = threadIdx.x < take;
+            const uint32_t pos = (head + threadIdx.x) & (2u * SHADE_THREADS - 1u);
+            const uint32_t ie = act ? p_idx[pos] : 0u;
+            float4 He = act ? p_hit[pos] : miss;
+            if (PAIRS && act) He = pairs_hit(ie, (unsigned long long)__float_as_uint(He.x) | ((unsigned long long)__float_as_uint(He.y) << 32));
+            head += take;
+            shade_entry(ie, He, act);
+        }
+    }
+    else shade_entry(i, H, active);
 }
 
 // ------------------------------------------------------------------ accumulate (Raytracing.metal:394-403)
@@ -1443,8 +1494,15 @@ int Renderer::render(int n_frames) {                                   // Render
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
-                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, SHADE_THREADS));
-                auto shade_kernel = materials ? k_shade<true, false>
+                const bool pack = shade_pack && b > 0;          // bounces >= 1 read a queue half of whose rays missed: its hits are compacted in LDS and shaded on full waves (k_shade<.., PACK>)
+                // entries per packing workgroup: SHADE_PACK_RANGE when the queue is long, less when that would leave fewer than ~2048 workgroups (a one-frame pass, a tile group, a shard) — never less than two rounds' worth
+                fp.pack_range = (uint32_t)std::min<size_t>(SHADE_PACK_RANGE, std::max<size_t>(2 * SHADE_THREADS, (size_t)capacity * B / 2048 / SHADE_THREADS * SHADE_THREADS));
+                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
+                auto shade_kernel = pack ? (materials ? k_shade<true, false, false, 0, false, true>
+                                                : pairs_pass ? k_shade<false, true, true, 0, true, true>
+                                                : planes_pass ? k_shade<false, true, true, 0, false, true>
+                                                : fp.chain ? k_shade<false, true, false, 0, false, true> : k_shade<false, false, false, 0, false, true>)
+                                              : materials ? k_shade<true, false>
                                               : (pairs_pass && b > 0) ? k_shade<false, true, true, 0, true>
                                               : (trace0_wide && b == 0 && two_level) ? k_shade<false, true, true, 3>
                                               : (trace0_wide && b == 0) ? k_shade<false, true, true, 2>

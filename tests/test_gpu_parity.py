@@ -378,7 +378,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
-                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint"])
+                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
@@ -406,6 +406,10 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend.startswith("primary_tile_walk"):              # the 64 primary rays of a tile walk the top of the tree together (traverse_wide_tile.h)
         r.set_option("tile_walk", 1)
         if backend.endswith("no_hint"): r.set_option("primary_hint", 0)
+    if backend.startswith("packed_shade"):                  # k_shade of bounces 1, 2 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
+        r.set_option("shade_pack", 1)          # (the default)
+        if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 2)
+    if backend == "unpacked_shade": r.set_option("shade_pack", 0)          # one queue entry per thread, hit or miss (round 4's form)
     if backend == "no_hit_lds_static_split": r.set_option("persistent", 0); r.set_option("hit_lds", 0)              # the static split without them (persistent_never runs it with them: the default)
     if backend in ("lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"):
         r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
@@ -450,6 +454,20 @@ def test_tile_groups_render_the_same_image(mrt, orc, gpu_ctx, groups, size):
     assert r.get_option("groups_used") == 1
     assert r.frameIndex == 26
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 26)
+    assert_parity(r.accumulation(), ref)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    r.close()
+
+
+@pytest.mark.parametrize("scene_name,size", [("dragon", (333, 187)), ("cornell", (64, 64)), ("cornell", (1000, 3)), ("garden", (257, 129)), ("dragon_hostile", (320, 180))])
+def test_packed_shade_at_ragged_sizes_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size):
+    """k_shade<.., PACK> (renderer option shade_pack) where the queue's length is no multiple of anything, on all four light types and on the hostile stand-in."""
+    w, h = size
+    sc = mrt.SCENES[scene_name]((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+    r.set_option("shade_pack", 1)
+    r.draw(3, wait=True); r.draw(2, wait=True)
+    ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     r.close()

@@ -17,16 +17,16 @@ def mk(groups, **o):
     for k, v in {**o, **extra}.items(): r.set_option(k, float(v))
     return r
 for rep in range(2):
-    for g, stag in ((1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 1), (0, 0)):
-        r = mk(g, frames_in_flight=1, frame_batch=1, tile_stagger=stag)
+    for g in (1, 2, 3, 4, 0):
+        r = mk(g, frames_in_flight=1, frame_batch=1)
         r.draw(4, wait=True); ts = []
         for i in range(24): r.draw(1, wait=True); ts.append(r.stats.ms_gpu_last)
-        print(f"one frame alone, tile_groups {g} stagger {stag} (used {int(r.get_option('groups_used'))}): median {np.median(ts):.4f} ms  min {np.min(ts):.4f}", flush=True)
+        print(f"one frame alone, tile_groups {g} (used {int(r.get_option('groups_used'))}): median {np.median(ts):.4f} ms  min {np.min(ts):.4f}", flush=True)
         r.close()
-    for g, stag in ((1, 0), (2, 0), (2, 1), (0, 0)):
-        r = mk(g, frames_in_flight=3, frame_batch=1, tile_stagger=stag)
+    for g in (1, 2, 0):
+        r = mk(g, frames_in_flight=3, frame_batch=1)
         r.draw(6, wait=True); t0 = time.perf_counter(); r.draw(30, wait=True); dt = time.perf_counter() - t0
-        print(f"three one-frame passes in flight, tile_groups {g} stagger {stag} (used {int(r.get_option('groups_used'))}): {dt * 1e3 / 30:.4f} ms per frame", flush=True)
+        print(f"three one-frame passes in flight, tile_groups {g} (used {int(r.get_option('groups_used'))}): {dt * 1e3 / 30:.4f} ms per frame", flush=True)
         r.close()
     for g in (1, 2, 0):
         r = mk(g); r.set_shard(0, 8); r.set_option("frame_batch", 8)
