@@ -32,6 +32,7 @@
 #include "traverse_instanced.h"
 #include "traverse_wide_pool.h"
 #include "traverse_wide_tile.h"
+#include "traverse_wide_bundle.h"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -61,6 +62,11 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     uint32_t pack_range;            // k_shade<.., PACK>: queue entries per workgroup (a multiple of the workgroup size; the host sizes it by the launch: SHADE_PACK_RANGE for large queues, less for small ones so that the grid still fills the chip)
     int32_t tile_walk;              // k_shade<.., TRACE0 = 2>: the tile's primary rays walk the top of the tree together (traverse_wide_tile.h); the launch then carries TILE_FRONT_WORDS more words of LDS per wave
     uint32_t wide_stack_words;      // k_shade<.., TRACE0 = 2>: 32-bit words of LDS stack per wave (the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES / 4)
+    // k_shade, bounce 0 of a pass of several frames (renderer option frame_bundle): a wave takes bundle_per_wave slots x bundle_w sub-frames — the rays of one pixel side by side, bundle_w
+    // = batch / ceil(batch / 8) rounded up of them (8 for passes of 8, 16, 32; 7 for 7: nine bundles in a wave and one idle lane) — instead of the 64 slots of one tile in one sub-frame;
+    // the launch is then one grid row of ceil(capacity x bundle_groups / bundle_per_wave) waves.  0 = off; 2 = and each bundle walks the tree as one (traverse_wide_bundle.h: bundle_w = 8 only)
+    int32_t frame_bundle;
+    uint32_t bundle_w, bundle_groups, bundle_per_wave, bundle_magic;      // bundle_magic = ceil(65536 / bundle_w): lane / bundle_w = lane * bundle_magic >> 16 for lane < 64
 };
 
 
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
     StreamStats wst{0, 0, 0, 0, 0, 0};
     struct WT { unsigned long long t0; uint32_t tag; StreamStats &st; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) {
         g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64();
-        g_wave_iters[4 * blockIdx.x] = st.iters; g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{wt0, wt_tag, wst};
+        g_wave_iters[4 * blockIdx.x] = st.iters | (st.drain_le8 << 16); g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{wt0, wt_tag, wst};
 #endif
     if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
     auto fetch = [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
@@ -351,11 +357,24 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     extern __shared__ uint32_t lds_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
+#ifdef MRT_WAVE_TIMES
+    const uint32_t wt_tag = rays_per_wave >> 24; rays_per_wave &= 0xFFFFFFu;
+    StreamStats wst{0, 0, 0, 0, 0, 0};
+    struct WT { unsigned long long t0; uint32_t tag; StreamStats &st; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) {
+        g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64();
+        g_wave_iters[4 * blockIdx.x] = st.iters | (st.drain_le8 << 16); g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{(unsigned long long)wall_clock64(), wt_tag, wst};
+    StreamStats *const wss = wt_tag == 0 ? &wst : nullptr;
+#else
+    StreamStats *const wss = nullptr;
+#endif
+    const bool strided = (even_waves >> 31) != 0u; even_waves &= 0x7FFFFFFFu;
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
     StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u};
-    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, OneRange{begin, min(n, begin + rays_per_wave)}, lds_dyn + 256u,
+    // stream_stride: the (n + rays_per_wave - 1) / rays_per_wave waves that have work take the queue's 64-ray batches round-robin instead of one contiguous range each
+    const BatchStride src = strided ? BatchStride{blockIdx.x * 64u, 64u * ((n + rays_per_wave - 1u) / rays_per_wave), n} : BatchStride{begin, 64u, min(n, begin + rays_per_wave)};
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, src, lds_dyn + 256u,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -365,7 +384,7 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
         [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
             if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
             else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
-        }, nullptr, NoPairs{}, ext);
+        }, wss, NoPairs{}, ext);
 }
 
 #include "two_level_passes.h"      // k_tl_top, k_tl_top_flat, k_tl_blas: the binned walk of two-level scenes
@@ -464,11 +483,18 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
     __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES];
     __shared__ unsigned long long blk_base;
     // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
-    const uint32_t sub = sample_primary ? blockIdx.y : 0u;
-    const uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    uint32_t sub = sample_primary ? blockIdx.y : 0u;
+    uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
+    bool in_batch = true;
+    if (TRACE0 && fp.frame_bundle) {          // (wave-uniform) thread -> (slot, sub-frame): the lanes 8 b .. 8 b + 7 of a wave are eight sub-frames of ONE slot
+        const uint32_t lane = threadIdx.x & 63u, wave = slot >> 6;
+        const uint32_t bi = (lane * fp.bundle_magic) >> 16, q = wave * fp.bundle_per_wave + bi;          // the lane's bundle: bi-th of its wave, q-th of the launch
+        slot = q / fp.bundle_groups; sub = (q - slot * fp.bundle_groups) * fp.bundle_w + (lane - bi * fp.bundle_w);
+        in_batch = bi < fp.bundle_per_wave && sub < (uint32_t)fp.batch;
+    }
     const uint32_t i = sub * capacity + slot;
     uint32_t n = count_in ? (uint32_t)*count_in : capacity;
-    bool active = slot < n;
+    bool active = slot < n && in_batch;
     int px_x = 0, px_y = 0;
     uint32_t spix = 0;                   // sample index (seed table, sample buffer, contribution planes)
     if (sample_primary) {
@@ -500,6 +526,33 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
         }
         TravHit h;
         const bool hit = traverse_wide_tile<true>(s, active, org, dir, t0, seed, h, stk, fp.wide_stack_words, front);
+        if (active) {
+            if (hint != nullptr && h.pk != guess) hint[pixel] = h.pk;
+            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
+        }
+    }
+    else if (TRACE0 == 2 && fp.frame_bundle == 2) {          // (wave-uniform) the eight sub-frames of a slot walk the tree as one bundle (traverse_wide_bundle.h): every lane takes part
+        extern __shared__ uint32_t shade_stk[];
+        uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
+        f3 dir = mk3(0.0f, 0.0f, 1.0f);
+        const f3 org = mk3(fp.cam_pos);                  // :214 — the same for every ray
+        uint32_t pixel = 0, guess = 0xFFFFFFFFu, seed = 0xFFFFFFFFu; float t0 = __builtin_inff();
+        if (active) {
+            f3 org_;
+            primary_ray(fp, seeds, spix, px_x, px_y, org_, dir);
+            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
+            if (hint != nullptr) {
+                pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
+                guess = hint[pixel];
+                if (guess < s.num_wpackets) {
+                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
+                    float t, U, V, ad;
+                    if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+                }
+            }
+        }
+        TravHit h;
+        const bool hit = traverse_wide_bundle<true>(s, active, org, dir, t0, seed, h, stk);
         if (active) {
             if (hint != nullptr && h.pk != guess) hint[pixel] = h.pk;
             if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
@@ -1497,7 +1550,13 @@ int Renderer::render(int n_frames) {                                   // Render
                 const bool pack = shade_pack && b > 0;          // bounces >= 1 read a queue half of whose rays missed: its hits are compacted in LDS and shaded on full waves (k_shade<.., PACK>)
                 // entries per packing workgroup: SHADE_PACK_RANGE when the queue is long, less when that would leave fewer than ~2048 workgroups (a one-frame pass, a tile group, a shard) — never less than two rounds' worth
                 fp.pack_range = (uint32_t)std::min<size_t>(SHADE_PACK_RANGE, std::max<size_t>(2 * SHADE_THREADS, (size_t)capacity * B / 2048 / SHADE_THREADS * SHADE_THREADS));
-                const dim3 gs = b == 0 ? dim3(grid_shade, B) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
+                fp.frame_bundle = (frame_bundle && !tile_walk && b == 0 && trace0_wide && B > 1) ? 1 : 0;
+                if (fp.frame_bundle) {
+                    fp.bundle_groups = ((uint32_t)B + 7u) / 8u; fp.bundle_w = ((uint32_t)B + fp.bundle_groups - 1u) / fp.bundle_groups;
+                    fp.bundle_per_wave = 64u / fp.bundle_w; fp.bundle_magic = (65536u + fp.bundle_w - 1u) / fp.bundle_w;
+                    if (frame_bundle >= 2 && !two_level && fp.bundle_w == 8u) fp.frame_bundle = 2;
+                }
+                const dim3 gs = b == 0 ? (fp.frame_bundle ? dim3(cdiv(cdiv((size_t)capacity * fp.bundle_groups, fp.bundle_per_wave) * 64, SHADE_THREADS), 1) : dim3(grid_shade, B)) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
                 auto shade_kernel = pack ? (materials ? k_shade<true, false, false, 0, false, true>
                                                 : pairs_pass ? k_shade<false, true, true, 0, true, true>
                                                 : planes_pass ? k_shade<false, true, true, 0, false, true>
@@ -1604,7 +1663,12 @@ int Renderer::render(int n_frames) {                                   // Render
                     const size_t slots_m = 2 * (size_t)capacity * B;
                     const uint32_t even = stream_even > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)stream_even / 100)) : 0u;     // stream_even: percent of the wave slots
                     const dim3 grid_s(even ? even : cdiv(slots_m, rpw_m));
-                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + 1024, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m, lit_b, even);
+#ifdef MRT_WAVE_TIMES
+                    const uint32_t rpw_m_arg = rpw_m | ((uint32_t)b << 24);
+#else
+                    const uint32_t rpw_m_arg = rpw_m;
+#endif
+                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + 1024, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m_arg, lit_b, even | (stream_stride ? 0x80000000u : 0u));
                     else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }

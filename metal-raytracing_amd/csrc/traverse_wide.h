@@ -449,7 +449,7 @@ struct StreamStats {
     uint32_t probe[3] = {0, 0, 0};          // = 2: pending triangles summed over lanes and iterations | lanes with two or more pending | iterations in which fewer than 16 lanes test a triangle
 #endif
 #ifdef MRT_WAVE_TIMES
-    uint32_t drain_iters = 0, drain_live = 0, maxdt = 0; unsigned long long prev = 0ull, drain_t0 = 0ull;
+    uint32_t drain_iters = 0, drain_live = 0, maxdt = 0, drain_le8 = 0; unsigned long long prev = 0ull, drain_t0 = 0ull;
 #endif
 };
 
@@ -458,6 +458,12 @@ struct StreamStats {
 struct OneRange {            // the static split: the wave owns one range
     uint32_t b, e; bool used = false;
     MRT_DEV bool operator()(uint32_t &ob, uint32_t &oe) { if (used) return false; used = true; ob = b; oe = e; return b < e; }
+};
+// The static split in 64-ray batches: `step` = 64 walks one contiguous range [next, limit) like OneRange; a larger step deals the queue's batches round-robin to the launch's
+// waves (renderer option stream_stride): neighbouring rays cost alike, so a contiguous range makes some waves several times longer than the average one.
+struct BatchStride {
+    uint32_t next, step, limit;
+    MRT_DEV bool operator()(uint32_t &ob, uint32_t &oe) { if (next >= limit) return false; ob = next; oe = min(limit, next + 64u); next += step; return true; }
 };
 // The dynamic split ("persistent waves"): every resident wave keeps pulling `chunk` rays from a shared counter until the queue is
 // empty, so all waves of a launch end within one chunk of each other instead of the last round of a static grid running on a
@@ -706,7 +712,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
 #ifdef MRT_WAVE_TIMES
         if (ss) {
-            if (draining) { ss->drain_iters++; ss->drain_live += (uint32_t)__popcll(__ballot(live)); }
+            if (draining) { const uint32_t nl_ = (uint32_t)__popcll(__ballot(live)); ss->drain_iters++; ss->drain_live += nl_; if (nl_ <= 8u) ss->drain_le8++; }
             const unsigned long long now_ = wall_clock64(); const uint32_t dt_ = (uint32_t)(now_ - ss->prev);
             if (ss->prev != 0ull && dt_ > ss->maxdt) ss->maxdt = dt_;
             ss->prev = now_; if (draining && ss->drain_t0 == 0ull) ss->drain_t0 = now_;

@@ -378,7 +378,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
-                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes"])
+                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes", "no_frame_bundle", "frame_bundle_passes_of_three", "frame_bundle_no_hint", "frame_bundle_walk", "frame_bundle_walk_passes_of_three", "frame_bundle_walk_no_hint", "stream_stride_static_split"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
@@ -409,6 +409,12 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend.startswith("packed_shade"):                  # k_shade of bounces 1, 2 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
         r.set_option("shade_pack", 1)          # (the default)
         if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 2)
+    if backend == "no_frame_bundle": r.set_option("frame_bundle", 0)          # shade(0): a wave = the 64 pixels of one tile in one sub-frame (round 4's form)
+    if backend.startswith("frame_bundle"):                  # shade(0) of a multi-frame pass: a wave takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 5 frames: three lanes of every eight idle
+        r.set_option("frame_bundle", 2 if "walk" in backend else 1)          # 1: the default; 2: and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h)
+        if backend.endswith("passes_of_three"): r.set_option("frame_batch", 3)
+        if backend.endswith("no_hint"): r.set_option("primary_hint", 0)
+    if backend == "stream_stride_static_split": r.set_option("persistent", 0); r.set_option("stream_stride", 1)      # the static split deals 64-ray batches round-robin to the waves (traverse_wide.h BatchStride)
     if backend == "unpacked_shade": r.set_option("shade_pack", 0)          # one queue entry per thread, hit or miss (round 4's form)
     if backend == "no_hit_lds_static_split": r.set_option("persistent", 0); r.set_option("hit_lds", 0)              # the static split without them (persistent_never runs it with them: the default)
     if backend in ("lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"):
@@ -483,6 +489,27 @@ def test_primary_tile_walk_at_ragged_sizes_and_other_scenes(mrt, orc, gpu_ctx, s
     r.set_option("tile_walk", 1)
     r.draw(3, wait=True); r.draw(2, wait=True)
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
+    assert_parity(r.accumulation(), ref)
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
+    r.close()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("scene_name,size,batch", [("dragon", (333, 187), 8), ("cornell", (64, 64), 12), ("cornell", (1000, 3), 5), ("garden", (257, 129), 8), ("dragon_hostile", (320, 180), 6), ("dragon4", (192, 108), 7)])
+def test_frame_bundle_at_ragged_sizes_batches_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size, batch, level):
+    """shade(0) with eight sub-frames of a slot side by side in a wave (renderer option frame_bundle): passes of more than eight frames (two groups per slot), of fewer
+    (idle lanes), partial tiles, the image's centre row and column (bundles whose directions change sign walk one ray per lane), the hostile stand-in and a two-level scene
+    (dragon x 4 as instances) must give the oracle's image and counts — with the one-ray-per-lane walk (level 1) and with the bundle walk (level 2, traverse_wide_bundle.h)."""
+    w, h = size
+    sc = mrt.SCENES[scene_name]((w, h))
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1} if scene_name == "dragon4" else None)
+    r.set_option("frame_bundle", level); r.set_option("frame_batch", batch)          # (level 2 on the two-level scene: the mapping alone — the bundle walk is for flattened scenes)
+    n = batch + 2
+    r.draw(batch, wait=True); r.draw(2, wait=True)
+    if scene_name == "dragon4":          # a two-level scene's rays are tested in object space: its oracle is the two-level one
+        o = orc.OracleRenderer(orc.OracleScene(mrt.flatten_scene(sc, share=True), sc.lights, instancing=True), w, h, seed=1, max_bounces=3, camera=sc.camera)
+        o.render(n); ref, cnt = o.accumulation(), o.counters()
+    else: ref, cnt = oracle_render(orc, mrt, sc, w, h, n)
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     r.close()

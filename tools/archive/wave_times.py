@@ -22,6 +22,7 @@ it = np.zeros(32768, np.uint32)
 lib.mrt_debug_wave_iters.restype = C.c_int
 assert lib.mrt_debug_wave_iters(it.ctypes.data_as(C.c_void_p)) == 0
 it = it.reshape(-1, 4).astype(np.int64)[t[:, 1] > 0]
+le8 = it[:, 0] >> 16; it[:, 0] &= 0xFFFF
 t = t[t[:, 1] > 0]
 t0 = t[:, 0].min(); s = (t[:, 0] - t0) / 100.0; e = (t[:, 1] - t0) / 100.0      # microseconds
 T = e.max()
@@ -34,6 +35,8 @@ for k in last:
     dur = (t[k, 1] - t[k, 0]) / 100.0
     nd = it[k, 1] & 0xFFF; maxdt = (it[k, 1] >> 12) / 100.0
     d0 = ((it[k, 3] - (t0 & 0xFFFFFFFF)) & 0xFFFFFFFF) / 100.0 if it[k, 3] else -1
-    print(f"   late wave: alive {dur:.0f} us, {it[k, 0]} iterations ({dur / max(it[k, 0], 1):.2f} us each), longest single iteration {maxdt:.1f} us, drain phase from {d0:.0f} us on: {nd} iterations with {it[k, 2] / max(nd, 1):.1f} live lanes on average")
+    print(f"   late wave: alive {dur:.0f} us, {it[k, 0]} iterations ({dur / max(it[k, 0], 1):.2f} us each), longest single iteration {maxdt:.1f} us, drain phase from {d0:.0f} us on: {nd} iterations with {it[k, 2] / max(nd, 1):.1f} live lanes on average, {le8[k]} of them with <= 8 live lanes")
 print(f"   all waves: {it[:, 0].mean():.0f} iterations on average, {1e0 * ((t[:, 1] - t[:, 0]) / 100.0).mean() / it[:, 0].mean():.2f} us per iteration")
 print(f"mean residency {np.mean(e - s) / T:.3f} of the launch time (1.0 = every wave alive from start to end)")
+nd_all = it[:, 1] & 0xFFF
+print(f"   drain iterations per wave: mean {nd_all.mean():.1f}, p50 {np.percentile(nd_all, 50):.0f}, p99 {np.percentile(nd_all, 99):.0f}, max {nd_all.max()}; with <= 8 live lanes: mean {le8.mean():.1f}, p99 {np.percentile(le8, 99):.0f}, max {le8.max()}")
