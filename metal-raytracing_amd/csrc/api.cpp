@@ -500,7 +500,8 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     else if (k == "lds_top") { REQUIRE(value >= 0 && value <= 4 && value == (int)value, "lds_top must be 0 (off), 1 (levels 0-1 per wave), 2 (levels 0-2 per 256-thread workgroup), 3 (levels 0-1 per 256-thread workgroup) or 4 (256-thread workgroups, nothing staged)"); r->r.lds_top = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
-    else if (k == "stream_stride") r->r.stream_stride = value != 0;
+    else if (k == "stream_stride") { REQUIRE(value >= 0 && value <= 2, "stream_stride must be 0 (contiguous ranges), 1 (round-robin batches) or 2 (round-robin for a shard's launches)"); r->r.stream_stride = (int)value; }
+    else if (k == "halton_table") r->r.halton_table = value != 0;
     else if (k == "frame_bundle") { REQUIRE(value >= 0 && value <= 2, "frame_bundle must be 0 (off), 1 (eight sub-frames of a slot side by side in a wave) or 2 (and walking the tree as one bundle)"); r->r.frame_bundle = (int)value; }
     else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
     else if (k == "primary_hint") r->r.primary_hint = value != 0;
@@ -532,6 +533,7 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     else if (k == "xcd_counters") *value = r->r.xcd_counters;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "stream_stride") *value = r->r.stream_stride;
+    else if (k == "halton_table") *value = r->r.halton_table;
     else if (k == "frame_bundle") *value = r->r.frame_bundle;
     else if (k == "stream_even") *value = r->r.stream_even;
     else if (k == "primary_hint") *value = r->r.primary_hint ? 1 : 0;

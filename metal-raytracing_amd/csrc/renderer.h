@@ -51,6 +51,10 @@ struct Renderer {
     uint64_t frames_rendered = 0;
 
     DevBuf<uint32_t> seeds;              // randomTexture (R32Uint, :246-274)
+    DevBuf<float> halton_tab;            // bounce 0's Halton values by index, dimensions 1 .. 6 (renderer.hip FrameParams::halton_tab), for the window [halton_w0, halton_w0 + 2^20 + 2^16); allocated by the first bundled pass
+    uint32_t halton_w0 = 0;
+    int halton_table = 1;                // renderer option: bundled passes read bounce 0's Halton values from the table
+    int ensure_halton_table(hipStream_t st, uint32_t sample_index, uint32_t batch);
     DevBuf<uint32_t> hint;               // per pixel: the packet its primary ray hit last (k_trace_primary tests it first); 0xFFFFFFFF = none
     bool primary_hint = true;
     bool throughput_chain = true;        // bounce rays carry the resource slots of their path instead of a throughput record (renderer.hip FrameParams::chain)
@@ -89,7 +93,7 @@ struct Renderer {
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     int frame_bundle = 1;                // bounce 0 of a multi-frame pass: 1 = a wave of k_shade<.., TRACE0> takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 2 = and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h; flattened scenes)
-    int stream_stride = 0;               // the static split deals 64-ray batches round-robin to the waves (BatchStride) instead of one contiguous range each
+    int stream_stride = 2;               // the static split deals 64-ray batches round-robin to the waves (BatchStride) instead of one contiguous range each: 0 never, 1 always, 2 = a shard's launches (with one round of waves)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
     int tl_pair_cap = 0;                 // test aid: > 0 bounds the pair queue (pushes beyond it walk their instance in place); 0 = one pair per virtual ray
     int tl_pairs = 1;                    // two-level scenes: bounce / shadow rays as TLAS pass + BLAS pass over (ray, instance) pairs (k_tl_top / k_tl_blas) instead of one loop over both levels; 0 = the one-loop walk

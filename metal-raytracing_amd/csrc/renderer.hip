@@ -67,7 +67,22 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // the launch is then one grid row of ceil(capacity x bundle_groups / bundle_per_wave) waves.  0 = off; 2 = and each bundle walks the tree as one (traverse_wide_bundle.h: bundle_w = 8 only)
     int32_t frame_bundle;
     uint32_t bundle_w, bundle_groups, bundle_per_wave, bundle_magic;      // bundle_magic = ceil(65536 / bundle_w): lane / bundle_w = lane * bundle_magic >> 16 for lane < 64
+    // Halton values of bounce 0 from a table (Renderer::halton_tab): halton_tab[(d - 1) * halton_n + (i - halton_w0)] = halton_dev(i, d) for the dimensions d = 1 .. 6 of the pixel jitter's
+    // second component, the light pick, the area light's point and the first hemisphere sample (Raytracing.metal:203, :272, :284-285, :384-385), filled by halton_dev itself.  The
+    // recurrence is ~18 % of the VALU cycles of k_shade<.., TRACE0> (up to 13 digits per value, a quarter-rate 32-bit multiply per pair of digits); a bundled wave reads the values
+    // of a pixel's sub-frames — consecutive indices — from one or two cache lines instead.  nullptr (passes of one frame, narrow bundles, an index outside the window): the recurrence.
+    const float *halton_tab; uint32_t halton_w0, halton_n;
 };
+constexpr uint32_t HALTON_TAB_DIMS = 6, HALTON_TAB_SPAN = (1u << 20) + (1u << 16);      // seed offsets are below 2^20 (Renderer.swift:259): the window serves 2^16 frames before it moves
+MRT_DEV float halton_b0(const FrameParams &fp, int idx, int d /* 1 .. 6 */) {
+    const uint32_t j = (uint32_t)idx - fp.halton_w0;
+    if (fp.halton_tab != nullptr && j < fp.halton_n) return fp.halton_tab[(size_t)(d - 1) * fp.halton_n + j];
+    return halton_dev(idx, d);
+}
+__global__ void k_halton_table(float *__restrict__ tab, uint32_t w0, uint32_t n) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) tab[(size_t)blockIdx.y * n + j] = halton_dev((int)(w0 + j), (int)blockIdx.y + 1);
+}
 
 
 // local slot -> pixel: one wave = one 8x8 tile (Renderer.swift:295-300), tiles dealt round-robin to shards
@@ -100,7 +115,7 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
     uint32_t offset = q2load(&seeds[sample_index]);                      // :175 (+ sub-frame index)
     int idx = (int)(offset + fp.sampleIndex);
     float r0, r1;                                                        // :202-203
-    r0 = halton_dev(idx, 0); r1 = halton_dev(idx, 1);
+    r0 = halton_dev(idx, 0); r1 = halton_b0(fp, idx, 1);
     float px = (float)x + r0, py = (float)y + r1;                        // :204
     float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
     uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
@@ -308,7 +323,7 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
         for (uint32_t i = threadIdx.x; i < top_n * WNODE_STRIDE; i += 64u * WAVES) dst[i] = s.wnodes[i];
         __syncthreads();
     }
-    uint32_t *const mine = lds_dyn + (TOP ? top_n * WNODE_STRIDE * 4u : 0u) + wv * ((HIT ? 256u : 0u) + stack_words);
+    uint32_t *const mine = lds_dyn + (TOP ? top_n * WNODE_STRIDE * 4u : 0u) + wv * ((HIT ? HIT_LDS_WORDS : 0u) + stack_words);
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
     if ((blockIdx.x * WAVES + wv) * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once (after the workgroup's barrier)
@@ -322,8 +337,9 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
             if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
             else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
         };
-    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n};
-    traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? 256u : 0u), fetch, emit, nullptr, NoPairs{}, ext);
+    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n, reinterpret_cast<const uint8_t *>(mine + 256u)};
+    if (StreamExt<HIT, TOP>::nh_lut) nh_lut_fill(mine + 256u);
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? HIT_LDS_WORDS : 0u), fetch, emit, nullptr, NoPairs{}, ext);
 }
 
 // The pulling launch of flattened scenes with the triangle tests pooled across the lanes of a wave (traverse_wide_pool.h; renderer option pool).  Shadow planes only.
@@ -371,10 +387,11 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u};
+    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u, reinterpret_cast<const uint8_t *>(lds_dyn + 256u)};
+    if (StreamExt<true, false>::nh_lut) nh_lut_fill(lds_dyn + 256u);
     // stream_stride: the (n + rays_per_wave - 1) / rays_per_wave waves that have work take the queue's 64-ray batches round-robin instead of one contiguous range each
     const BatchStride src = strided ? BatchStride{blockIdx.x * 64u, 64u * ((n + rays_per_wave - 1u) / rays_per_wave), n} : BatchStride{begin, 64u, min(n, begin + rays_per_wave)};
-    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, src, lds_dyn + 256u,
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, src, lds_dyn + HIT_LDS_WORDS,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -755,13 +772,13 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
             }
         }
         if (diffuse) {
-        float ls = halton_dev(idx, dim0 + 0);               // :272
+        float ls = TRACE0 ? halton_b0(fp, idx, 2) : halton_dev(idx, dim0 + 0);               // :272 (TRACE0: bounce 0 — dimensions 2 .. 6, from the table when there is one)
         int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
         const LightDev L = s.lights[li];
         int ltype = __float_as_int(L.position.w);
         if (ltype == MRTLightTypeAreaLight) {                            // :281-290, :94-128
-            float ax = halton_dev(idx, dim0 + 1) * 2.0f - 1.0f;
-            float ay = halton_dev(idx, dim0 + 2) * 2.0f - 1.0f;
+            float ax = (TRACE0 ? halton_b0(fp, idx, 3) : halton_dev(idx, dim0 + 1)) * 2.0f - 1.0f;
+            float ay = (TRACE0 ? halton_b0(fp, idx, 4) : halton_dev(idx, dim0 + 2)) * 2.0f - 1.0f;
             f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
             ldir = sp - P;
             ldist = length3(ldir);
@@ -794,7 +811,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
         want_shadow = length3(lcol) > 0.0001f;                           // :341
         want_next = fp.bounce + 1 < fp.max_bounces;
         if (want_next) {
-            float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);   // :384-385
+            float hx = TRACE0 ? halton_b0(fp, idx, 5) : halton_dev(idx, dim0 + 3), hy = TRACE0 ? halton_b0(fp, idx, 6) : halton_dev(idx, dim0 + 4);   // :384-385
             ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
         }
         }
@@ -1161,6 +1178,20 @@ int read_wave_iters(uint32_t *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(
 #endif
 
 // ====================================================================== Renderer (host)
+// The table of bounce 0's Halton values (FrameParams::halton_tab) for the indices [w0, w0 + HALTON_TAB_SPAN): a pass needs offset + sampleIndex + sub-frame for offsets below 2^20.
+// Filled on `st` (the pass's stream, ahead of its shade(0)) when the window has to move: every 2^16 frames, or when the frame index went back (resize, reset).
+int Renderer::ensure_halton_table(hipStream_t st, uint32_t sample_index, uint32_t batch) {
+    const bool fits = halton_tab.p != nullptr && sample_index >= halton_w0 && (uint64_t)sample_index + batch + (1u << 20) <= (uint64_t)halton_w0 + HALTON_TAB_SPAN;
+    if (fits) return MRT_OK;
+    MRT_HIP(hipDeviceSynchronize());            // passes in flight on other streams may still read the old window: they finish first (rare: once per 65 536 frames)
+    if (!halton_tab.p) MRT_HIP(halton_tab.alloc((size_t)HALTON_TAB_DIMS * HALTON_TAB_SPAN));
+    halton_w0 = sample_index;
+    hipLaunchKernelGGL(k_halton_table, dim3(cdiv(HALTON_TAB_SPAN, 256), HALTON_TAB_DIMS), dim3(256), 0, st, halton_tab.p, halton_w0, HALTON_TAB_SPAN);
+    MRT_HIP(hipGetLastError());
+    MRT_HIP(hipStreamSynchronize(st));          // (rare: once per 65 536 frames) every later pass, on any stream, sees the new window
+    return MRT_OK;
+}
+
 int Renderer::init(hipStream_t st, const DeviceScene *sc, int w, int h, uint32_t seed_, int max_bounces_) {
     stream = st; scene = sc; seed = seed_; max_bounces = max_bounces_;
     MRT_HIP(hipEventCreate(&ev_begin)); MRT_HIP(hipEventCreate(&ev_end));
@@ -1556,6 +1587,11 @@ int Renderer::render(int n_frames) {                                   // Render
                     fp.bundle_per_wave = 64u / fp.bundle_w; fp.bundle_magic = (65536u + fp.bundle_w - 1u) / fp.bundle_w;
                     if (frame_bundle >= 2 && !two_level && fp.bundle_w == 8u) fp.frame_bundle = 2;
                 }
+                fp.halton_tab = nullptr; fp.halton_w0 = 0; fp.halton_n = 0;
+                if (b == 0 && fp.frame_bundle && fp.bundle_w >= 4u && halton_table) {          // a wave reads bundle_w consecutive values per load: the table pays from four on
+                    if (int rc = ensure_halton_table(st, fp.sampleIndex, (uint32_t)B)) return rc;
+                    fp.halton_tab = halton_tab.p; fp.halton_w0 = halton_w0; fp.halton_n = HALTON_TAB_SPAN;
+                }
                 const dim3 gs = b == 0 ? (fp.frame_bundle ? dim3(cdiv(cdiv((size_t)capacity * fp.bundle_groups, fp.bundle_per_wave) * 64, SHADE_THREADS), 1) : dim3(grid_shade, B)) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
                 auto shade_kernel = pack ? (materials ? k_shade<true, false, false, 0, false, true>
                                                 : pairs_pass ? k_shade<false, true, true, 0, true, true>
@@ -1635,7 +1671,7 @@ int Renderer::render(int n_frames) {                                   // Render
                         const bool TOPX = lds_top >= 1 && lds_top <= 3;
                         const uint32_t top_n = !TOPX ? 0u : lds_top == 2 ? scene->wide_level_end[2] : scene->wide_level_end[1];
                         const uint32_t stack_words = (uint32_t)(stack_bytes / 4);
-                        const size_t lds_x = (size_t)top_n * WNODE_STRIDE * 16 + (size_t)WV * ((hit_lds ? 1024 : 0) + stack_bytes);
+                        const size_t lds_x = (size_t)top_n * WNODE_STRIDE * 16 + (size_t)WV * ((hit_lds ? HIT_LDS_WORDS * 4 : 0) + stack_bytes);
                         using KX = void (*)(SceneView, const float4 *, const float4 *, float4 *, const float4 *, const float4 *, const unsigned long long *, uint32_t *, uint32_t, uint8_t *, uint32_t, uint32_t, uint32_t);
                         const KX kx = WV == 4 ? (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, true, true> : (KX)k_trace_mixed_wide_persist_x<4, true, false>) : (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, false, true> : (KX)k_trace_mixed_wide_persist_x<4, false, false>))
                                               : (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<1, true, true> : (KX)k_trace_mixed_wide_persist_x<1, true, false>) : (KX)k_trace_mixed_wide_persist_x<1, false, true>);
@@ -1661,14 +1697,20 @@ int Renderer::render(int n_frames) {                                   // Render
                 }
                 else if (on_wide) {
                     const size_t slots_m = 2 * (size_t)capacity * B;
-                    const uint32_t even = stream_even > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)stream_even / 100)) : 0u;     // stream_even: percent of the wave slots
+                    // a shard's launches (a rank of eight over the driver's 20 frames: three passes of its 1/8 of the tiles in flight) do better with ONE round of waves that take the queue's
+                    // 64-ray batches round-robin — every rank of eight timed: 2.00 against 2.21 ms on average, the slowest 2.13-2.18 against 2.46-2.50 (profiles/r05_shard_stride.txt); a whole
+                    // image's one-frame launches do not (one frame alone 1.38 = 1.38 ms, three in flight 0.775 against 0.765)
+                    const bool shard_auto = stream_stride == 2 && stream_even == 200 && this->shard_world > 1 && G == 1;
+                    const bool strided = stream_stride == 1 || shard_auto;
+                    const int even_pct = shard_auto ? 100 : stream_even;
+                    const uint32_t even = even_pct > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)even_pct / 100)) : 0u;     // stream_even: percent of the wave slots
                     const dim3 grid_s(even ? even : cdiv(slots_m, rpw_m));
 #ifdef MRT_WAVE_TIMES
                     const uint32_t rpw_m_arg = rpw_m | ((uint32_t)b << 24);
 #else
                     const uint32_t rpw_m_arg = rpw_m;
 #endif
-                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + 1024, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m_arg, lit_b, even | (stream_stride ? 0x80000000u : 0u));
+                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + HIT_LDS_WORDS * 4, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m_arg, lit_b, even | (strided ? 0x80000000u : 0u));
                     else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }

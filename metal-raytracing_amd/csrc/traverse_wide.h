@@ -72,10 +72,42 @@ MRT_DEV void wstack_pop(const uint32_t *stack, uint32_t sp, uint32_t lane, uint3
 // The comparison is strict because both ends clamp to the same value when the box lies behind the origin (far = 0 = near) or beyond the
 // limit (near >= 1 = far); for a box that the exact test accepts the widened far side is strictly beyond the near side.  Per node this costs
 // v_med3 + v_mul + v_rcp + 3 v_mul and saves 8 x (v_max + v_min).
-template <bool SCALED = false>
+// NHLUT (the stream kernels with LDS extras, MRT_NH_LUT): the per-child `bit (slot ^ octant) of the internal children` — a bit-field extract, an xor and a shift-or per child,
+// two of them half-rate — becomes one `or` with a literal per child (raw hit bits by slot) and, per node, two byte reads of a 128-byte table in LDS:
+// nh_lut[o << 4 | n] = the bits of nibble n moved to (position ^ o); the high nibble's bits 4 + j go to (4 ^ (o & 4)) + (j ^ (o & 3)) — the same table at octant o ^ 4.
+#ifndef MRT_NH_LUT
+#define MRT_NH_LUT 0
+#endif
+constexpr uint32_t NH_LUT_WORDS = 32;
+MRT_DEV uint32_t lds_u8(const uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)p);
+#else
+    return *p;
+#endif
+}
+// the wave writes its table: lane l < 32 holds entries 4 l .. 4 l + 3 (octant l >> 2, nibbles 4 (l & 3) ..)
+MRT_DEV void nh_lut_fill(uint32_t *lut_words) {
+    const uint32_t l = threadIdx.x & 63u;
+    if (l < NH_LUT_WORDS) {
+        const uint32_t o = l >> 2; uint32_t w = 0;
+        for (uint32_t e = 0; e < 4u; e++) {
+            const uint32_t n = 4u * (l & 3u) + e; uint32_t r = 0;
+            for (uint32_t j = 0; j < 4u; j++) if ((n >> j) & 1u) r |= 1u << (j ^ o);
+            w |= r << (8u * e);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(lut_words + l)) = w;      // (a ds_write, ordered with the ds_reads of the table)
+#else
+        lut_words[l] = w;
+#endif
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <bool SCALED = false, bool NHLUT = false>
 MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4, const f3 o,
                             float ix, float iy, float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
-                            const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
+                            const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits, const uint8_t *nh_lut = nullptr) {
 #if MRT_WIDE6
     {   // six children in 64 bytes (scene_device.h): physical child j carries its slot and its triangle count; its packets follow those of the children before it
         const uint32_t ew = __float_as_uint(n0.w);
@@ -155,9 +187,13 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
         }
         if (SCALED ? tn < tf : tn <= tf) {
             // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
-            nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
+            if (NHLUT) nh |= 1u << i; else nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
             th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
         }
+    }
+    if (NHLUT) {
+        const uint32_t x = nh & imask, o4 = oct << 4;
+        nh = lds_u8(nh_lut + (o4 | (x & 15u))) | lds_u8(nh_lut + ((o4 | (x >> 4)) ^ 64u));
     }
     node_hits = nh; tri_hits = th;
 #endif
@@ -588,13 +624,15 @@ MRT_DEV float4 lds_f4(const float4 *p) {
     return *p;
 #endif
 }
-struct NoExt { static constexpr bool hit_lds = false, top_lds = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; };      // (members never read: every use sits behind one of the two flags)
+struct NoExt { static constexpr bool hit_lds = false, top_lds = false, nh_lut = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; const uint8_t *nh = nullptr; };      // (members never read: every use sits behind one of the two flags)
 template <bool HIT, bool TOP> struct StreamExt {
-    static constexpr bool hit_lds = HIT, top_lds = TOP;
-    float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far
+    static constexpr bool hit_lds = HIT, top_lds = TOP, nh_lut = HIT && MRT_NH_LUT != 0;
+    float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far; MRT_NH_LUT: followed by the wave's 128-byte table (wide_node_test<.., NHLUT>)
     const float4 *top;      // TOP: wnodes[0 .. top_n) in LDS
     uint32_t top_n;
+    const uint8_t *nh = nullptr;
 };
+constexpr uint32_t HIT_LDS_WORDS = 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u);      // per wave, in front of its stack
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -925,7 +963,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
-            wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
+            wide_node_test<MRT_WIDE_SCALED != 0, Ext::nh_lut>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits, ext.nh);
             uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16;
             const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit

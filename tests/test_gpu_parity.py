@@ -378,7 +378,7 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
-                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes", "no_frame_bundle", "frame_bundle_passes_of_three", "frame_bundle_no_hint", "frame_bundle_walk", "frame_bundle_walk_passes_of_three", "frame_bundle_walk_no_hint", "stream_stride_static_split"])
+                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes", "no_frame_bundle", "no_halton_table", "frame_bundle_passes_of_three", "frame_bundle_no_hint", "frame_bundle_walk", "frame_bundle_walk_passes_of_three", "frame_bundle_walk_no_hint", "stream_stride_static_split"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
@@ -409,6 +409,7 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend.startswith("packed_shade"):                  # k_shade of bounces 1, 2 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
         r.set_option("shade_pack", 1)          # (the default)
         if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 2)
+    if backend == "no_halton_table": r.set_option("halton_table", 0)          # bounce 0's Halton values by the recurrence (default: a bundled pass reads them from the renderer's table, FrameParams::halton_tab)
     if backend == "no_frame_bundle": r.set_option("frame_bundle", 0)          # shade(0): a wave = the 64 pixels of one tile in one sub-frame (round 4's form)
     if backend.startswith("frame_bundle"):                  # shade(0) of a multi-frame pass: a wave takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 5 frames: three lanes of every eight idle
         r.set_option("frame_bundle", 2 if "walk" in backend else 1)          # 1: the default; 2: and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h)
@@ -513,6 +514,25 @@ def test_frame_bundle_at_ragged_sizes_batches_and_other_scenes(mrt, orc, gpu_ctx
     assert_parity(r.accumulation(), ref)
     assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
     r.close()
+
+
+def test_halton_table_window_moves_with_the_frame_index(mrt, gpu_ctx):
+    """A bundled pass reads bounce 0's Halton values from a table over a window of indices (renderer.hip FrameParams::halton_tab, filled by the recurrence itself).  When the frame
+    index leaves the window — 65 536 frames on, or back after a reset — the table is refilled: the image and the ray counts must be those of the recurrence throughout."""
+    w, h = 160, 96
+    sc = mrt.DragonScene((w, h))
+    out = []
+    for tab in (1, 0):
+        r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+        r.set_option("halton_table", tab); r.set_option("frame_batch", 8)
+        r.draw(8, wait=True); imgs = [r.accumulation().copy()]
+        r.frameIndex = 65532; r.draw(8, wait=True); imgs.append(r.accumulation().copy())          # 65532 + 8 > 65536: the window moves
+        r.frameIndex = 3; r.draw(5, wait=True); imgs.append(r.accumulation().copy())               # and back
+        r.frameIndex = (1 << 31) - 4; r.draw(8, wait=True); imgs.append(r.accumulation().copy())   # indices wrap past 2^31 (halton = 0 there): outside any window
+        out.append((imgs, (r.stats.closest_rays, r.stats.shadow_rays)))
+        r.close()
+    assert out[0][1] == out[1][1]
+    for a, b in zip(out[0][0], out[1][0]): assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_frame_batch_can_change_between_draws(mrt, orc, gpu_ctx):
