@@ -199,6 +199,13 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value);
  * .transformationMatrix, Renderer.swift:193-200); takes effect at the next mrt_scene_commit, which rebuilds the
  * world-space BVH on the device (the reference would refit/rebuild its instance AS, Renderer.swift:205-213).   */
 int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const float *transform_colmajor_4x4);
+/* Deforming geometry: new object-space positions and normals for the vertices of one mesh (same count, same submesh indices: the topology is kept).  The library copies
+ * the arrays.  Takes effect at the next mrt_scene_commit.  When nothing else changed since the last commit, a flattened scene with the 8-wide layout REFITS its tree — every
+ * triangle packet rewritten, the boxes recomputed bottom-up, the tree's shape (and MRTSceneStats.sah_cost) as built — in a fraction of a build's time; the image is the one a
+ * fresh build of the deformed scene gives (the closest hit does not depend on the tree).  Two-level scenes, scenes on the rope layout and scene option refit = 0 build again.
+ * The reference builds its acceleration structures once (Renderer.swift:184-214) and never deforms a mesh; this is the counterpart of Metal's refit of a primitive AS.   */
+int mrt_scene_update_mesh(MRTScene scene, int32_t mesh_id, const float *positions, size_t pos_stride_bytes,
+                          const float *normals, size_t nrm_stride_bytes, size_t vertex_count);
 int mrt_scene_stats(MRTScene scene, MRTSceneStats *out);
 /* 4x3 packed instance transform as the reference stores it (Renderer.swift:193-203).          */
 int mrt_scene_instance_transform(MRTScene scene, int32_t mesh_id, float out_colmajor_4x3[12]);
@@ -342,6 +349,8 @@ int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int
 int mrt_debug_wide_histogram(MRTScene scene, uint32_t *out12);
 /* Diagnostics: the 8-wide nodes of a committed scene as they lie in device memory (80 bytes each); out == NULL: only the count.                      */
 int mrt_debug_read_wnodes(MRTScene scene, void *out, size_t nbytes, uint64_t *num_nodes);
+/* Diagnostics: commits of this scene served by a refit (mrt_scene_update_mesh) since its last build.   */
+int mrt_debug_scene_refits(MRTScene scene, uint32_t *out);
 /* Diagnostics: host wall time (ms) of the last mrt_scene_commit of a flattened scene by phase: {upload staging, device allocations + upload enqueue,
  * topology (flatten .. refit, with its read-backs), 8-wide emit, rope emit, validation}.                                                              */
 int mrt_debug_commit_times(MRTScene scene, double *out6);

@@ -134,6 +134,8 @@ SIGNATURES = {
     "mrt_scene_commit": (C.c_int, [_P]),
     "mrt_scene_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "mrt_scene_set_instance_transform": (C.c_int, [_P, _I32, _P]),
+    "mrt_scene_update_mesh": (C.c_int, [_P, _I32, _P, _SZ, _P, _SZ, _SZ]),
+    "mrt_debug_scene_refits": (C.c_int, [_P, C.POINTER(_U32)]),
     "mrt_scene_stats": (C.c_int, [_P, C.POINTER(SceneStats)]),
     "mrt_scene_instance_transform": (C.c_int, [_P, _I32, _PF]),
     "mrt_scene_intersect_closest": (C.c_int, [_P, _P, _SZ, _P]),

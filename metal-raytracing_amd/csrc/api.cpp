@@ -104,7 +104,7 @@ int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride
     memcpy(m.xf, xf, 64);
     m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;              // matrix4x4_drop_last_row (Utilities.swift:92-101)
     scene->meshes.push_back(std::move(m));
-    scene->committed = false; scene->only_transforms_changed = false;
+    scene->committed = false; scene->only_transforms_changed = false; scene->only_vertices_changed = false;
     if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
     return MRT_OK;
     MRT_CATCH
@@ -121,7 +121,7 @@ int mrt_scene_add_instance(MRTScene scene, int32_t source_mesh_id, const float *
     m.xf[3] = m.xf[7] = m.xf[11] = 0.0f; m.xf[15] = 1.0f;
     const int geometry_of = m.source;
     scene->meshes.push_back(std::move(m));
-    scene->committed = false; scene->only_transforms_changed = false;
+    scene->committed = false; scene->only_transforms_changed = false; scene->only_vertices_changed = false;
     if (mesh_id) *mesh_id = (int32_t)scene->meshes.size() - 1;
     if (!scene->opt.instancing) {           // a flattened scene stages a copy of the source's geometry per instance: the pinned area grows here (see mrt_mesh_add_submesh)
         const mrt::HostMesh &g = scene->meshes[geometry_of];
@@ -145,7 +145,7 @@ int mrt_mesh_add_submesh(MRTScene scene, int32_t mesh_id, const uint32_t *indice
     for (size_t i = 0; i < ntris * 3; i++) REQUIRE(indices[i] < nv, "mrt_mesh_add_submesh: vertex index out of range");
     m.sub_indices.emplace_back(indices, indices + ntris * 3);
     m.sub_materials.push_back(*material);
-    scene->committed = false; scene->only_transforms_changed = false;
+    scene->committed = false; scene->only_transforms_changed = false; scene->only_vertices_changed = false;
     if (geometry_id) *geometry_id = (int32_t)m.sub_indices.size() - 1;
     // the pinned staging area the commit uploads from grows HERE, as the geometry is handed over (by doubling: a handful of allocations whatever the mesh count), not inside
     // mrt_scene_commit: pinning 25 MB is ~1.1 ms, a fifth of DragonScene's commit.  Flattened scenes stage every instance's copy; a failure here is not an error (the commit retries).
@@ -197,9 +197,10 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "fat_shade") { REQUIRE(value == 0 || value == 1, "fat_shade must be 0 or 1"); scene->opt.fat_shade = (int)value; }
     else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
     else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
+    else if (k == "refit") scene->opt.refit = value != 0;
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
-    scene->committed = false; scene->only_transforms_changed = false;
+    scene->committed = false; scene->only_transforms_changed = false; scene->only_vertices_changed = false;
     return MRT_OK;
     MRT_CATCH
 }
@@ -209,11 +210,33 @@ int mrt_scene_commit(MRTScene scene) {
     int rc = bind_device(scene->ctx); if (rc) return rc;
     if (scene->only_transforms_changed && scene->opt.instancing && scene->dev.num_inst == scene->meshes.size())
         rc = mrt::update_tlas(scene->meshes, scene->ctx->stream, scene->dev);         // instance rows + TLAS; the BLASes stay (the refit of an animated scene)
-    else rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev, scene->only_transforms_changed && !scene->opt.instancing);
+    else rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev, scene->only_transforms_changed && !scene->opt.instancing, scene->only_vertices_changed && !scene->opt.instancing);
     if (rc) return rc;
-    scene->only_transforms_changed = false;
+    scene->only_transforms_changed = false; scene->only_vertices_changed = false;
+    for (auto &m : scene->meshes) m.dirty = false;
     rc = mrt::upload_lights(scene->lights.data(), (int)scene->lights.size(), scene->ctx->stream, scene->dev); if (rc) return rc;
     scene->committed = true;
+    return MRT_OK;
+    MRT_CATCH
+}
+int mrt_scene_update_mesh(MRTScene scene, int32_t mesh_id, const float *positions, size_t pos_stride, const float *normals, size_t nrm_stride, size_t nverts) {
+    MRT_TRY
+    REQUIRE(scene && positions && normals, "mrt_scene_update_mesh: bad argument");
+    REQUIRE(mesh_id >= 0 && (size_t)mesh_id < scene->meshes.size(), "mrt_scene_update_mesh: mesh_id out of range");
+    REQUIRE(pos_stride >= 12 && nrm_stride >= 12 && pos_stride % 4 == 0 && nrm_stride % 4 == 0, "mrt_scene_update_mesh: strides must be multiples of 4 and >= 12");
+    mrt::HostMesh &m = scene->meshes[(size_t)mesh_id];
+    REQUIRE(m.source < 0, "mrt_scene_update_mesh: an instance has no vertices of its own (update its source mesh)");
+    REQUIRE(nverts * 3 == m.positions.size(), "mrt_scene_update_mesh: the vertex count must stay the same (the topology is kept)");
+    for (size_t i = 0; i < nverts; i++) {
+        const float *p = (const float *)((const char *)positions + i * pos_stride);
+        const float *n = (const float *)((const char *)normals + i * nrm_stride);
+        for (int k = 0; k < 3; k++) { m.positions[i * 3 + k] = p[k]; m.normals[i * 3 + k] = n[k]; }
+    }
+    // a committed scene in which nothing else changes until the next commit keeps its tree: that commit refits (flattened scenes with the 8-wide layout; others build again)
+    m.dirty = true;
+    if (scene->committed) scene->only_vertices_changed = true;                         // the first change since the commit
+    else if (!scene->only_vertices_changed) scene->only_transforms_changed = false;    // something else changed already (a transform, a mesh, an option): the next commit builds
+    scene->committed = false;
     return MRT_OK;
     MRT_CATCH
 }
@@ -227,6 +250,7 @@ int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const floa
     // flattened scene: the world-space BVH is rebuilt by the next mrt_scene_commit (22 ms for 885 K triangles);
     // two-level scene: the next commit rewrites the instance rows and rebuilds the TLAS only
     if (scene->committed) scene->only_transforms_changed = true;
+    if (scene->only_vertices_changed) { scene->only_vertices_changed = false; scene->only_transforms_changed = false; }      // vertices AND transforms changed: a full build
     scene->committed = false;
     return MRT_OK;
     MRT_CATCH
@@ -670,6 +694,11 @@ int mrt_debug_read_wnodes(MRTScene scene, void *out, size_t nbytes, uint64_t *nu
     MRT_CATCH
 }
 // host wall time of the last commit of a flattened scene by phase (ms): staging, device allocations, topology, 8-wide emit, rope emit, validation
+int mrt_debug_scene_refits(MRTScene scene, uint32_t *out) {
+    REQUIRE(scene && out, "mrt_debug_scene_refits: bad argument");
+    *out = scene->dev.refits;
+    return MRT_OK;
+}
 int mrt_debug_commit_times(MRTScene scene, double *out6) {
     REQUIRE(scene && out6, "mrt_debug_commit_times: bad argument");
     for (int k = 0; k < 6; k++) out6[k] = scene->dev.commit_ms[k];

@@ -15,6 +15,7 @@ struct MRTScene_ {
     mrt::BuildOptions opt;
     mrt::DeviceScene dev;
     bool committed = false;
+    bool only_vertices_changed = false;     // since the last commit: nothing but mrt_scene_update_mesh calls — a flattened scene with the 8-wide layout refits its tree (scene option refit)
     bool only_transforms_changed = false;   // since the last commit: a two-level scene rebuilds its TLAS only, a flattened one rebuilds from the geometry already on the device
     size_t stage_need = 0;                  // bytes the upload staging of the meshes added so far will take (mrt_mesh_add_submesh grows the pinned area)
 };

@@ -926,6 +926,95 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
 #endif
 }
 
+// ------------------------------------------------------------------ refit of the 8-wide layout (deformed geometry, same topology: mrt_scene_update_mesh + commit)
+// The reference rebuilds nothing per frame (Renderer.swift:184-214 runs once); Metal's refit of a primitive acceleration structure is what this stands for.
+// The tree keeps its shape: every packet takes its triangle's new vertices (k_flatten's records, by the id the packet carries), then the levels are walked bottom-up —
+// one thread per node: the boxes of its leaf children from their triangles' padded boxes (k_flatten's, the build's own leaves; a pre-split triangle's references all get
+// the whole triangle's box), those of its internal children from the level below, the node's grid and the children's planes by k_wide_level's rules.
+__global__ void k_refit_wide_packets(const float4 *__restrict__ tri_world, float4 *__restrict__ wpackets, uint32_t n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t gid = __float_as_uint(wpackets[WPK * (size_t)p].w);
+    for (int j = 0; j < 3; j++) wpackets[WPK * (size_t)p + j] = tri_world[3 * (size_t)gid + j];
+}
+// A leaf child none of whose triangles moved (its instance's mesh was not updated) keeps the box it has — decoded from its planes on the node's old grid: the box the BUILD gave
+// that reference, clipped to its slab if the triangle was pre-split (walls and floor: 32 references each; with the whole triangle's box on every one of them the refitted
+// DragonScene rendered 14 % slower than a fresh build at a deformation of half a percent of the dragon's size).
+__global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__restrict__ wpackets, const float4 *__restrict__ tri_lo, const float4 *__restrict__ tri_hi,
+                                   const uint4 *__restrict__ tri_shade, const uint8_t *__restrict__ inst_dirty, float4 *__restrict__ nbox, uint32_t first, uint32_t count) {
+    static_assert(!MRT_WIDE6, "the refit reads the 80-byte node");
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const size_t w = WNODE_STRIDE * (size_t)(first + i);
+    const float4 n0 = wnodes[w], n1 = wnodes[w + 1];
+    const uint32_t imask = __float_as_uint(n0.w) >> 24, cbase = __float_as_uint(n1.x), tbase = __float_as_uint(n1.y), meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+    const float BIG = 3.0e38f;
+    float clo[8][3], chi[8][3]; bool occ[8];
+    float nl[3] = {BIG, BIG, BIG}, nh[3] = {-BIG, -BIG, -BIG};
+    uint32_t rank = 0; bool any = false;
+    for (int sl = 0; sl < 8; sl++) {
+        float lo[3] = {BIG, BIG, BIG}, hi[3] = {-BIG, -BIG, -BIG};
+        occ[sl] = false;
+        if ((imask >> sl) & 1u) {
+            const uint32_t c = cbase + rank++;
+            const float4 a = nbox[2 * (size_t)c], b = nbox[2 * (size_t)c + 1];
+            lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; occ[sl] = true;
+        } else {
+            const uint32_t m = (meta[sl >> 2] >> (8 * (sl & 3))) & 0xFFu, cnt = m >> 5, off = m & 31u;
+            bool moved = false;
+            for (uint32_t r = 0; r < cnt; r++) {
+                const uint32_t gid = __float_as_uint(wpackets[WPK * (size_t)(tbase + off + r)].w);
+                moved = moved || inst_dirty[tri_shade[gid].w >> 16] != 0;
+                const float4 a = tri_lo[gid], b = tri_hi[gid];
+                lo[0] = fminf(lo[0], a.x); lo[1] = fminf(lo[1], a.y); lo[2] = fminf(lo[2], a.z);
+                hi[0] = fmaxf(hi[0], b.x); hi[1] = fmaxf(hi[1], b.y); hi[2] = fmaxf(hi[2], b.z);
+                occ[sl] = true;
+            }
+            if (cnt != 0u && !moved) {          // the box this child has: planes q * 2^e + p on the node's grid as it stands (rounded outwards when they were written)
+                const uint32_t ew = __float_as_uint(n0.w);
+                const float org[3] = {n0.x, n0.y, n0.z};
+                const float4 p2 = wnodes[w + 2], p3 = wnodes[w + 3], p4 = wnodes[w + 4];
+                const uint32_t pl[6][2] = {{__float_as_uint(p2.x), __float_as_uint(p2.y)}, {__float_as_uint(p2.z), __float_as_uint(p2.w)}, {__float_as_uint(p3.x), __float_as_uint(p3.y)},
+                                           {__float_as_uint(p3.z), __float_as_uint(p3.w)}, {__float_as_uint(p4.x), __float_as_uint(p4.y)}, {__float_as_uint(p4.z), __float_as_uint(p4.w)}};
+                for (int a = 0; a < 3; a++) {
+                    const float st = __builtin_ldexpf(1.0f, (int)(int8_t)((ew >> (8 * a)) & 0xFFu));
+                    const float ql = (float)((pl[a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu), qh = (float)((pl[3 + a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu);
+                    lo[a] = __builtin_fmaf(ql, st, org[a]); hi[a] = __builtin_fmaf(qh, st, org[a]);          // (exact: a plane is p + q * 2^e with q < 256)
+                }
+            }
+        }
+        for (int a = 0; a < 3; a++) { clo[sl][a] = lo[a]; chi[sl][a] = hi[a]; if (occ[sl]) { nl[a] = fminf(nl[a], lo[a]); nh[a] = fmaxf(nh[a], hi[a]); } }
+        any = any || occ[sl];
+    }
+    if (!any) { nbox[2 * (size_t)(first + i)] = make_float4(n0.x, n0.y, n0.z, 0.0f); nbox[2 * (size_t)(first + i) + 1] = make_float4(n0.x, n0.y, n0.z, 0.0f); return; }      // (a node without children: nothing to move)
+    // the node's grid: p = lo, step 2^e >= extent / 255 per axis; a child's planes rounded outwards and checked against their decoded positions (as k_wide_level)
+    uint32_t eb[3]; float inv_step[3], step[3];
+    for (int a = 0; a < 3; a++) {
+        const float sdiv = (nh[a] - nl[a]) / 255.0f;
+        const uint32_t bits = __float_as_uint(sdiv);
+        uint32_t e = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+        if (e < 1u) e = 1u; if (e > 254u) e = 254u;
+        eb[a] = e; step[a] = __uint_as_float(e << 23); inv_step[a] = __uint_as_float((254u - e) << 23);
+    }
+    uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int sl = 0; sl < 8; sl++) {
+        uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
+        if (occ[sl]) for (int a = 0; a < 3; a++) {
+            float fl = floorf((clo[sl][a] - nl[a]) * inv_step[a]), fh = ceilf((chi[sl][a] - nl[a]) * inv_step[a]);
+            fl = fminf(fmaxf(fl, 0.0f), 255.0f); fh = fminf(fmaxf(fh, 0.0f), 255.0f);
+            if (nl[a] + fl * step[a] > clo[sl][a] && fl > 0.0f) fl -= 1.0f;
+            if (nl[a] + fh * step[a] < chi[sl][a] && fh < 255.0f) fh += 1.0f;
+            ql[a] = (uint32_t)fl; qh[a] = (uint32_t)fh;
+        }
+        for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
+    }
+    wnodes[w + 0] = make_float4(nl[0], nl[1], nl[2], __uint_as_float(((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24)));
+    wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
+    wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
+    wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
+    nbox[2 * (size_t)(first + i)] = make_float4(nl[0], nl[1], nl[2], 0.0f); nbox[2 * (size_t)(first + i) + 1] = make_float4(nh[0], nh[1], nh[2], 0.0f);
+}
+
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // diagnostics: how full are the 8-wide nodes?  out[c] = nodes with c children (c = 0..8), out[9] = internal children, out[10] = leaf children, out[11] = triangles
@@ -1019,14 +1108,14 @@ void pack_material(const MRTMaterial &m, float4 *out3) {
     out3[2] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.refractionIndex);
 }
 
-int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed) {
+int build_scene(const std::vector<HostMesh> &meshes_in, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed, bool only_vertices_changed) {
     out.validate = opt.validate != 0;
     if (opt.instancing) return build_two_level(meshes_in, opt, stream, out);
     out.num_inst = 0; out.inst.release(); out.tlas_index.release(); out.wtlas_index.release(); out.tri_packet.release(); out.inst_box.release(); out.tlas_wcap = 0; out.blas_wdepth = 0; out.bnodes.release(); out.h_inst.clear();
     // an instance (mrt_scene_add_instance) takes its geometry from its source mesh; flattening gives every instance its own world-space copy
     std::vector<MeshRef> refs;
     for (auto &m : meshes_in) refs.push_back(MeshRef{m.source >= 0 ? &meshes_in[(size_t)m.source] : &m, m.xf});
-    if (int rc = build_flat(refs, opt, stream, out, nullptr, only_transforms_changed)) return rc;
+    if (int rc = build_flat(refs, opt, stream, out, nullptr, only_transforms_changed, only_vertices_changed && opt.refit)) return rc;
     const auto tv = std::chrono::steady_clock::now();
     const int rc = out.validate ? validate_layout(out, stream, false) : MRT_OK;
     out.commit_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count();
@@ -1045,7 +1134,7 @@ static void run_tasks(std::vector<std::function<void()>> &tasks, size_t bytes) {
     for (auto &t : th) t.join();
 }
 
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage, bool geometry_unchanged) {
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage, bool geometry_unchanged, bool refit) {
     struct MeshView { const std::vector<float> &positions, &normals; const float *xf; const std::vector<std::vector<uint32_t>> &sub_indices; const std::vector<MRTMaterial> &sub_materials; };
     std::vector<MeshView> meshes;
     for (auto &r : refs) meshes.push_back(MeshView{r.g->positions, r.g->normals, r.xf, r.g->sub_indices, r.g->sub_materials});
@@ -1123,6 +1212,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         catch (...) { for (auto &f : tasks_n) f(); }
     }
     run_tasks(tasks, task_bytes);
+    // a refit keeps the tree (and what the statistics say about it): same triangle count as the build that made the 8-wide layout, that layout usable and the only one resident
+    const bool do_refit = refit && opt.wide && out.num_wnodes != 0 && out.wnodes.p && out.wpackets.p && !out.nodes.p && out.refit_triangles == T && T != 0 && !out.wide_levels.empty() && !MRT_WIDE6;
+    const MRTSceneStats stats_before = out.stats;
+    if (!do_refit) { out.wide_levels.clear(); out.refit_triangles = 0; out.refits = 0; }
     out.stats = MRTSceneStats{};
     out.stats.triangles = T; out.stats.vertices = V; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub;
     out.stats.max_leaf_tris = opt.max_leaf;
@@ -1197,6 +1290,31 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     const auto tw2 = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs_p, (int)nrec, d_pos_p, d_idx_p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
+    if (do_refit) {
+        DevBuf<float4> nbox; MRT_HIP(nbox.alloc_in(arena, 2 * (size_t)out.num_wnodes));
+        DevBuf<uint8_t> inst_dirty; MRT_HIP(inst_dirty.alloc_in(arena, std::max<size_t>(I, 1)));
+        std::vector<uint8_t> h_dirty(std::max<size_t>(I, 1), 0);
+        for (size_t mi = 0; mi < I; mi++) h_dirty[mi] = refs[mi].g->dirty ? 1 : 0;
+        MRT_HIP(hipMemcpyAsync(inst_dirty.p, h_dirty.data(), h_dirty.size(), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(out.num_packets, B)), dim3(B), 0, stream, tri_world.p, out.wpackets.p, out.num_packets);
+        std::vector<uint32_t> first(out.wide_levels.size(), 0u);
+        for (size_t L = 1; L < out.wide_levels.size(); L++) first[L] = first[L - 1] + out.wide_levels[L - 1];
+        for (size_t L = out.wide_levels.size(); L-- > 0;)
+            hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(out.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, out.tri_shade.p, inst_dirty.p, nbox.p, first[L], out.wide_levels[L]);
+        MRT_HIP(hipEventRecord(ev1, stream));
+        float4 h_box[2];
+        MRT_HIP(hipMemcpyAsync(h_box, nbox.p, sizeof h_box, hipMemcpyDeviceToHost, stream));
+        if (int rc = upload_normals()) return rc;
+        MRT_HIP(hipStreamSynchronize(stream));
+        MRT_HIP(hipGetLastError());
+        float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        out.stats = stats_before;          // the tree's shape, and what was measured on it (sah_cost is the build's: a refit does not re-evaluate it)
+        out.stats.build_ms = ms;
+        out.root_lo[0] = h_box[0].x; out.root_lo[1] = h_box[0].y; out.root_lo[2] = h_box[0].z; out.root_hi[0] = h_box[1].x; out.root_hi[1] = h_box[1].y; out.root_hi[2] = h_box[1].z;
+        out.commit_ms[2] = since(tw2);
+        out.refits++;
+        return build_fat_shade(out, opt, stream);
+    }
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
     uint32_t n = T32;
     const float4 *leaf_lo_p = tri_lo.p, *leaf_hi_p = tri_hi.p;
@@ -1396,6 +1514,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.stats.build_ms += wms;
         out.wide_depth = depth;
         { uint32_t acc = 0; for (int L = 0; L < 4; L++) { acc += (uint32_t)L < WIDE_LV_MAX ? h_lv[L] : 0u; out.wide_level_end[L] = acc; } }
+        out.wide_levels.assign(h_lv.begin(), h_lv.begin() + depth); out.refit_triangles = T;
         if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;

@@ -192,6 +192,7 @@ struct HostMesh {                  // what the caller handed over through mrt_sc
     float xf[16];                  // column-major, last row forced to (0,0,0,1)
     std::vector<std::vector<uint32_t>> sub_indices;
     std::vector<MRTMaterial> sub_materials;
+    bool dirty = false;            // vertices replaced by mrt_scene_update_mesh since the last commit (a refit recomputes the boxes of such meshes' triangles only)
 };
 
 struct BuildOptions {
@@ -207,6 +208,7 @@ struct BuildOptions {
                                                             // (0.45 ... 1.0 measured +1 ... +2 % on DragonScene, 0.5 against 0.3: garden 4K +1 %, dragon x 4 +3 ... +4 %, hostile +1.5 %, Cornell 256^2 +8 ... +13 %; profiles/r05_wide_cost_tri.txt)
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
     int fat_shade = 0;        // 1: also keep, per triangle, its three vertex normals beside its instance / geometry word (48 B; SceneView::tri_fat): k_shade then needs one dependent gather per hit instead of two.  Measured (profiles/r05_lds_top_ab.txt): the shade launches alone 0.772 against 0.777 ms, the frame within noise — off by default (it would add 42 MB to DragonScene's 70)
+    int refit = 1;            // a commit after mrt_scene_update_mesh alone (same topology, new vertex positions / normals) REFITS the 8-wide tree of a flattened scene — packets rewritten, boxes recomputed bottom-up, the tree's shape kept — instead of building it again; 0: always build
     int refit_fenced = 0;     // 1: the bottom-up pass of the build with __threadfence() hand-offs instead of write-through stores (the slow reference form; same tree bit for bit)
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
@@ -217,6 +219,9 @@ struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
     uint32_t wide_level_end[4] = {0, 0, 0, 0};   // flattened scenes: nodes of the 8-wide tree in levels 0..k (BFS numbering: wnodes[0 .. wide_level_end[k]) ARE those levels) — what the traversal stages in LDS (renderer option lds_top)
+    std::vector<uint32_t> wide_levels;           // flattened scenes: nodes per level of the 8-wide tree (BFS numbering) — what a refit walks bottom-up (build_flat, refit)
+    uint32_t refits = 0;                         // commits served by a refit since the last build
+    uint64_t refit_triangles = 0;                // triangles of the build that made the 8-wide layout (a refit needs the same count)
     uint32_t num_packets = 0;        // triangle packets per layout = build references (stats.triangles, or more when long triangles were pre-split)
     uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
@@ -246,11 +251,11 @@ void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_fat_shade(DeviceScene &out, const BuildOptions &opt, hipStream_t stream);      // tri_fat from tri_shade + normals (flattened scenes and single BLASes: vertex ids are absolute in `normals`)
-int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
+int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false, bool only_vertices_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
 void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);
 struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + object->world matrix (column-major 4x4)
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr, bool geometry_unchanged = false);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr, bool geometry_unchanged = false, bool refit = false);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched

@@ -69,6 +69,17 @@ class DeviceScene:
         xf = np.ascontiguousarray(np.asarray(transform, np.float32).reshape(16))
         check(lib.mrt_scene_set_instance_transform(self.handle, int(mesh_id), ptr(xf)))
 
+    def update_mesh(self, mesh_id, positions, normals):
+        """Deforming geometry: new object-space positions / normals of one mesh's vertices (same count); call commit() afterwards — a flattened scene refits its tree."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3); nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        check(lib.mrt_scene_update_mesh(self.handle, int(mesh_id), ptr(pos), 12, ptr(nrm), 12, pos.shape[0]))
+
+    @property
+    def refits(self):
+        v = C.c_uint32()
+        check(lib.mrt_debug_scene_refits(self.handle, C.byref(v)))
+        return v.value
+
     def commit(self):
         check(lib.mrt_scene_commit(self.handle))
 
