@@ -110,7 +110,7 @@ struct SceneView {           // passed by value to kernels
     const InstanceDev *inst;
     const uint32_t *tlas_index;  // instance ids, TLAS leaf order
     const uint32_t *wtlas_index; // instance ids in the leaf order of the 8-wide TLAS (wnodes[0 ..]: its leaf children are single instances)
-    const float4 *inst_box;      // two-level scenes: per instance the box of its BLAS in OBJECT space (lo, hi): what the flat TLAS pass (k_tl_top_flat) tests a transformed ray against
+    const float4 *inst_box;      // two-level scenes: per instance four float4 — the box of its BLAS in OBJECT space (lo, hi: what the BLAS pass tests a fetched pair's ray against) and the instance's padded WORLD box (lo, hi: what the flat TLAS pass, k_tl_top_flat, queues pairs on)
     const uint32_t *tri_packet;  // two-level scenes with the 8-wide layout: per shading record (InstanceDev::ts_base + triangle of the BLAS) its packet in wpackets — how k_shade<.., PAIRS> finds the triangle a key names
     const float4 *bnodes;        // rope nodes of all BLASes, 4 x float4 each; followed, in the same allocation, by
     const float4 *bpackets;      // their triangle packets (object space), 3 x float4 each

@@ -379,7 +379,7 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
     std::vector<Box> boxes(I);
     std::vector<uint32_t> live;
     std::vector<float4> h_cols(std::max<size_t>(I * 4, 4));
-    std::vector<float4> h_box(2 * std::max<size_t>(I, 1), make_float4(0, 0, 0, 0));      // per instance, the box of its BLAS in OBJECT space (the flat TLAS pass tests the transformed ray against it); lo > hi: no ray enters
+    std::vector<float4> h_box(4 * std::max<size_t>(I, 1), make_float4(0, 0, 0, 0));      // + the instance's world box (padded, as the TLAS has it): what the flat TLAS pass queues pairs on      // per instance, the box of its BLAS in OBJECT space (the flat TLAS pass tests the transformed ray against it); lo > hi: no ray enters
     for (size_t i = 0; i < I; i++) {
         InstanceDev &d = out.h_inst[i];
         const float *xf = meshes[i].xf;
@@ -389,9 +389,10 @@ int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceS
         for (int r = 0; r < 3; r++) d.w2o[r] = ok ? make_float4(rows[r][0], rows[r][1], rows[r][2], rows[r][3]) : make_float4(0, 0, 0, 0);
         if (ok && d.ntri > 0) {
             boxes[i] = instance_box(xf, &out.blas_lo[3 * (size_t)d.blas], &out.blas_hi[3 * (size_t)d.blas]); live.push_back((uint32_t)i);
-            h_box[2 * i] = make_float4(out.blas_lo[3 * (size_t)d.blas], out.blas_lo[3 * (size_t)d.blas + 1], out.blas_lo[3 * (size_t)d.blas + 2], 0);
-            h_box[2 * i + 1] = make_float4(out.blas_hi[3 * (size_t)d.blas], out.blas_hi[3 * (size_t)d.blas + 1], out.blas_hi[3 * (size_t)d.blas + 2], 0);
-        } else { h_box[2 * i] = make_float4(1, 1, 1, 0); h_box[2 * i + 1] = make_float4(-1, -1, -1, 0); }
+            h_box[4 * i] = make_float4(out.blas_lo[3 * (size_t)d.blas], out.blas_lo[3 * (size_t)d.blas + 1], out.blas_lo[3 * (size_t)d.blas + 2], 0);
+            h_box[4 * i + 1] = make_float4(out.blas_hi[3 * (size_t)d.blas], out.blas_hi[3 * (size_t)d.blas + 1], out.blas_hi[3 * (size_t)d.blas + 2], 0);
+            h_box[4 * i + 2] = make_float4(boxes[i].lo[0], boxes[i].lo[1], boxes[i].lo[2], 0); h_box[4 * i + 3] = make_float4(boxes[i].hi[0], boxes[i].hi[1], boxes[i].hi[2], 0);
+        } else { h_box[4 * i] = make_float4(1, 1, 1, 0); h_box[4 * i + 1] = make_float4(-1, -1, -1, 0); h_box[4 * i + 2] = make_float4(1, 1, 1, 0); h_box[4 * i + 3] = make_float4(-1, -1, -1, 0); }
     }
     TlasBuilder tb(boxes);
     tb.order = live;
