@@ -972,6 +972,11 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
             else { t_base = __float_as_uint(n1.y); t_mask = tri_hits; }
         }
         if (last_step && live) { live = false; unreported = true; }
+#ifdef MRT_PROBE_EXTRA_VALU      // diagnostics build: N more full-rate VALU instructions per iteration, on a scratch register (how much of the loop's time is VALU issue?)
+        { float sink_; asm volatile("v_mov_b32 %0, %1" : "=v"(sink_) : "v"(best_t));
+#pragma unroll
+          for (int k_ = 0; k_ < MRT_PROBE_EXTRA_VALU; k_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(sink_)); }
+#endif
     }
 }
 
