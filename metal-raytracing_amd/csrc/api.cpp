@@ -526,6 +526,7 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
     else if (k == "stream_stride") { REQUIRE(value >= 0 && value <= 2, "stream_stride must be 0 (contiguous ranges), 1 (round-robin batches) or 2 (round-robin for a shard's launches)"); r->r.stream_stride = (int)value; }
     else if (k == "halton_table") r->r.halton_table = value != 0;
+    else if (k == "equal_passes") r->r.equal_passes = value != 0;
     else if (k == "frame_bundle") { REQUIRE(value >= 0 && value <= 2, "frame_bundle must be 0 (off), 1 (eight sub-frames of a slot side by side in a wave) or 2 (and walking the tree as one bundle)"); r->r.frame_bundle = (int)value; }
     else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
     else if (k == "primary_hint") r->r.primary_hint = value != 0;

@@ -92,6 +92,7 @@ struct Renderer {
     bool tail_accumulate = true;         // the last passes of a draw (one per lane) are accumulated in one launch after the join instead of one after the other
     int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
+    int equal_passes = 1;                // a draw's frames go in passes of equal size (20 frames at frame_batch 8: 7 + 7 + 6); 0: full passes first (8 + 8 + 4) — measured worse
     int frame_bundle = 1;                // bounce 0 of a multi-frame pass: 1 = a wave of k_shade<.., TRACE0> takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 2 = and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h; flattened scenes)
     int stream_stride = 2;               // the static split deals 64-ray batches round-robin to the waves (BatchStride) instead of one contiguous range each: 0 never, 1 always, 2 = a shard's launches (with one round of waves)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity

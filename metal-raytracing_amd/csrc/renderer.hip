@@ -1462,7 +1462,7 @@ int Renderer::render(int n_frames) {                                   // Render
     AccGroup tail{}; tail.n = 0;
     for (int f = 0; f < n_frames; pass++) {
         // the draw's frames in passes of equal size (20 frames at frame_batch 8: 7 + 7 + 6, not 8 + 8 + 4 — the passes of a short draw run side by side and end together)
-        int B = std::min(batch_max, (n_frames - f + (n_passes - pass) - 1) / std::max(1, n_passes - pass));
+        int B = equal_passes ? std::min(batch_max, (n_frames - f + (n_passes - pass) - 1) / std::max(1, n_passes - pass)) : std::min(batch_max, n_frames - f);
         f += B;
         fp.batch = B;
         for (int g = 0; g < G; g++) {
