@@ -174,6 +174,8 @@ class Renderer {                                                     // Renderer
     void setFrameIndex(uint32_t f) { check(mrt_renderer_set_frame_index(r_, f)); }
     // animated transforms: new object->world matrix (column-major 4x4) for one mesh / instance, then commit(); a two-level scene rebuilds only its TLAS
     void setInstanceTransform(int32_t meshId, const float transform[16]) { check(mrt_scene_set_instance_transform(scene_, meshId, transform)); }
+    /// deforming geometry: new object-space positions / normals (packed xyz) of one mesh's vertices, same count; commit() then refits the tree of a flattened scene
+    void updateMesh(int32_t meshId, const float *positions, const float *normals, size_t vertexCount) { check(mrt_scene_update_mesh(scene_, meshId, positions, 12, normals, 12, vertexCount)); }
     void commit() { check(mrt_scene_commit(scene_)); }
     // implementation knobs (mrt_abi.h): "frames_in_flight" (HIP streams, default 12), "frame_batch" (frames per pass, default 4), ...
     void setOption(const char *key, double value) { check(mrt_renderer_set_option(r_, key, value)); }

@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
             if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
             else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
         };
-    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n, reinterpret_cast<const uint8_t *>(mine + 256u)};
+    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n, reinterpret_cast<const uint8_t *>(mine + 256u), mine + 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u)};
     if (StreamExt<HIT, TOP>::nh_lut) nh_lut_fill(mine + 256u);
     traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? HIT_LDS_WORDS : 0u), fetch, emit, nullptr, NoPairs{}, ext);
 }
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u, reinterpret_cast<const uint8_t *>(lds_dyn + 256u)};
+    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u, reinterpret_cast<const uint8_t *>(lds_dyn + 256u), lds_dyn + 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u)};
     if (StreamExt<true, false>::nh_lut) nh_lut_fill(lds_dyn + 256u);
     // stream_stride: the (n + rays_per_wave - 1) / rays_per_wave waves that have work take the queue's 64-ray batches round-robin instead of one contiguous range each
     const BatchStride src = strided ? BatchStride{blockIdx.x * 64u, 64u * ((n + rays_per_wave - 1u) / rays_per_wave), n} : BatchStride{begin, 64u, min(n, begin + rays_per_wave)};

@@ -78,6 +78,12 @@ MRT_DEV void wstack_pop(const uint32_t *stack, uint32_t sp, uint32_t lane, uint3
 #ifndef MRT_NH_LUT
 #define MRT_NH_LUT 0
 #endif
+// MRT_ROOT_AT_FETCH (the stream kernels with LDS extras): every ray's walk begins with the SAME node.  The batch prefetch — 64 rays, one per lane, every lane busy — tests the root's
+// eight boxes for its rays there (the root's words are wave-uniform loads) and leaves the hit bits in LDS; a lane that takes a ray starts with the root's children as its group
+// instead of spending its first iteration — a round trip, and a node test at the loop's ~55 % of the lanes — on node 0.
+#ifndef MRT_ROOT_AT_FETCH
+#define MRT_ROOT_AT_FETCH 1
+#endif
 constexpr uint32_t NH_LUT_WORDS = 32;
 MRT_DEV uint32_t lds_u8(const uint8_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -624,15 +630,16 @@ MRT_DEV float4 lds_f4(const float4 *p) {
     return *p;
 #endif
 }
-struct NoExt { static constexpr bool hit_lds = false, top_lds = false, nh_lut = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; const uint8_t *nh = nullptr; };      // (members never read: every use sits behind one of the two flags)
+struct NoExt { static constexpr bool hit_lds = false, top_lds = false, nh_lut = false, root_pre = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; const uint8_t *nh = nullptr; uint32_t *root = nullptr; };      // (members never read: every use sits behind one of the two flags)
 template <bool HIT, bool TOP> struct StreamExt {
-    static constexpr bool hit_lds = HIT, top_lds = TOP, nh_lut = HIT && MRT_NH_LUT != 0;
+    static constexpr bool hit_lds = HIT, top_lds = TOP, nh_lut = HIT && MRT_NH_LUT != 0, root_pre = HIT && MRT_ROOT_AT_FETCH != 0;
     float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far; MRT_NH_LUT: followed by the wave's 128-byte table (wide_node_test<.., NHLUT>)
     const float4 *top;      // TOP: wnodes[0 .. top_n) in LDS
     uint32_t top_n;
     const uint8_t *nh = nullptr;
+    uint32_t *root = nullptr;      // MRT_ROOT_AT_FETCH: [2][64] words of this wave: the root's {internal-child hits, leaf-triangle hits} of the prefetched batch's rays
 };
-constexpr uint32_t HIT_LDS_WORDS = 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u);      // per wave, in front of its stack
+constexpr uint32_t HIT_LDS_WORDS = 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u) + (MRT_ROOT_AT_FETCH ? 128u : 0u);      // per wave, in front of its stack
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -713,6 +720,20 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     if constexpr (SEED || ROOTS) fetch(cur + lane, pA, pB, tag, is_any, pS); else fetch(cur + lane, pA, pB, tag, is_any);
                     pB.w = __uint_as_float((tag & 0x7FFFFFFFu) | (is_any << 31));
                 }
+                if constexpr (Ext::root_pre) {
+                    if (batch_n != 0u && s.num_wnodes != 0) {          // (wave-uniform) the root against every ray of the batch, here
+                        const float4 *__restrict__ nd = s.wnodes;
+                        const float4 r0_ = nd[0], r1_ = nd[1], r2_ = nd[2], r3_ = nd[3], r4_ = nd[WNODE_N4];
+                        if (lane < batch_n) {
+                            const f3 o_ = mk3(pA.x, pA.y, pA.z);
+                            const float ix_ = box_inv(pB.x), iy_ = box_inv(pB.y), iz_ = box_inv(pB.z);
+                            const bool nx_ = pB.x < 0.0f, ny_ = pB.y < 0.0f, nz_ = pB.z < 0.0f;
+                            uint32_t nh_, th_;
+                            wide_node_test<MRT_WIDE_SCALED != 0>(r0_, r1_, r2_, r3_, r4_, o_, ix_, iy_, iz_, nx_, ny_, nz_, (nx_ ? 1u : 0u) | (ny_ ? 2u : 0u) | (nz_ ? 4u : 0u), 0.0f, pA.w, nh_, th_);
+                            ext.root[lane] = nh_; ext.root[64u + lane] = th_;
+                        }
+                    }
+                }
                 cur += batch_n;
             }
             const uint32_t avail = batch_n - batch_used;
@@ -732,6 +753,13 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     tagw = __float_as_uint(bw_);
                     // enter the root as the only "hit child" of a pseudo group: base 0, no internal-child bits -> node 0; empty stack
                     g_base = ROOTS ? seed_ : 0u; g_mask = s.num_wnodes != 0 ? 0x100u : 0u; t_base = 0; t_mask = 0;      // (the pseudo group has no internal-child bits: its one "hit child" is node g_base itself)
+                    if constexpr (Ext::root_pre) {
+                        if (s.num_wnodes != 0) {          // the root was tested when the batch was fetched: its children are the lane's first group
+                            const float4 q1_ = s.wnodes[1];
+                            g_base = __float_as_uint(q1_.x) & WNODE_BASE_MASK; g_mask = (ext.root[sl] << 8) | (__float_as_uint(s.wnodes[0].w) >> 24);
+                            t_base = __float_as_uint(q1_.y); t_mask = ext.root[64u + (uint32_t)sl];
+                        }
+                    }
                     if (SPEC) { u_base = 0; u_mask = 0; }
                     live = true;
                     if (Pairs::on) qi = batch_first + (uint32_t)sl;
