@@ -979,7 +979,9 @@ __global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__
                 for (int a = 0; a < 3; a++) {
                     const float st = __builtin_ldexpf(1.0f, (int)(int8_t)((ew >> (8 * a)) & 0xFFu));
                     const float ql = (float)((pl[a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu), qh = (float)((pl[3 + a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu);
-                    lo[a] = __builtin_fmaf(ql, st, org[a]); hi[a] = __builtin_fmaf(qh, st, org[a]);          // (exact: a plane is p + q * 2^e with q < 256)
+                    // (exact: a plane is p + q * 2^e with q < 256)  Never beyond its triangles' own boxes: a moving sibling changes the node's grid with every refit, and a box
+                    // re-rounded outwards onto each new grid would creep; an unsplit triangle's leaf thus keeps exactly its box, a pre-split reference at worst ends at its triangle's
+                    lo[a] = fmaxf(lo[a], __builtin_fmaf(ql, st, org[a])); hi[a] = fminf(hi[a], __builtin_fmaf(qh, st, org[a]));
                 }
             }
         }
