@@ -610,12 +610,18 @@ __global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WA
                     const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
                     const uint32_t guess = hint[pixel];
                     float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
+                    TravHit sh_; sh_.U = 0.0f; sh_.V = 0.0f; sh_.ad = 1.0f; sh_.gid = 0xFFFFFFFFu;
                     if (guess < s.num_wpackets) {
                         const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
+                        const float4 q0_ = pk[0];
                         float t, U, V, ad;
-                        if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
+                        if (tri_test(q0_, pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; sh_.U = U; sh_.V = V; sh_.ad = ad; sh_.gid = __float_as_uint(q0_.w); }
                     }
+#if MRT_LANE_HIT_LDS
+                    hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk, nullptr, 0, reinterpret_cast<float *>(shade_stk + SHADE_WAVES * fp.wide_stack_words + (threadIdx.x >> 6) * 256u), &sh_);
+#else
                     hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk);
+#endif
                     if (h.pk != guess) hint[pixel] = h.pk;
                 }
                 else hit = traverse_wide_lane<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk);
@@ -1606,7 +1612,7 @@ int Renderer::render(int n_frames) {                                   // Render
                                               : fp.chain ? k_shade<false, true> : k_shade<false, false>;
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
-                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (tile_walk ? TILE_FRONT_WORDS * 4 : 0)) : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + ((tile_walk || MRT_LANE_HIT_LDS) ? 1024 : 0)) : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
                              L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && trace0_hint) ? hint.p : (uint32_t *)nullptr);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)

@@ -275,13 +275,19 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 // SEED: `seed_pk` is a packet the caller has already tested (distance in tmax); the walk starts with it as its closest hit.  h.pk = packet of the final hit.
 // ROOTS (traverse_wide_tile.h): the walk starts not at node 0 but at the nodes of `front` — nroots pairs {node, lower bound of the distance at which any ray of the tile enters it (float bits)},
 // nearest first — taking the next one whenever its own stack runs empty and skipping those that lie beyond its closest hit.
+#ifndef MRT_LANE_HIT_LDS
+#define MRT_LANE_HIT_LDS 1      // 1: the lane walk keeps U, V, |det|, id of its closest hit in four words of LDS (`hitw`, [4][64] behind the caller's stack) instead of testing the winner again at the end
+#endif
 template <bool SEED, bool ROOTS = false>
-MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */, const uint32_t *front = nullptr, uint32_t nroots = 0) {
+MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */, const uint32_t *front = nullptr, uint32_t nroots = 0, float *hitw = nullptr, const TravHit *seed_hit = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     const float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
     const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     float best_t = tmax; uint32_t best_pk = SEED ? seed_pk : 0xFFFFFFFFu;
+    if (MRT_LANE_HIT_LDS && hitw) {          // the seed's own U, V, |det|, id (the caller tested it) are the closest hit so far
+        if (SEED && seed_hit && seed_pk != 0xFFFFFFFFu) { hitw[lane] = seed_hit->U; hitw[64u + lane] = seed_hit->V; hitw[128u + lane] = seed_hit->ad; hitw[192u + lane] = __uint_as_float(seed_hit->gid); }
+    }
     uint32_t g_base = 0, g_mask = (!ROOTS && s.num_wnodes != 0) ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
     uint32_t cursor = 0;                 // ROOTS: next entry of `front`
     for (;;) {
@@ -329,8 +335,8 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
             float t, U, V, ad;
             if (tri_test(r0, r1, r2, o, d, 0.0f, best_t, t, U, V, ad)) {
                 bool better = t < best_t || best_pk == 0xFFFFFFFFu;
-                if (!better) better = __float_as_uint(r0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);      // t == best_t: ties go to the lowest id
-                if (better) { best_t = t; best_pk = tri_pk; }
+                if (!better) better = (MRT_LANE_HIT_LDS && hitw) ? __float_as_uint(r0.w) < __float_as_uint(hitw[192u + lane]) : __float_as_uint(r0.w) < __float_as_uint(s.wpackets[WPK * (size_t)best_pk].w);      // t == best_t: ties go to the lowest id
+                if (better) { best_t = t; best_pk = tri_pk; if (MRT_LANE_HIT_LDS && hitw) { hitw[lane] = U; hitw[64u + lane] = V; hitw[128u + lane] = ad; hitw[192u + lane] = r0.w; } }
             }
         }
         if (want_node) {
@@ -345,6 +351,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
     }
     h.t = best_t; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = best_pk;
     if (best_pk == 0xFFFFFFFFu) return false;
+    if (MRT_LANE_HIT_LDS && hitw) { h.U = hitw[lane]; h.V = hitw[64u + lane]; h.ad = hitw[128u + lane]; h.gid = __float_as_uint(hitw[192u + lane]); return true; }
     // id and barycentrics of the winning triangle: recomputed (same arithmetic) instead of living in four registers through the loop
     const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)best_pk;
     const float4 q0 = pk[0];
