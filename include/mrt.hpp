@@ -176,6 +176,11 @@ class Renderer {                                                     // Renderer
     void setInstanceTransform(int32_t meshId, const float transform[16]) { check(mrt_scene_set_instance_transform(scene_, meshId, transform)); }
     /// deforming geometry: new object-space positions / normals (packed xyz) of one mesh's vertices, same count; commit() then refits the tree of a flattened scene
     void updateMesh(int32_t meshId, const float *positions, const float *normals, size_t vertexCount) { check(mrt_scene_update_mesh(scene_, meshId, positions, 12, normals, 12, vertexCount)); }
+    // the checked form: one normal per vertex, or std::invalid_argument before anything is read
+    void updateMesh(int32_t meshId, const std::vector<float> &positions, const std::vector<float> &normals) {
+        if (positions.size() % 3 != 0 || normals.size() != positions.size()) throw std::invalid_argument("updateMesh: positions and normals must hold 3 floats per vertex, the same number of vertices");
+        updateMesh(meshId, positions.data(), normals.data(), positions.size() / 3);
+    }
     void commit() { check(mrt_scene_commit(scene_)); }
     // implementation knobs (mrt_abi.h): "frames_in_flight" (HIP streams, default 12), "frame_batch" (frames per pass, default 4), ...
     void setOption(const char *key, double value) { check(mrt_renderer_set_option(r_, key, value)); }

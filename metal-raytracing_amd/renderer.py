@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._ffi import Camera, Light, RenderStats, SceneStats, check, lib, ptr
+from ._ffi import Camera, Light, MRTError, RenderStats, SceneStats, check, lib, ptr
 from .scene import DragonScene, Scene
 
 
@@ -72,6 +72,8 @@ class DeviceScene:
     def update_mesh(self, mesh_id, positions, normals):
         """Deforming geometry: new object-space positions / normals of one mesh's vertices (same count); call commit() afterwards — a flattened scene refits its tree."""
         pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3); nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        if nrm.shape[0] != pos.shape[0]:          # the C side reads vertex_count normals: a shorter array would be read past its end
+            raise MRTError(1, f"update_mesh: {nrm.shape[0]} normals for {pos.shape[0]} positions (one normal per vertex)")
         check(lib.mrt_scene_update_mesh(self.handle, int(mesh_id), ptr(pos), 12, ptr(nrm), 12, pos.shape[0]))
 
     @property

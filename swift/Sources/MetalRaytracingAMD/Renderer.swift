@@ -54,7 +54,11 @@ public final class Renderer {
     /// animated transforms: a new object->world matrix (column-major 4x4) for one mesh / instance, then commit(); a two-level scene rebuilds only its TLAS
     public func setInstanceTransform(meshId: Int32, transform: [Float]) throws { try check(mrt_scene_set_instance_transform(scene, meshId, transform)) }
     /// Deforming geometry: new object-space positions / normals (packed xyz) for one mesh's vertices, same count; `commit()` then refits the tree of a flattened scene.
-    public func updateMesh(meshId: Int32, positions: [Float], normals: [Float]) throws { try check(mrt_scene_update_mesh(scene, meshId, positions, 12, normals, 12, positions.count / 3)) }
+    public func updateMesh(meshId: Int32, positions: [Float], normals: [Float]) throws {
+        // the C side reads positions.count / 3 normals: a shorter array would be read past its end
+        guard positions.count % 3 == 0, normals.count == positions.count else { throw MRTError(code: 1, message: "updateMesh: \(normals.count / 3) normals for \(positions.count / 3) positions (one normal per vertex)") }
+        try check(mrt_scene_update_mesh(scene, meshId, positions, 12, normals, 12, positions.count / 3))
+    }
     public func commit() throws { try check(mrt_scene_commit(scene)) }
     /// implementation knobs of include/mrt_abi.h: "frames_in_flight", "frame_batch", "materials", "megakernel", ...
     public func setOption(_ key: String, _ value: Double) throws { try check(mrt_renderer_set_option(renderer, key, value)) }

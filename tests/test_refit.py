@@ -79,6 +79,7 @@ def test_refit_argument_checks_and_fallbacks(mrt, gpu_ctx):
     assert ds.refits == 0
     with pytest.raises(mrt.MRTError): ds.update_mesh(k, pos[:-1], nrm[:-1])          # the vertex count must stay
     with pytest.raises(mrt.MRTError): ds.update_mesh(len(meshes) + 3, pos, nrm)
+    with pytest.raises(mrt.MRTError): ds.update_mesh(k, pos, nrm[:-1])              # fewer normals than positions: refused by the wrapper before the C side reads past the array
     # scene option refit = 0: the same calls build
     ds2 = mrt.DeviceScene(gpu_ctx, sc, {"refit": 0})
     ds2.update_mesh(k, pos * np.float32(1.01), nrm); ds2.commit()
