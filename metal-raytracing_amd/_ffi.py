@@ -204,7 +204,7 @@ SIGNATURES = {
     "mrt_debug_layout_limits": (C.c_int, [C.c_uint64, C.c_uint64]),
     "mrt_debug_host_sah": (C.c_int, [_P, _P, _U32, _P, _P, _P, _P]),
     "mrt_debug_validate": (C.c_int, [_P]),
-    "mrt_debug_poke_wnode": (C.c_int, [_P, _U32, _U32, _U32, _PU32]),
+    "mrt_debug_validate_patched": (C.c_int, [_P, _U32, _U32, _U32]),
 }
 
 # Frames in flight run on separate HIP streams; the runtime maps streams onto 4 hardware queues by default,

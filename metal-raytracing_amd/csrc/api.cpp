@@ -3,6 +3,7 @@
 // There is no CPU fallback: without a HIP device mrt_context_create fails (MRT_ERR_NO_DEVICE).
 #include "api_types.h"
 #include "abi_check.h"
+#include "../../include/mrt_debug.h"
 #include <algorithm>
 #include <cstring>
 #include <cstdio>
@@ -194,7 +195,6 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "validate") { REQUIRE(value == 0 || value == 1, "validate must be 0 or 1"); scene->opt.validate = (int)value; }
     else if (k == "wide_collapse") { REQUIRE(value == 0 || value == 1, "wide_collapse must be 0 (greedy) or 1 (SAH-optimal)"); scene->opt.wide_collapse = (int)value; }
     else if (k == "wide_cost_node") { REQUIRE(value > 0, "wide_cost_node must be positive"); scene->opt.wide_cost_node = (float)value; }
-    else if (k == "fat_shade") { REQUIRE(value == 0 || value == 1, "fat_shade must be 0 or 1"); scene->opt.fat_shade = (int)value; }
     else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
     else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
     else if (k == "refit") scene->opt.refit = value != 0;
@@ -518,16 +518,13 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     else if (k == "xcd_counters") { REQUIRE(value == 0 || value == 1, "xcd_counters must be 0 or 1"); r->r.xcd_counters = (int)value; }
     else if (k == "tile_groups") { REQUIRE(value >= 0 && value <= mrt::MAX_TILE_GROUPS && value == (int)value, "tile_groups must be 0 (by the draw), 1 (never) or 2..4"); r->r.tile_groups = (int)value; }
     else if (k == "shade_pack") { REQUIRE(value == 0 || value == 1, "shade_pack must be 0 or 1"); r->r.shade_pack = (int)value; }
-    else if (k == "tile_walk") { REQUIRE(value == 0 || value == 1, "tile_walk must be 0 or 1"); r->r.tile_walk = (int)value; }
-    else if (k == "pool") { REQUIRE(value == 0 || value == 1, "pool must be 0 or 1"); r->r.pool = (int)value; }
     else if (k == "hit_lds") { REQUIRE(value == 0 || value == 1, "hit_lds must be 0 or 1"); r->r.hit_lds = (int)value; }
-    else if (k == "lds_top") { REQUIRE(value >= 0 && value <= 4 && value == (int)value, "lds_top must be 0 (off), 1 (levels 0-1 per wave), 2 (levels 0-2 per 256-thread workgroup), 3 (levels 0-1 per 256-thread workgroup) or 4 (256-thread workgroups, nothing staged)"); r->r.lds_top = (int)value; }
     else if (k == "persist_chunk") { REQUIRE(value >= 64 && value <= 65536 && ((int)value % 64) == 0, "persist_chunk must be a multiple of 64 in [64, 65536]"); r->r.persist_chunk = (int)value; }
     else if (k == "wave_slots") { REQUIRE(value >= 1 && value <= (1 << 20), "wave_slots must be in [1, 2^20]"); r->r.wave_slots = (int)value; r->r.wave_slots_user = true; }
     else if (k == "stream_stride") { REQUIRE(value >= 0 && value <= 2, "stream_stride must be 0 (contiguous ranges), 1 (round-robin batches) or 2 (round-robin for a shard's launches)"); r->r.stream_stride = (int)value; }
     else if (k == "halton_table") r->r.halton_table = value != 0;
     else if (k == "equal_passes") r->r.equal_passes = value != 0;
-    else if (k == "frame_bundle") { REQUIRE(value >= 0 && value <= 2, "frame_bundle must be 0 (off), 1 (eight sub-frames of a slot side by side in a wave) or 2 (and walking the tree as one bundle)"); r->r.frame_bundle = (int)value; }
+    else if (k == "frame_bundle") { REQUIRE(value == 0 || value == 1, "frame_bundle must be 0 (off) or 1 (the sub-frames of a slot side by side in a wave)"); r->r.frame_bundle = (int)value; }
     else if (k == "stream_even") { REQUIRE(value >= 0 && value <= 1600, "stream_even must be in [0,1600] (percent of the wave slots; 0 = off)"); r->r.stream_even = (int)value; }
     else if (k == "primary_hint") r->r.primary_hint = value != 0;
     else if (k == "throughput_chain") r->r.throughput_chain = value != 0;
@@ -549,12 +546,9 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     if (k == "persistent") *value = r->r.persistent;
     else if (k == "persist_chunk") *value = r->r.persist_chunk;
     else if (k == "hit_lds") *value = r->r.hit_lds;
-    else if (k == "pool") *value = r->r.pool;
-    else if (k == "tile_walk") *value = r->r.tile_walk;
     else if (k == "shade_pack") *value = r->r.shade_pack;
     else if (k == "tile_groups") *value = r->r.tile_groups;
     else if (k == "groups_used") *value = r->r.groups_used;
-    else if (k == "lds_top") *value = r->r.lds_top;
     else if (k == "xcd_counters") *value = r->r.xcd_counters;
     else if (k == "wave_slots") *value = r->r.wave_slots;
     else if (k == "stream_stride") *value = r->r.stream_stride;
@@ -714,6 +708,17 @@ int mrt_debug_validate(MRTScene scene) {
     return mrt::validate_layout(scene->dev, scene->ctx->stream, false);
     MRT_CATCH
 }
+int mrt_debug_validate_patched(MRTScene scene, uint32_t node, uint32_t word, uint32_t value) {
+    MRT_TRY
+    REQUIRE(scene && scene->committed && node < scene->dev.num_wnodes && word < 4 * mrt::WNODE_STRIDE, "mrt_debug_validate_patched: bad argument");
+    int rc = bind_device(scene->ctx); if (rc) return rc;
+    mrt::DevBuf<float4> copy; MRT_HIP(copy.alloc(scene->dev.wnodes.n));
+    MRT_HIP(hipMemcpy(copy.p, scene->dev.wnodes.p, scene->dev.wnodes.bytes(), hipMemcpyDeviceToDevice));
+    MRT_HIP(hipMemcpy(reinterpret_cast<uint32_t *>(copy.p + (size_t)mrt::WNODE_STRIDE * node) + word, &value, 4, hipMemcpyHostToDevice));
+    return mrt::validate_layout(scene->dev, scene->ctx->stream, false, copy.p);
+    MRT_CATCH
+}
+#ifdef MRT_DIAGNOSTICS
 int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t value, uint32_t *old_value) {
     MRT_TRY
     REQUIRE(scene && scene->committed && node < scene->dev.num_wnodes && word < 4 * mrt::WNODE_STRIDE, "mrt_debug_poke_wnode: bad argument");
@@ -724,6 +729,7 @@ int mrt_debug_poke_wnode(MRTScene scene, uint32_t node, uint32_t word, uint32_t 
     return MRT_OK;
     MRT_CATCH
 }
+#endif
 // builder = 2's host part on caller boxes (n x {lo.xyz, -} and {hi.xyz, -}): leaf order, left / right of the n - 1 internal nodes, parent of all 2n - 1 (no device needed)
 int mrt_debug_host_sah(const float *lo4, const float *hi4, uint32_t n, uint32_t *order, uint32_t *left, uint32_t *right, uint32_t *parent) {
     MRT_TRY

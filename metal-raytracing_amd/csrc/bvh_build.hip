@@ -45,16 +45,6 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t u) {
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 
-// ------------------------------------------------------------------ fat shading records (SceneView::tri_fat)
-__global__ void k_fat_shade(const uint4 *__restrict__ tri_shade, const float4 *__restrict__ normals, uint32_t n, float4 *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4 ts = tri_shade[i];
-    const float4 a = normals[ts.x], b = normals[ts.y], c = normals[ts.z];
-    out[3 * (size_t)i + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(ts.w));
-    out[3 * (size_t)i + 1] = make_float4(b.x, b.y, b.z, 0.0f);
-    out[3 * (size_t)i + 2] = make_float4(c.x, c.y, c.z, 0.0f);
-}
 // ------------------------------------------------------------------ flatten
 __global__ void k_flatten(const SubRec *__restrict__ recs, int nrec, const float *__restrict__ pos,
                           const uint32_t *__restrict__ indices, const float4 *__restrict__ inst_cols, uint32_t T,
@@ -405,7 +395,6 @@ __device__ __forceinline__ void wide_dp_node(const float *cl, const float *cr, f
         for (int k = 1; k < i; k++) { const float c = cl[k] + cr[i - k]; if (c < b) { b = c; k_ = k; } }
         if (b < C[i - 1]) { C[i] = b; D[i] = (uint8_t)k_; } else { C[i] = C[i - 1]; D[i] = 0; }
     }
-    for (int i = WIDE_N; i <= 7; i++) { C[i] = C[WIDE_N - 1]; D[i] = 0; }          // (entries beyond the node's width — the 6-wide variant — are never read; kept finite)
 }
 
 // Bottom-up pass: one thread per leaf climbs; at every node the thread that arrives second computes it from the two children.  What one thread hands to
@@ -862,15 +851,6 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
     const float pl[3] = {nlo.x, nlo.y, nlo.z};
     uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};     // qlo x,y,z then qhi x,y,z; 2 dwords (8 bytes) each
     uint32_t meta[2] = {0, 0}, imask = 0, rank_i = 0, off_t = 0;
-#if MRT_WIDE6
-    uint32_t pw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, m6[6] = {0, 0, 0, 0, 0, 0}; int phys = 0;      // plane words and per-child meta of the 64-byte node; physical children in slot order
-    auto put6 = [&](int j, const uint32_t ql[3], const uint32_t qh[3]) {
-        for (int a = 0; a < 3; a++) {
-            if (j < 4) { pw[3 * a] |= ql[a] << (8 * j); pw[3 * a + 2] |= qh[a] << (8 * j); }
-            else { pw[3 * a + 1] |= (ql[a] << (8 * (j - 4))) | (qh[a] << (16 + 8 * (j - 4))); }
-        }
-    };
-#endif
     for (int sl = 0; sl < 8; sl++) {
         int k = child_in_slot[sl];
         uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
@@ -902,28 +882,14 @@ __global__ void k_wide_level(TreeArrays t, WideDP dp, const uint32_t *__restrict
             }
         }
         for (int a = 0; a < 3; a++) { q[a][sl >> 2] |= ql[a] << (8 * (sl & 3)); q[3 + a][sl >> 2] |= qh[a] << (8 * (sl & 3)); }
-#if MRT_WIDE6
-        if (k >= 0) { m6[phys] = (uint32_t)sl | ((isleaf[k] ? t.ntri[ch[k]] : 0u) << 3); put6(phys, ql, qh); phys++; }
-#endif
     }
-#if MRT_WIDE6
-    { const uint32_t el[3] = {255, 255, 255}, eh[3] = {0, 0, 0}; for (; phys < 6; phys++) { m6[phys] = 0; put6(phys, el, eh); } }      // unused children: boxes no ray enters
-#endif
     const size_t w = WNODE_STRIDE * (size_t)(base_in + i);
     // exponents are stored unbiased (int8, e - 127): the traversal scales 1/direction with v_ldexp_f32
     wnodes[w + 0] = make_float4(nlo.x, nlo.y, nlo.z, __uint_as_float(((eb[0] - 127u) & 0xFFu) | (((eb[1] - 127u) & 0xFFu) << 8) | (((eb[2] - 127u) & 0xFFu) << 16) | (imask << 24)));
-#if MRT_WIDE6
-    wnodes[w + 1] = make_float4(__uint_as_float(((next_base + my_i) & 0xFFFFFFu) | (m6[5] << 24)), __uint_as_float(my_t),
-                                __uint_as_float(m6[0] | (m6[1] << 6) | (m6[2] << 12) | (m6[3] << 18) | (m6[4] << 24)), __uint_as_float(pw[0]));
-    wnodes[w + 2] = make_float4(__uint_as_float(pw[1]), __uint_as_float(pw[2]), __uint_as_float(pw[3]), __uint_as_float(pw[4]));
-    wnodes[w + 3] = make_float4(__uint_as_float(pw[5]), __uint_as_float(pw[6]), __uint_as_float(pw[7]), __uint_as_float(pw[8]));
-    (void)q; (void)meta;
-#else
     wnodes[w + 1] = make_float4(__uint_as_float(next_base + my_i), __uint_as_float(my_t), __uint_as_float(meta[0]), __uint_as_float(meta[1]));
     wnodes[w + 2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[1][0]), __uint_as_float(q[1][1]));
     wnodes[w + 3] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[3][0]), __uint_as_float(q[3][1]));
     wnodes[w + 4] = make_float4(__uint_as_float(q[4][0]), __uint_as_float(q[4][1]), __uint_as_float(q[5][0]), __uint_as_float(q[5][1]));
-#endif
 }
 
 // ------------------------------------------------------------------ refit of the 8-wide layout (deformed geometry, same topology: mrt_scene_update_mesh + commit)
@@ -942,7 +908,6 @@ __global__ void k_refit_wide_packets(const float4 *__restrict__ tri_world, float
 // DragonScene rendered 14 % slower than a fresh build at a deformation of half a percent of the dragon's size).
 __global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__restrict__ wpackets, const float4 *__restrict__ tri_lo, const float4 *__restrict__ tri_hi,
                                    const uint4 *__restrict__ tri_shade, const uint8_t *__restrict__ inst_dirty, float4 *__restrict__ nbox, uint32_t first, uint32_t count) {
-    static_assert(!MRT_WIDE6, "the refit reads the 80-byte node");
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const size_t w = WNODE_STRIDE * (size_t)(first + i);
@@ -1033,19 +998,9 @@ __global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, 
 
 }  // namespace
 
-int build_fat_shade(DeviceScene &out, const BuildOptions &opt, hipStream_t stream) {
-    const size_t T = out.stats.triangles;
-    if (!opt.fat_shade || T == 0) { out.tri_fat.release(); return MRT_OK; }
-    MRT_HIP(out.tri_fat.alloc(3 * T));
-    hipLaunchKernelGGL(k_fat_shade, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, stream, out.tri_shade.p, out.normals.p, (uint32_t)T, out.tri_fat.p);
-    out.stats.scene_bytes += (uint64_t)T * 48;
-    return MRT_OK;
-}
-
-
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]) {
     memset(out12, 0, 48);
-    if (sc.num_wnodes == 0 || MRT_WIDE6) return MRT_OK;          // (the 64-byte node of the 6-wide variant is not decoded here)
+    if (sc.num_wnodes == 0) return MRT_OK;
     DevBuf<uint32_t> d; MRT_HIP(d.alloc(12));
     MRT_HIP(hipMemsetAsync(d.p, 0, 48, stream));
     hipLaunchKernelGGL(k_wide_histogram, dim3(cdiv(sc.num_wnodes, 256)), dim3(256), 0, stream, sc.wnodes.p, sc.num_wnodes, d.p);
@@ -1056,7 +1011,7 @@ int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]
 
 SceneView DeviceScene::view() const {
     SceneView v{};
-    v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p; v.tri_fat = tri_fat.n > 1 ? tri_fat.p : nullptr;
+    v.nodes = nodes.p; v.packets = nodes.p ? nodes.p + packets_offset : nullptr; v.tri_shade = tri_shade.p; v.normals = normals.p;
     v.base_color = base_color.p; v.materials = materials.p; v.inst_cols = inst_cols.p; v.geom_base = geom_base.p; v.lights = lights.p;
     v.wnodes = wnodes.p; v.wpackets = wpackets.p; v.num_wnodes = num_wnodes;
     v.num_wpackets = wpackets.p ? (uint32_t)(wpackets.n / WPK) : 0u; v.num_wtlas = wtlas_index.p ? (uint32_t)wtlas_index.n : 0u;
@@ -1215,7 +1170,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     }
     run_tasks(tasks, task_bytes);
     // a refit keeps the tree (and what the statistics say about it): same triangle count as the build that made the 8-wide layout, that layout usable and the only one resident
-    const bool do_refit = refit && opt.wide && out.num_wnodes != 0 && out.wnodes.p && out.wpackets.p && !out.nodes.p && out.refit_triangles == T && T != 0 && !out.wide_levels.empty() && !MRT_WIDE6;
+    const bool do_refit = refit && opt.wide && out.num_wnodes != 0 && out.wnodes.p && out.wpackets.p && !out.nodes.p && out.refit_triangles == T && T != 0 && !out.wide_levels.empty();
     const MRTSceneStats stats_before = out.stats;
     if (!do_refit) { out.wide_levels.clear(); out.refit_triangles = 0; out.refits = 0; }
     out.stats = MRTSceneStats{};
@@ -1244,7 +1199,6 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         return MRT_OK;
     };
     if (T == 0) {       // empty scene: every ray misses
-        out.tri_fat.release();
         if (int rc = upload_normals()) return rc;
         MRT_HIP(out.nodes.alloc(8)); out.packets_offset = 4;
         MRT_HIP(hipStreamSynchronize(stream));
@@ -1315,7 +1269,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.root_lo[0] = h_box[0].x; out.root_lo[1] = h_box[0].y; out.root_lo[2] = h_box[0].z; out.root_hi[0] = h_box[1].x; out.root_hi[1] = h_box[1].y; out.root_hi[2] = h_box[1].z;
         out.commit_ms[2] = since(tw2);
         out.refits++;
-        return build_fat_shade(out, opt, stream);
+        return MRT_OK;
     }
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
     uint32_t n = T32;
@@ -1515,7 +1469,6 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
         out.stats.build_ms += wms;
         out.wide_depth = depth;
-        { uint32_t acc = 0; for (int L = 0; L < 4; L++) { acc += (uint32_t)L < WIDE_LV_MAX ? h_lv[L] : 0u; out.wide_level_end[L] = acc; } }
         out.wide_levels.assign(h_lv.begin(), h_lv.begin() + depth); out.refit_triangles = T;
         if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
@@ -1545,7 +1498,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.stats.scene_bytes += (uint64_t)h_size * 64 + (uint64_t)n * 48;
     }
     out.commit_ms[4] = since(tw4);
-    return build_fat_shade(out, opt, stream);          // (behind the normals' upload on the same stream)
+    return MRT_OK;
 }
 
 }  // namespace mrt

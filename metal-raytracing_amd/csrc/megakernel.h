@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending_node;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
         if (has_tri) {
             float t, U, V, ad;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64, 4) k_megakernel(SceneView s, FrameParams f
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);      // (the scaled form needs one more register: 128 -> spills)
             uint32_t sp = g_mask >> 16;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
-            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }

@@ -23,7 +23,6 @@ struct FrameLane {
     // shadow planes (default path): the light's contribution of bounces 1 and 2 per sample (bounce 0 uses `sample`) and one byte per sample and bounce "the shadow ray got through"
     DevBuf<float4> f_con[2];
     DevBuf<uint8_t> f_lit;               // [sub-frame][pixel][bounce]: one 32-bit word per sample
-    DevBuf<float4> hituv;                // two-level scenes, binned walk: per bounce ray {u, v, global triangle id, t} of the hit that last touched its key (traverse_wide.h MRT_TL_FAT)
     DevBuf<uint4> pairs;                 // two-level scenes, binned walk (tl_pairs): {ray, instance, bound, report tag} queued by the TLAS pass for the BLAS pass; allocated at the first such pass
 };
 constexpr int MAX_FRAMES_IN_FLIGHT = 16;
@@ -74,26 +73,23 @@ struct Renderer {
     int alloc_batch = 0;                 // batch the queues / sample buffers / seed table are sized for
     bool megakernel = false;             // one launch per frame (k_megakernel): lowest latency of a single frame; the wavefront pipeline has the higher throughput
     int mega_slots = 0; size_t mega_slots_for_stack = ~(size_t)0;
-    bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (k_shade<true>); off = the reference's diffuse-only kernel
+    bool materials = false;              // the materials extension: emission, specular lobe, dielectric refraction (shade_entry<MATERIALS>); off = the reference's diffuse-only kernel
     int primary_wide = 2;                // primary rays of a flattened scene: 2 = one ray per lane on the 8-wide layout (inside shade(0) or in their own launch; default), 1 = the 8-wide stream kernel with lane refill (own launch), 0 = the rope walk (scene option rope = 1)
     int persistent = 2;                  // bounce / shadow traversal as persistent waves pulling chunks of rays from a shared counter: 0 never, 1 always, 2 by launch size
     int xcd_counters = 1;                  // pulling traversal launches: 1 = one work counter and one eighth of every sub-frame's rays per XCD (traverse_wide.h XcdRegions), 0 = one counter for all
     int hit_lds = 1;                     // pulling traversal launches of flattened scenes: a lane's closest hit keeps U, V, |det| and id in LDS; a finished ray is reported without re-testing its triangle (traverse_wide.h StreamExt)
-    int shade_pack = 1;                  // k_shade of bounces >= 1 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
-    int tile_walk = 0;                   // flattened scenes, primary rays inside shade(0): the 64 rays of a tile walk the top levels of the 8-wide tree together (traverse_wide_tile.h)
-    int pool = 0;                        // pulling traversal launches of flattened scenes: triangle tests pooled across the lanes of a wave (traverse_wide_pool.h)
-    int lds_top = 0;                     // the same launches read the top of the 8-wide tree from LDS: 1 = levels 0..1, a copy per wave (64-thread workgroups); 2 = levels 0..2, one copy per 256-thread workgroup; 3 = levels 0..1 per 256-thread workgroup; 4 = 256-thread workgroups, nothing staged (A/B of the workgroup shape alone)
-    int wave_slots_x = 0; int slots_x_key = -1;      // wave slots of the variant kernel those two options select, and what they were computed for
+    int shade_pack = 1;                  // k_shade of bounces >= 1 compacts the hits of its queue in LDS and shades them on full waves (k_shade_pack)
+    int wave_slots_x = 0; int slots_x_key = -1;      // wave slots of that kernel (k_trace_mixed_wide_persist_x), and the LDS size they were computed for
     int persist_chunk = 256;             // rays per pull (upper bound; small queues pull less, see render())
     int wave_slots = 7168;               // resident waves the persistent launch is sized for (occupancy query at the first draw)
     bool wave_slots_user = false;        // set through the option: keep it
     size_t slots_for_stack = ~(size_t)0;
     int alloc_planes(FrameLane &L);
     bool tail_accumulate = true;         // the last passes of a draw (one per lane) are accumulated in one launch after the join instead of one after the other
-    int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade<..., TRACE0>): no hit / direction records, one launch less per pass
+    int fuse_primary = 1;                // the primary rays are generated, traced and shaded in ONE launch (k_shade_primary): no hit / direction records, one launch less per pass
     int shadow_planes = 1;               // the light's contribution per pixel and bounce + one byte per shadow ray that got through, instead of a contribution queue and a read-modify-write of the sample buffer (renderer.hip k_accumulate_planes)
     int equal_passes = 1;                // a draw's frames go in passes of equal size (20 frames at frame_batch 8: 7 + 7 + 6); 0: full passes first (8 + 8 + 4) — measured worse
-    int frame_bundle = 1;                // bounce 0 of a multi-frame pass: 1 = a wave of k_shade<.., TRACE0> takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 2 = and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h; flattened scenes)
+    int frame_bundle = 1;                // bounce 0 of a multi-frame pass: a wave of k_shade_primary takes 8 slots x 8 sub-frames (FrameParams::frame_bundle)
     int stream_stride = 2;               // the static split deals 64-ray batches round-robin to the waves (BatchStride) instead of one contiguous range each: 0 never, 1 always, 2 = a shard's launches (with one round of waves)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
     int tl_pair_cap = 0;                 // test aid: > 0 bounds the pair queue (pushes beyond it walk their instance in place); 0 = one pair per virtual ray

@@ -30,9 +30,7 @@
 #include "traverse.h"
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
-#include "traverse_wide_pool.h"
-#include "traverse_wide_tile.h"
-#include "traverse_wide_bundle.h"
+#include "shade.h"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -40,59 +38,9 @@
 namespace mrt {
 namespace {
 
-struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + bounce
-    int32_t width, height;
-    uint32_t frameIndex;        // accumulation weight (Raytracing.metal:395-401)
-    uint32_t sampleIndex;       // Halton index = seed offset + sampleIndex (:202); == frameIndex unless sample-sharded
-    int32_t lightCount;
-    float4 cam_pos, cam_right, cam_up, cam_fwd;
-    int32_t shard_rank, shard_world;
-    int32_t tiles_x, tiles_local;
-    int32_t bounce, max_bounces;
-    // frame batching: one pass of the pipeline carries `batch` consecutive frames.  Sub-frame s uses Halton index
-    // sampleIndex + s (the offset is baked into its copy of the seed table), slots [s * capacity, (s + 1) * capacity)
-    // of the primary queue, of the seed table and of the sample buffer / contribution planes (a SAMPLE INDEX = s * capacity + slot: per-pixel state of a pass is laid
-    // out by the shard's own slots, so a rank of N holds 1/N of it and a wave's 8x8 tile is 64 consecutive entries); k_accumulate applies the sub-frames in order.
-    uint32_t npix, capacity;
-    int32_t batch;
-    // throughput chain (fused pipeline, diffuse-only, max_bounces <= 3, <= 65 536 resource slots): a bounce ray carries the resource slots of the surfaces its path has left
-    // (16 bits each, in the tmax word — always +inf for a bounce ray, and every traversal kernel takes it as such) instead of a 16-byte throughput record; the next
-    // shade multiplies the same base colours in the same order (Raytracing.metal:339), so the floats are the ones the record would have held
-    int32_t chain;
-    uint32_t pack_range;            // k_shade<.., PACK>: queue entries per workgroup (a multiple of the workgroup size; the host sizes it by the launch: SHADE_PACK_RANGE for large queues, less for small ones so that the grid still fills the chip)
-    int32_t tile_walk;              // k_shade<.., TRACE0 = 2>: the tile's primary rays walk the top of the tree together (traverse_wide_tile.h); the launch then carries TILE_FRONT_WORDS more words of LDS per wave
-    uint32_t wide_stack_words;      // k_shade<.., TRACE0 = 2>: 32-bit words of LDS stack per wave (the scene's wide-tree depth x WIDE_STACK_LEVEL_BYTES / 4)
-    // k_shade, bounce 0 of a pass of several frames (renderer option frame_bundle): a wave takes bundle_per_wave slots x bundle_w sub-frames — the rays of one pixel side by side, bundle_w
-    // = batch / ceil(batch / 8) rounded up of them (8 for passes of 8, 16, 32; 7 for 7: nine bundles in a wave and one idle lane) — instead of the 64 slots of one tile in one sub-frame;
-    // the launch is then one grid row of ceil(capacity x bundle_groups / bundle_per_wave) waves.  0 = off; 2 = and each bundle walks the tree as one (traverse_wide_bundle.h: bundle_w = 8 only)
-    int32_t frame_bundle;
-    uint32_t bundle_w, bundle_groups, bundle_per_wave, bundle_magic;      // bundle_magic = ceil(65536 / bundle_w): lane / bundle_w = lane * bundle_magic >> 16 for lane < 64
-    // Halton values of bounce 0 from a table (Renderer::halton_tab): halton_tab[(d - 1) * halton_n + (i - halton_w0)] = halton_dev(i, d) for the dimensions d = 1 .. 6 of the pixel jitter's
-    // second component, the light pick, the area light's point and the first hemisphere sample (Raytracing.metal:203, :272, :284-285, :384-385), filled by halton_dev itself.  The
-    // recurrence is ~18 % of the VALU cycles of k_shade<.., TRACE0> (up to 13 digits per value, a quarter-rate 32-bit multiply per pair of digits); a bundled wave reads the values
-    // of a pixel's sub-frames — consecutive indices — from one or two cache lines instead.  nullptr (passes of one frame, narrow bundles, an index outside the window): the recurrence.
-    const float *halton_tab; uint32_t halton_w0, halton_n;
-};
-constexpr uint32_t HALTON_TAB_DIMS = 6, HALTON_TAB_SPAN = (1u << 20) + (1u << 16);      // seed offsets are below 2^20 (Renderer.swift:259): the window serves 2^16 frames before it moves
-MRT_DEV float halton_b0(const FrameParams &fp, int idx, int d /* 1 .. 6 */) {
-    const uint32_t j = (uint32_t)idx - fp.halton_w0;
-    if (fp.halton_tab != nullptr && j < fp.halton_n) return fp.halton_tab[(size_t)(d - 1) * fp.halton_n + j];
-    return halton_dev(idx, d);
-}
 __global__ void k_halton_table(float *__restrict__ tab, uint32_t w0, uint32_t n) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) tab[(size_t)blockIdx.y * n + j] = halton_dev((int)(w0 + j), (int)blockIdx.y + 1);
-}
-
-
-// local slot -> pixel: one wave = one 8x8 tile (Renderer.swift:295-300), tiles dealt round-robin to shards
-MRT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, int &x, int &y) {
-    uint32_t lt = slot >> 6, k = slot & 63;
-    if ((int)lt >= fp.tiles_local) return false;
-    uint32_t tile = lt * (uint32_t)fp.shard_world + (uint32_t)fp.shard_rank;
-    uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
-    x = (int)(tx * 8 + (k & 7)); y = (int)(ty * 8 + (k >> 3));
-    return x < fp.width && y < fp.height;
 }
 
 // seeds[s * n + i] = hash(seed, i) + s: sub-frame s of a batch reads its Halton offset with the sub-frame index already added
@@ -107,20 +55,6 @@ __global__ void k_seed_slots(uint32_t *__restrict__ seeds, FrameParams fp, uint3
     if (slot >= fp.capacity) return;
     int x, y;
     seeds[(size_t)blockIdx.y * fp.capacity + slot] = slot_to_pixel(fp, slot, x, y) ? seed_hash_dev(seed, (uint32_t)y * (uint32_t)fp.width + (uint32_t)x) + blockIdx.y : 0u;
-}
-
-// ------------------------------------------------------------------ primary rays
-// Raytracing.metal:175, :202-221
-MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ seeds, uint32_t sample_index, int x, int y, f3 &org, f3 &dir) {
-    uint32_t offset = q2load(&seeds[sample_index]);                      // :175 (+ sub-frame index)
-    int idx = (int)(offset + fp.sampleIndex);
-    float r0, r1;                                                        // :202-203
-    r0 = halton_dev(idx, 0); r1 = halton_b0(fp, idx, 1);
-    float px = (float)x + r0, py = (float)y + r1;                        // :204
-    float uvx = px / (float)fp.width, uvy = py / (float)fp.height;       // :207
-    uvx = uvx * 2.0f - 1.0f; uvy = uvy * 2.0f - 1.0f;                    // :208
-    dir = normalize3((uvx * mk3(fp.cam_right) + uvy * mk3(fp.cam_up)) + mk3(fp.cam_fwd));   // :216-218
-    org = mk3(fp.cam_pos);                                               // :214
 }
 
 // ------------------------------------------------------------------ traversal launches of the pipeline
@@ -309,24 +243,15 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
     else traverse_wide_stream<false>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, stk_dyn, fetch, emit, wss);
 }
 
-// The pulling launch of flattened scenes with LDS extras (traverse_wide.h StreamExt; renderer options hit_lds, lds_top).  WAVES waves per workgroup share one copy of the
-// top of the tree (TOP: wnodes[0 .. top_n), loaded by the workgroup at its start — a persistent grid pays that once per wave slot); every wave has its own hit words
-// (HIT: 1 KB) and stack.  LDS layout: [top_n nodes][per wave: hit words | stack].  Shadow planes only (`lit`): the default path of the pipeline.
-template <int WAVES, bool HIT, bool TOP>
-__global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist_x(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
+// The pulling launch of flattened scenes with the hit words in LDS (traverse_wide.h StreamExt; renderer option hit_lds, default): every wave has its own hit
+// words (1 KB + the root's hit bits of the prefetched batch) in front of its stack.  Shadow planes only (`lit`): the default path of the pipeline.
+__global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_persist_x(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
                                                                 const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes, uint32_t top_n, uint32_t stack_words) {
+                                                                uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes) {
     extern __shared__ uint32_t lds_dyn[];
-    const uint32_t wv = WAVES == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: the wave's LDS base is a scalar
-    if (TOP) {
-        float4 *const dst = reinterpret_cast<float4 *>(lds_dyn);
-        for (uint32_t i = threadIdx.x; i < top_n * WNODE_STRIDE; i += 64u * WAVES) dst[i] = s.wnodes[i];
-        __syncthreads();
-    }
-    uint32_t *const mine = lds_dyn + (TOP ? top_n * WNODE_STRIDE * 4u : 0u) + wv * ((HIT ? HIT_LDS_WORDS : 0u) + stack_words);
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
-    if ((blockIdx.x * WAVES + wv) * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once (after the workgroup's barrier)
+    if (blockIdx.x * chunk >= n) return;            // more waves than chunks (small queue): the surplus leaves at once
     auto fetch = [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -337,33 +262,8 @@ __global__ void __launch_bounds__(64 * WAVES, MRT_WIDE_STREAM_WAVES) k_trace_mix
             if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
             else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
         };
-    StreamExt<HIT, TOP> ext{reinterpret_cast<float *>(mine), reinterpret_cast<const float4 *>(lds_dyn), top_n, reinterpret_cast<const uint8_t *>(mine + 256u), mine + 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u)};
-    if (StreamExt<HIT, TOP>::nh_lut) nh_lut_fill(mine + 256u);
-    traverse_wide_stream<false, false, false, NoPairs, StreamExt<HIT, TOP>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, mine + (HIT ? HIT_LDS_WORDS : 0u), fetch, emit, nullptr, NoPairs{}, ext);
-}
-
-// The pulling launch of flattened scenes with the triangle tests pooled across the lanes of a wave (traverse_wide_pool.h; renderer option pool).  Shadow planes only.
-#ifndef MRT_POOL_WAVES
-#define MRT_POOL_WAVES 5          // waves per SIMD the kernel is compiled for: its LDS (4 KB of pool + the stack per wave) admits 19 waves per CU at DragonScene's depth
-#endif
-__global__ void __launch_bounds__(64, MRT_POOL_WAVES) k_trace_mixed_wide_pool(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, float4 *__restrict__ hits,
-                                                                const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint32_t subframes) {
-    extern __shared__ uint32_t lds_dyn[];
-    const unsigned long long c = *counts;
-    const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
-    if (blockIdx.x * chunk >= n) return;
-    traverse_wide_pool(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, lds_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
-            const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
-            A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
-            if (!sh) A.w = __builtin_inff();          // a bounce ray's tmax word may carry the throughput chain
-            else tag = __float_as_uint(B.w);          // shadow planes: the ray reports to its pixel's byte
-        },
-        [&](uint32_t j, bool is_any, bool hit, const TravHit &h) {
-            if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }
-            else qstore(&hits[j], hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)));
-        });
+    StreamExt<true> ext{reinterpret_cast<float *>(lds_dyn), lds_dyn + 256u};
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true>>(s, XcdRegions{work, n_next, n, chunk, subframes, blockIdx.x & 7u}, lds_dyn + HIT_LDS_WORDS, fetch, emit, nullptr, NoPairs{}, ext);
 }
 
 // The static split of small launches (k_trace_mixed_wide_stream) with the hit words in LDS (renderer option hit_lds): flattened scenes, shadow planes.
@@ -387,11 +287,10 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     if (even_waves) rays_per_wave = max(64u, ((n + even_waves - 1u) / even_waves + 63u) & ~63u);
     const uint32_t begin = blockIdx.x * rays_per_wave;
     if (begin >= n) return;
-    StreamExt<true, false> ext{reinterpret_cast<float *>(lds_dyn), nullptr, 0u, reinterpret_cast<const uint8_t *>(lds_dyn + 256u), lds_dyn + 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u)};
-    if (StreamExt<true, false>::nh_lut) nh_lut_fill(lds_dyn + 256u);
+    StreamExt<true> ext{reinterpret_cast<float *>(lds_dyn), lds_dyn + 256u};
     // stream_stride: the (n + rays_per_wave - 1) / rays_per_wave waves that have work take the queue's 64-ray batches round-robin instead of one contiguous range each
     const BatchStride src = strided ? BatchStride{blockIdx.x * 64u, 64u * ((n + rays_per_wave - 1u) / rays_per_wave), n} : BatchStride{begin, 64u, min(n, begin + rays_per_wave)};
-    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true, false>>(s, src, lds_dyn + HIT_LDS_WORDS,
+    traverse_wide_stream<false, false, false, NoPairs, StreamExt<true>>(s, src, lds_dyn + HIT_LDS_WORDS,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             const bool sh = i >= n_next; tag = sh ? i - n_next : i; is_any = sh ? 1u : 0u;
             A = qload(sh ? &srayA[tag] : &rayA[tag]); B = qload(sh ? &srayB[tag] : &rayB[tag]);
@@ -464,435 +363,6 @@ __global__ void __launch_bounds__(64, 5) k_trace_primary_wide_stream(SceneView s
                 hits[slot] = hit ? make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
             });
     }
-}
-
-// Queue compaction.  Lanes ballot, waves post their two counts to LDS, and ONE packed 64-bit atomic per
-// workgroup reserves the output ranges of both queues ({next rays: low word, shadow rays: high word}):
-// a single counter word sustains only ~88 returning atomics/us on gfx950 (MI355X_MICROARCH.md, row
-// "dequeue"), so per-wave atomics on 32 K waves would cost more than the shading itself.
-#ifndef MRT_SHADE_THREADS
-#define MRT_SHADE_THREADS 256
-#endif
-#ifndef MRT_SHADE_WAVES
-#define MRT_SHADE_WAVES 6     // waves per SIMD k_shade is compiled for: it needs 76-78 registers; capped at 72 (7 waves) it spills 16-48 bytes and the frame is 4 % slower, at 64 (8 waves) 6 % slower
-#endif
-#ifndef MRT_SHADE_WIDE_WAVES
-#define MRT_SHADE_WIDE_WAVES 5     // k_shade<.., TRACE0 = 2>: the 8-wide walk holds a node (20 registers) and a packet (10) on top of the shading state
-#endif
-constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
-constexpr int SHADE_WAVES = SHADE_THREADS / 64;
-
-// ------------------------------------------------------------------ shade (Raytracing.metal:249-391)
-#ifndef MRT_SHADE_PACK_RANGE
-#define MRT_SHADE_PACK_RANGE 4096
-#endif
-constexpr uint32_t SHADE_PACK_RANGE = MRT_SHADE_PACK_RANGE;      // k_shade<.., PACK>: queue entries per workgroup, at most (FrameParams::pack_range)
-template <bool MATERIALS, bool CHAIN, bool PLANES = false, int TRACE0 = 0, bool PAIRS = false, bool PACK = false>      // PACK (bounces >= 1, renderer option shade_pack): half the entries of a bounce queue are rays that missed — their lanes sit out the whole kernel (41 % of the lanes per VALU instruction, profiles/r05_summary.json).  A workgroup then takes SHADE_PACK_RANGE consecutive entries, compacts the HITS into a ring in LDS 256 entries at a time and shades 256 of them per round, every lane busy; TRACE0 (bounce 0 of flattened scenes, Renderer::fuse_primary): the primary ray is generated and traced HERE (1: k_trace_primary's body, the rope walk; 2: one ray per lane on the 8-wide layout, traverse_wide_lane, the wave's stack in dynamic LDS) and its hit shaded from registers — no hit record, no direction record, one launch less per pass; PLANES: the light's contribution goes to con[pixel] of this bounce's plane (`scon`) instead of the shadow queue, and nothing is zeroed (shadow planes, Renderer::shadow_planes); CHAIN: FrameParams::chain (compile-time: the flag as a run-time branch cost 40 bytes of spills); PAIRS (two-level scenes, bounces >= 1, renderer option tl_pairs): `hits` holds 64-bit keys (t bits << 32 | global triangle id, ~0 = miss) left by k_tl_top / k_tl_blas instead of hit records — the barycentrics come from re-testing the winning triangle in its instance's object space
-__global__ void __launch_bounds__(SHADE_THREADS, TRACE0 >= 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, const uint32_t *__restrict__ seeds,
-                                              const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr,
-                                              const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,
-                                              float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,
-                                              float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon,
-                                              unsigned long long *__restrict__ count_out /* lo = next rays, hi = shadow rays */,
-                                              float4 *__restrict__ sample_primary /* fused pipeline, bounce 0: regenerate the primary ray, zero the sample */,
-                                              float4 *__restrict__ sample /* MATERIALS: emitted radiance is added here */,
-                                              uint32_t *__restrict__ hint /* TRACE0: per pixel, the packet its primary ray hit last (or nullptr) */) {
-    __shared__ uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES];
-    __shared__ unsigned long long blk_base;
-    // bounce 0 of the fused pipeline: grid = (blocks over one sub-frame's slots, sub-frames); later bounces: the compact queue
-    uint32_t sub = sample_primary ? blockIdx.y : 0u;
-    uint32_t slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
-    bool in_batch = true;
-    if (TRACE0 && fp.frame_bundle) {          // (wave-uniform) thread -> (slot, sub-frame): the lanes 8 b .. 8 b + 7 of a wave are eight sub-frames of ONE slot
-        const uint32_t lane = threadIdx.x & 63u, wave = slot >> 6;
-        const uint32_t bi = (lane * fp.bundle_magic) >> 16, q = wave * fp.bundle_per_wave + bi;          // the lane's bundle: bi-th of its wave, q-th of the launch
-        slot = q / fp.bundle_groups; sub = (q - slot * fp.bundle_groups) * fp.bundle_w + (lane - bi * fp.bundle_w);
-        in_batch = bi < fp.bundle_per_wave && sub < (uint32_t)fp.batch;
-    }
-    const uint32_t i = sub * capacity + slot;
-    uint32_t n = count_in ? (uint32_t)*count_in : capacity;
-    bool active = slot < n && in_batch;
-    int px_x = 0, px_y = 0;
-    uint32_t spix = 0;                   // sample index (seed table, sample buffer, contribution planes)
-    if (sample_primary) {
-        active = active && slot_to_pixel(fp, slot, px_x, px_y);
-        spix = i;                        // sample index = sub * capacity + slot
-        if (active && !PLANES) q2store(&sample_primary[spix], make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // Raytracing.metal:227
-    }
-    float4 H = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)), Bprim = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-    if (TRACE0 == 2 && fp.tile_walk) {          // (wave-uniform) the tile's rays walk the top of the tree together: every lane takes part, also those outside the image
-        extern __shared__ uint32_t shade_stk[];          // SHADE_WAVES x (wide-tree depth x WIDE_STACK_LEVEL_BYTES) + SHADE_WAVES x TILE_FRONT_WORDS words
-        const uint32_t wv_ = threadIdx.x >> 6;
-        uint32_t *const stk = shade_stk + wv_ * fp.wide_stack_words, *const front = shade_stk + SHADE_WAVES * fp.wide_stack_words + wv_ * TILE_FRONT_WORDS;
-        f3 dir = mk3(0.0f, 0.0f, 1.0f);
-        const f3 org = mk3(fp.cam_pos);                  // :214 — the same for every ray
-        uint32_t pixel = 0, guess = 0xFFFFFFFFu, seed = 0xFFFFFFFFu; float t0 = __builtin_inff();
-        if (active) {
-            f3 org_;
-            primary_ray(fp, seeds, spix, px_x, px_y, org_, dir);
-            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
-            if (hint != nullptr) {
-                pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-                guess = hint[pixel];
-                if (guess < s.num_wpackets) {
-                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
-                    float t, U, V, ad;
-                    if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
-                }
-            }
-        }
-        TravHit h;
-        const bool hit = traverse_wide_tile<true>(s, active, org, dir, t0, seed, h, stk, fp.wide_stack_words, front);
-        if (active) {
-            if (hint != nullptr && h.pk != guess) hint[pixel] = h.pk;
-            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
-        }
-    }
-    else if (TRACE0 == 2 && fp.frame_bundle == 2) {          // (wave-uniform) the eight sub-frames of a slot walk the tree as one bundle (traverse_wide_bundle.h): every lane takes part
-        extern __shared__ uint32_t shade_stk[];
-        uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
-        f3 dir = mk3(0.0f, 0.0f, 1.0f);
-        const f3 org = mk3(fp.cam_pos);                  // :214 — the same for every ray
-        uint32_t pixel = 0, guess = 0xFFFFFFFFu, seed = 0xFFFFFFFFu; float t0 = __builtin_inff();
-        if (active) {
-            f3 org_;
-            primary_ray(fp, seeds, spix, px_x, px_y, org_, dir);
-            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
-            if (hint != nullptr) {
-                pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-                guess = hint[pixel];
-                if (guess < s.num_wpackets) {
-                    const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
-                    float t, U, V, ad;
-                    if (tri_test(pk[0], pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
-                }
-            }
-        }
-        TravHit h;
-        const bool hit = traverse_wide_bundle<true>(s, active, org, dir, t0, seed, h, stk);
-        if (active) {
-            if (hint != nullptr && h.pk != guess) hint[pixel] = h.pk;
-            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
-        }
-    }
-    else if (TRACE0) {
-        if (active) {                        // k_trace_primary<false>, statement by statement
-            f3 org, dir;
-            primary_ray(fp, seeds, spix, px_x, px_y, org, dir);
-            Bprim = make_float4(dir.x, dir.y, dir.z, __uint_as_float(spix));
-            TravHit h;
-            bool hit;
-            if (TRACE0 == 3) {            // two-level scene: both levels on one stack, one ray per lane (traverse_wide_lane_two_level); the hint is (packet | instance << 24)
-                extern __shared__ uint32_t shade_stk[];
-                uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
-                if (hint != nullptr) {
-                    const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-                    const uint32_t guess = hint[pixel];
-                    float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
-                    const uint32_t gpk = guess & 0xFFFFFFu, gin = guess >> 24;
-                    if (guess != 0xFFFFFFFFu && gin < s.num_inst) {
-                        const InstanceDev &I = s.inst[gin];
-                        if (gpk - I.packet_base < I.ntri) {           // a legal guess names a packet of its instance's BLAS (a stale one — moved instances — is one wasted test or none)
-                            const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)gpk;
-                            float t, U, V, ad;
-                            if (tri_test(pk[0], pk[1], pk[2], to_object_point(I, org), to_object_dir(I, dir), 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; }
-                        }
-                    }
-                    hit = traverse_wide_lane_two_level<true>(s, org, dir, t0, seed, h, stk);
-                    if (hit && h.pk != guess) hint[pixel] = h.pk;
-                }
-                else hit = traverse_wide_lane_two_level<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk);
-            }
-            else if (TRACE0 == 2) {
-                extern __shared__ uint32_t shade_stk[];          // SHADE_WAVES x wide-tree depth x WIDE_STACK_LEVEL_BYTES
-                uint32_t *const stk = shade_stk + (threadIdx.x >> 6) * fp.wide_stack_words;
-                if (hint != nullptr) {
-                    const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-                    const uint32_t guess = hint[pixel];
-                    float t0 = __builtin_inff(); uint32_t seed = 0xFFFFFFFFu;
-                    TravHit sh_; sh_.U = 0.0f; sh_.V = 0.0f; sh_.ad = 1.0f; sh_.gid = 0xFFFFFFFFu;
-                    if (guess < s.num_wpackets) {
-                        const float4 *__restrict__ pk = s.wpackets + WPK * (size_t)guess;
-                        const float4 q0_ = pk[0];
-                        float t, U, V, ad;
-                        if (tri_test(q0_, pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { t0 = t; seed = guess; sh_.U = U; sh_.V = V; sh_.ad = ad; sh_.gid = __float_as_uint(q0_.w); }
-                    }
-#if MRT_LANE_HIT_LDS
-                    hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk, nullptr, 0, reinterpret_cast<float *>(shade_stk + SHADE_WAVES * fp.wide_stack_words + (threadIdx.x >> 6) * 256u), &sh_);
-#else
-                    hit = traverse_wide_lane<true>(s, org, dir, t0, seed, h, stk);
-#endif
-                    if (h.pk != guess) hint[pixel] = h.pk;
-                }
-                else hit = traverse_wide_lane<false>(s, org, dir, __builtin_inff(), 0xFFFFFFFFu, h, stk);
-            }
-            else if (hint != nullptr) {
-                const uint32_t pixel = (uint32_t)px_y * (uint32_t)fp.width + (uint32_t)px_x;
-                const uint32_t guess = hint[pixel];
-                h.t = __builtin_inff(); h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu; h.pk = 0xFFFFFFFFu;
-                if (guess < s.num_tris) {
-                    const float4 *__restrict__ pk = s.packets + 3 * (size_t)guess;
-                    const float4 q0 = pk[0];
-                    float t, U, V, ad;
-                    if (tri_test(q0, pk[1], pk[2], org, dir, 0.0f, __builtin_inff(), t, U, V, ad)) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = __float_as_uint(q0.w); h.pk = guess; }
-                }
-                hit = traverse<false, false, false, true>(s, org, dir, 0.0f, h.t, h);
-                if (h.pk != guess) hint[pixel] = h.pk;
-            }
-            else hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
-            if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
-        }
-    }
-    // PAIRS: a 64-bit key {t bits, global triangle id} left by the TLAS / BLAS passes becomes a hit record
-    auto pairs_hit = [&](const uint32_t i, const unsigned long long key) -> float4 {
-        const float4 uv = (MRT_TL_HITUV && key != ~0ull) ? qload(&thr[i]) : make_float4(0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu), 0.0f);      // (PAIRS: `thr` is the lane's hit-barycentrics array, written by the pass that set the key)
-        if (key != ~0ull && MRT_TL_HITUV && __float_as_uint(uv.z) == (uint32_t)key) return make_float4(__uint_as_float((uint32_t)(key >> 32)), uv.x, uv.y, uv.z);      // left by the winning hit itself
-        if (key != ~0ull) {          // (another pair of the same ray wrote its barycentrics last — rare — or the round-4 form: test the winner again)
-            const uint32_t g = (uint32_t)key;
-            const InstanceDev &I = s.inst[instance_of_gid(s, g)];
-            const uint32_t pk = s.tri_packet[I.ts_base + (g - I.gid_base)];
-            const float4 Aw = qload(&rayA[i]), Bw = qload(&rayB[i]);
-            const float4 *__restrict__ q = s.wpackets + WPK * (size_t)pk;
-            float t_, U, V, ad;
-            (void)tri_test(q[0], q[1], q[2], to_object_point(I, mk3(Aw)), to_object_dir(I, mk3(Bw)), 0.0f, __builtin_inff(), t_, U, V, ad);      // the traversal's own test of the winner: the same U, V, |det|
-            return make_float4(__uint_as_float((uint32_t)(key >> 32)), U / ad, V / ad, __uint_as_float(g));
-        }
-        return make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-    };
-    if (TRACE0) {}
-    else if (active && PAIRS && !PACK) H = pairs_hit(i, __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + i));
-    else if (active && !PACK) H = qload(&hits[i]);
-    // everything after the hit record: one entry per thread (i, its hit, whether there is one) — called once, or per round of a packing workgroup
-    auto shade_entry = [&](const uint32_t i, const float4 H, bool active) {
-    uint32_t gid = __float_as_uint(H.w);
-    active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
-    bool want_shadow = false, want_next = false;
-    f3 P = mk3(0, 0, 0), nrm = mk3(0, 1, 0), ldir = mk3(0, 1, 0), lcol = mk3(0, 0, 0), color = mk3(0, 0, 0), ndir = mk3(0, 1, 0), norg = mk3(0, 0, 0);
-    float ldist = 0.0f; uint32_t pix = 0;
-    bool special = false;                // next ray comes from a specular / dielectric lobe (materials extension): queued behind the diffuse ones
-    uint32_t chain_in = 0, chain_out = 0;   // throughput chain (FrameParams::chain)
-    if (active) {
-        float4 A, B, C;
-        if (sample_primary) {
-            A = make_float4(fp.cam_pos.x, fp.cam_pos.y, fp.cam_pos.z, __builtin_inff());   // :214
-            B = TRACE0 ? Bprim : qload(&rayB[i]);                        // direction | sample index, written by the primary trace
-            C = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                     // :226
-        } else if (CHAIN) {
-            A = qload(&rayA[i]); B = qload(&rayB[i]);
-            const uint32_t ch = __float_as_uint(A.w);          // slots of bounce 0 (low half) and, at bounce 2, of bounce 1 (high half)
-            chain_in = ch;
-            C = s.base_color[ch & 0xFFFFu];                     // (1, 1, 1) * surf0 == surf0
-            if (fp.bounce >= 2) { const float4 s1 = s.base_color[ch >> 16]; C = make_float4(C.x * s1.x, C.y * s1.y, C.z * s1.z, 0.0f); }
-            A.w = __builtin_inff();
-        } else { A = qload(&rayA[i]); B = qload(&rayB[i]); C = qload(&thr[i]); }
-        pix = __float_as_uint(B.w);
-        uint32_t inst, geom, rec = gid, vb = 0;
-        if (s.num_inst) {           // two-level scene: the shading record belongs to the BLAS, the instance is found from the global triangle id
-            inst = instance_of_gid(s, gid);
-            const InstanceDev &I = s.inst[inst];
-            rec = I.ts_base + (gid - I.gid_base); vb = I.vbase;
-        } else inst = 0;
-        float bu = H.y, bv = H.z;
-        P = mk3(A) + mk3(B) * H.x;                                       // :261
-        float bw = 1.0f - bu - bv;                                       // :63-64
-        f3 n_obj;
-        if (s.tri_fat) {            // the record's three normals sit beside its instance / geometry word: one gather (scene option fat_shade)
-            const float4 *__restrict__ fr = s.tri_fat + 3 * (size_t)rec;
-            const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
-            const uint32_t tw = __float_as_uint(f0.w);
-            if (!s.num_inst) inst = tw >> 16;
-            geom = tw & 0xFFFFu;
-            n_obj = (bu * mk3(f1) + bv * mk3(f2)) + bw * mk3(f0);       // :66-72
-        } else {
-            const uint4 ts = s.tri_shade[rec];
-            if (!s.num_inst) inst = ts.w >> 16;
-            geom = ts.w & 0xFFFFu;
-            n_obj = (bu * mk3(s.normals[vb + ts.y]) + bv * mk3(s.normals[vb + ts.z])) + bw * mk3(s.normals[vb + ts.x]);   // :66-72
-        }
-        f3 c0 = mk3(s.inst_cols[inst * 4 + 0]), c1 = mk3(s.inst_cols[inst * 4 + 1]), c2 = mk3(s.inst_cols[inst * 4 + 2]);
-        f3 n_w = mk3((c0.x * n_obj.x + c1.x * n_obj.y) + c2.x * n_obj.z,
-                     (c0.y * n_obj.x + c1.y * n_obj.y) + c2.y * n_obj.z,
-                     (c0.z * n_obj.x + c1.z * n_obj.y) + c2.z * n_obj.z);   // :267
-        nrm = normalize3(n_w);                                           // :268
-        const uint32_t rslot = inst * (uint32_t)s.max_sub + geom;
-        f3 surf = mk3(s.base_color[rslot]);  // :262-269
-        if (CHAIN) chain_out = fp.bounce == 0 ? rslot : (chain_in & 0xFFFFu) | (rslot << 16);
-        int idx = (int)(q2load(&seeds[pix]) + fp.sampleIndex);         // pix = sub * npix + pixel: the table entry already holds + sub
-        const int dim0 = 2 + fp.bounce * 5;
-        norg = P + nrm * 1e-3f;                                          // :350, :390
-        color = mk3(C);
-        bool diffuse = true;
-        if (MATERIALS) {
-            // the materials extension (renderer option materials = 1; not in raytracingKernel — README.md:8 lists it as open work; the
-            // fields are ShaderTypes.h:99-107).  Semantics: DESIGN.md "Materials extension"; the CPU checker restates this block expression by expression.
-            const float4 *__restrict__ mp = s.materials + 3 * (size_t)(inst * (uint32_t)s.max_sub + geom);
-            const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-            const f3 em = color * mk3(m2);
-            // bounce 0: pix == spix and the zero above went through `sample_primary`; the emission follows through the SAME pointer (both are
-            // __restrict__: two names for one address would leave the order of the two stores to the compiler)
-            if (sample_primary) sample_primary[pix] = make_float4(0.0f + em.x, 0.0f + em.y, 0.0f + em.z, 0.0f);
-            else { const float4 acc = sample[pix]; sample[pix] = make_float4(acc.x + em.x, acc.y + em.y, acc.z + em.z, 0.0f); }
-            const float ul = halton_dev(idx, 2 + 5 * fp.max_bounces + fp.bounce);
-            const f3 spec = mk3(m1);
-            const float kd = fmaxf(surf.x, fmaxf(surf.y, surf.z)), ks = fmaxf(spec.x, fmaxf(spec.y, spec.z));
-            const float dis = m0.w, ns = m1.w, ni = m2.w;
-            const float trn = (dis > 0.0f && dis < 1.0f && ni > 0.0f) ? 1.0f - dis : 0.0f;
-            if (ul < trn) {                                              // dielectric interface
-                const float u2 = ul / trn;
-                const f3 dir = mk3(B);
-                const float cd = dot3(dir, nrm);
-                const bool entering = cd < 0.0f;
-                const f3 nn = entering ? nrm : neg3(nrm);
-                const float eta = entering ? 1.0f / ni : ni;
-                const float cosi = entering ? -cd : cd;
-                const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
-                float r0 = (1.0f - ni) / (1.0f + ni); r0 = r0 * r0;
-                float F = 1.0f, cost = 0.0f;
-                if (sin2t < 1.0f) { cost = __builtin_sqrtf(1.0f - sin2t); const float c = entering ? cosi : cost; const float x = 1.0f - c; const float x2 = x * x; F = r0 + (1.0f - r0) * ((x2 * x2) * x); }
-                f3 nd;
-                if (u2 < F) { nd = dir + nn * (2.0f * cosi); norg = P + nn * 1e-3f; }
-                else { nd = dir * eta + nn * (eta * cosi - cost); norg = P + nn * -1e-3f; }
-                ndir = normalize3(nd);
-                diffuse = false; special = true;
-                want_next = fp.bounce + 1 < fp.max_bounces;
-            } else {
-                const float ud = trn > 0.0f ? (ul - trn) / (1.0f - trn) : ul;
-                const float ps = (ks > 0.0f && ns > 0.0f) ? ks / (ks + kd) : 0.0f;
-                if (ud < ps) {                                           // specular lobe
-                    const float hx = halton_dev(idx, dim0 + 3), hy = halton_dev(idx, dim0 + 4);
-                    const float a2 = 2.0f / (ns + 2.0f);
-                    const float ct2 = (1.0f - hy) / (1.0f + (a2 - 1.0f) * hy);
-                    const float ct = __builtin_sqrtf(ct2), st = __builtin_sqrtf(1.0f - ct2);
-                    float sp_, cp_; sincos_2pi_dev(hx, sp_, cp_);
-                    const f3 hw = align_hemisphere_dev(mk3(st * cp_, ct, st * sp_), nrm);
-                    const f3 dir = mk3(B);
-                    const float dh = dot3(dir, hw);
-                    const f3 wi = dir - hw * (2.0f * dh);
-                    diffuse = false; special = true;
-                    if (dot3(wi, nrm) > 0.0f) {
-                        color = color * (spec * (1.0f / ps));
-                        ndir = normalize3(wi);
-                        want_next = fp.bounce + 1 < fp.max_bounces;
-                    }                                                    // else: sampled below the surface, the path is absorbed
-                } else if (ps > 0.0f) surf = surf * (1.0f / (1.0f - ps));
-            }
-        }
-        if (diffuse) {
-        float ls = TRACE0 ? halton_b0(fp, idx, 2) : halton_dev(idx, dim0 + 0);               // :272 (TRACE0: bounce 0 — dimensions 2 .. 6, from the table when there is one)
-        int li = min((int)(ls * (float)fp.lightCount), fp.lightCount - 1);   // :273
-        const LightDev L = s.lights[li];
-        int ltype = __float_as_int(L.position.w);
-        if (ltype == MRTLightTypeAreaLight) {                            // :281-290, :94-128
-            float ax = (TRACE0 ? halton_b0(fp, idx, 3) : halton_dev(idx, dim0 + 1)) * 2.0f - 1.0f;
-            float ay = (TRACE0 ? halton_b0(fp, idx, 4) : halton_dev(idx, dim0 + 2)) * 2.0f - 1.0f;
-            f3 sp = (mk3(L.position) + mk3(L.right) * ax) + mk3(L.up) * ay;
-            ldir = sp - P;
-            ldist = length3(ldir);
-            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-            ldir = ldir * inv;
-            lcol = mk3(L.color) * (inv * inv);
-            lcol = lcol * saturatef(dot3(neg3(ldir), mk3(L.forward)));
-        } else if (ltype == MRTLightTypeSpotlight) {                     // :292-316
-            ldir = mk3(L.position) - P;
-            ldist = length3(ldir);
-            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-            ldir = ldir * inv;
-            lcol = mk3(0, 0, 0);
-            float spot = dot3(neg3(ldir), mk3(L.dirn));
-            if (spot > L.dirn.w) lcol = (mk3(L.color) * inv) * inv;
-        } else if (ltype == MRTLightTypePointlight) {                    // :317-322
-            ldir = mk3(L.position) - P;
-            ldist = length3(ldir);
-            float inv = 1.0f / (ldist > 1e-3f ? ldist : 1e-3f);
-            ldir = ldir * inv;
-            lcol = (mk3(L.color) * inv) * inv;
-        } else {                                                         // :323-327
-            ldir = neg3(mk3(L.dirn));
-            ldist = __builtin_inff();
-            lcol = mk3(L.color);
-        }
-        lcol = lcol * saturatef(dot3(nrm, ldir));                        // :331
-        lcol = lcol * (float)fp.lightCount;                              // :335
-        color = mk3(C) * surf;                                           // :339
-        want_shadow = length3(lcol) > 0.0001f;                           // :341
-        want_next = fp.bounce + 1 < fp.max_bounces;
-        if (want_next) {
-            float hx = TRACE0 ? halton_b0(fp, idx, 5) : halton_dev(idx, dim0 + 3), hy = TRACE0 ? halton_b0(fp, idx, 6) : halton_dev(idx, dim0 + 4);   // :384-385
-            ndir = align_hemisphere_dev(sample_cosine_hemisphere_dev(hx, hy), nrm);  // :387-388
-        }
-        }
-    }
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // MATERIALS: the block's next rays are queued by lobe class — diffuse first, specular / refracted behind them — so that the waves of the
-    // next traversal launch see rays of one kind (README.md:9 "sorting ... to reduce divergence"; the reference's stub is Raytracing.metal:178-197)
-    const unsigned long long m_sh = __ballot(want_shadow), m_nx = __ballot(want_next && !(MATERIALS && special)), m_sp = MATERIALS ? __ballot(want_next && special) : 0ull;
-    if (lane == 0) { w_shadow[wv] = (uint32_t)__popcll(m_sh); w_next[wv] = (uint32_t)__popcll(m_nx); if (MATERIALS) w_spec[wv] = (uint32_t)__popcll(m_sp); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tn = 0, ts = 0, tp = 0;
-        for (int k = 0; k < SHADE_WAVES; k++) { uint32_t a = w_next[k], b = w_shadow[k]; w_next[k] = tn; w_shadow[k] = ts; tn += a; ts += b; }
-        if (MATERIALS) for (int k = 0; k < SHADE_WAVES; k++) { uint32_t a = w_spec[k]; w_spec[k] = tn + tp; tp += a; }
-        blk_base = (tn | ts | tp) ? atomicAdd(count_out, ((unsigned long long)ts << 32) | (tn + tp)) : 0ull;
-    }
-    __syncthreads();
-    const unsigned long long base = blk_base;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    if (want_shadow) {
-        uint32_t ss = (uint32_t)(base >> 32) + w_shadow[wv] + (uint32_t)__popcll(m_sh & lt);
-        f3 so = P + nrm * 1e-3f;                                         // :350
-        f3 con = lcol * color;                                           // :372
-        qstore(&srayA[ss], make_float4(so.x, so.y, so.z, ldist - 1e-3f));        // :356
-        qstore(&srayB[ss], make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix)));
-        if (PLANES) q2store(&scon[pix], make_float4(con.x, con.y, con.z, 0.0f)); else qstore(&scon[ss], make_float4(con.x, con.y, con.z, 0.0f));
-    }
-    if (want_next) {
-        const bool sp = MATERIALS && special;
-        uint32_t ns = (uint32_t)base + (sp ? w_spec[wv] + (uint32_t)__popcll(m_sp & lt) : w_next[wv] + (uint32_t)__popcll(m_nx & lt));
-        qstore(&nrayA[ns], make_float4(norg.x, norg.y, norg.z, CHAIN ? __uint_as_float(chain_out) : __builtin_inff()));      // :390 (tmax = inf either way, see FrameParams::chain)
-        qstore(&nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
-        if (!CHAIN) qstore(&nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
-    }
-    };          // shade_entry
-    if constexpr (PACK) {
-        __shared__ uint32_t p_idx[2 * SHADE_THREADS], p_w[SHADE_WAVES];
-        __shared__ float4 p_hit[2 * SHADE_THREADS];
-        const float4 miss = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        const uint32_t begin = blockIdx.x * fp.pack_range, end = min(n, begin + fp.pack_range);
-        const uint32_t lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-        uint32_t head = 0, tail = 0, cur = begin;                  // the ring's positions only ever grow; entry k lives in slot k & (2 * SHADE_THREADS - 1); all three are workgroup-uniform
-        for (;;) {
-            const uint32_t pending = tail - head;
-            if (pending < (uint32_t)SHADE_THREADS && cur < end) {          // room for 256 more: the next 256 entries' hits join the ring
-                const uint32_t e = cur + threadIdx.x;
-                float4 He = miss;
-                if (PAIRS) {          // the entry's key: kept as two words of the record, turned into a hit record in the round that shades it
-                    const unsigned long long key = e < end ? __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(hits) + e) : ~0ull;
-                    He = make_float4(__uint_as_float((uint32_t)key), __uint_as_float((uint32_t)(key >> 32)), 0.0f, __uint_as_float(key != ~0ull ? 0u : 0xFFFFFFFFu));
-                }
-                else if (e < end) He = qload(&hits[e]);
-                const bool a = __float_as_uint(He.w) != 0xFFFFFFFFu;
-                const unsigned long long m = __ballot(a);
-                if (lane_ == 0) p_w[wv_] = (uint32_t)__popcll(m);
-                __syncthreads();
-                uint32_t off = 0, tot = 0;
-                for (int k = 0; k < SHADE_WAVES; k++) { const uint32_t c = p_w[k]; if ((uint32_t)k < wv_) off += c; tot += c; }
-                if (a) { const uint32_t pos = (tail + off + (uint32_t)__popcll(m & ((1ull << lane_) - 1ull))) & (2u * SHADE_THREADS - 1u); p_idx[pos] = e; p_hit[pos] = He; }
-                __syncthreads();
-                tail += tot; cur += SHADE_THREADS;
-                continue;
-            }
-            if (pending == 0u) break;
-            const uint32_t take = min(pending, (uint32_t)SHADE_THREADS);
-            const bool act = threadIdx.x < take;
-            const uint32_t pos = (head + threadIdx.x) & (2u * SHADE_THREADS - 1u);
-            const uint32_t ie = act ? p_idx[pos] : 0u;
-            float4 He = act ? p_hit[pos] : miss;
-            if (PAIRS && act) He = pairs_hit(ie, (unsigned long long)__float_as_uint(He.x) | ((unsigned long long)__float_as_uint(He.y) << 32));
-            head += take;
-            shade_entry(ie, He, act);
-        }
-    }
-    else shade_entry(i, H, active);
 }
 
 // ------------------------------------------------------------------ accumulate (Raytracing.metal:394-403)
@@ -1105,15 +575,6 @@ __global__ void __launch_bounds__(64) k_query_stream_stats(SceneView s, const MR
         }
     }
 #endif
-#ifdef MRT_STATS_POOL      // diagnostics build: the pooled walk (traverse_wide_pool.h) behind the same statistics (the host adds POOL_WORDS * 4 bytes of LDS)
-    if constexpr (!TWO_LEVEL) traverse_wide_pool(s, OneRange{begin, end}, stk_dyn,
-        [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
-            MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
-            A = make_float4(r.origin[0], r.origin[1], r.origin[2], r.max_distance); B = make_float4(r.direction[0], r.direction[1], r.direction[2], 0.0f); is_any = (uint32_t)any;
-        },
-        [&](uint32_t, bool, bool hit, const TravHit &) { sink += hit ? 1u : 0u; }, &ss);
-    else
-#endif
     traverse_wide_stream<TWO_LEVEL>(s, OneRange{begin, end}, stk_dyn,
         [&](uint32_t i, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any) {
             MRTRay r = rays[i]; tag = i & 0x7FFFFFFFu;
@@ -1317,12 +778,12 @@ size_t Renderer::lane_bytes() const {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
     const size_t planes_bytes = shadow_planes ? 2 * spix * sizeof(float4) + spix * 4 : 0;
     const bool need_scon = need_thr || !shadow_planes;
-    const size_t pairs_bytes = (scene && scene->num_inst && scene->num_wnodes && tl_pairs && shadow_planes && !need_thr) ? (2 * PairQueue::WORDS + (MRT_TL_HITUV ? 1 : 0)) * qcap * sizeof(uint4) : 0;      // two-level scenes: the (ray, instance) queue of the binned walk
+    const size_t pairs_bytes = (scene && scene->num_inst && scene->num_wnodes && tl_pairs && shadow_planes && !need_thr) ? 2 * PairQueue::WORDS * qcap * sizeof(uint4) : 0;      // two-level scenes: the (ray, instance) queue of the binned walk
     return ((need_thr ? 9 : 7) * qcap + (need_scon ? qcap : 0) + spix) * sizeof(float4) + planes_bytes + pairs_bytes;
 }
 void Renderer::release_lane(FrameLane &L) {
     for (int k = 0; k < 2; k++) { L.rayA[k].release(); L.rayB[k].release(); L.thr[k].release(); L.f_con[k].release(); }
-    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release(); L.pairs.release(); L.hituv.release();
+    L.hits.release(); L.srayA.release(); L.srayB.release(); L.scon.release(); L.sample.release(); L.f_lit.release(); L.pairs.release();
 }
 int Renderer::alloc_planes(FrameLane &L) {
     const size_t spix = (size_t)std::max<uint32_t>(capacity, 1u) * (size_t)std::max(1, alloc_batch);      // sample indices of a pass: sub-frame * capacity + slot
@@ -1548,7 +1009,6 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool pairs_pass = two_level && planes_pass && tl_pairs != 0 && sv.tri_packet != nullptr;
             const size_t pair_cap = 2 * (size_t)this->capacity * (size_t)std::max(1, alloc_batch);          // one pair per virtual ray of the combined queue; a push beyond it walks its instance in place
             if (pairs_pass && !L.pairs.p) MRT_HIP(L.pairs.alloc(std::max<size_t>(PairQueue::WORDS * pair_cap, 1)));
-            if (pairs_pass && MRT_TL_HITUV && !L.hituv.p) MRT_HIP(L.hituv.alloc(std::max<size_t>((size_t)this->capacity * (size_t)std::max(1, alloc_batch), 1)));      // a hit's barycentrics beside its key
             const uint32_t pair_cap_used = (uint32_t)std::min<size_t>(tl_pair_cap > 0 ? std::min<size_t>((size_t)tl_pair_cap, pair_cap) : pair_cap, 0xFFFFFFFFu);
             // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
@@ -1562,7 +1022,6 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool trace0_wide = trace0_pass && !prim_rope;          // (planes_pass implies the 8-wide layout)
             const bool trace0_hint = primary_hint && (!two_level || (sv.num_inst <= 255u && scene->wpackets.n / WPK < ((size_t)1 << 24)));      // two-level: the hint is (packet | instance << 24)
             fp.wide_stack_words = (uint32_t)((size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES / 4);
-            fp.tile_walk = tile_walk ? 1 : 0;
             if (!planes_pass && !L.scon.p) MRT_HIP(L.scon.alloc((size_t)this->capacity * (size_t)std::max(1, alloc_batch)));
             if ((ablate & 1) || trace0_pass) {}
             else if (two_level && on_wide) {
@@ -1584,14 +1043,13 @@ int Renderer::render(int n_frames) {                                   // Render
                 const unsigned long long *cin = b == 0 ? nullptr : bc + (b - 1);
                 // bounce 0 reads no ray queue (it regenerates the primary ray); bounce b > 0 reads the queue shade(b-1) wrote
                 // bounce 0: one grid row per sub-frame of the batch over the primary slots; later bounces: the compact queue of the whole batch
-                const bool pack = shade_pack && b > 0;          // bounces >= 1 read a queue half of whose rays missed: its hits are compacted in LDS and shaded on full waves (k_shade<.., PACK>)
+                const bool pack = shade_pack && b > 0;          // bounces >= 1 read a queue half of whose rays missed: its hits are compacted in LDS and shaded on full waves (k_shade_pack)
                 // entries per packing workgroup: SHADE_PACK_RANGE when the queue is long, less when that would leave fewer than ~2048 workgroups (a one-frame pass, a tile group, a shard) — never less than two rounds' worth
                 fp.pack_range = (uint32_t)std::min<size_t>(SHADE_PACK_RANGE, std::max<size_t>(2 * SHADE_THREADS, (size_t)capacity * B / 2048 / SHADE_THREADS * SHADE_THREADS));
-                fp.frame_bundle = (frame_bundle && !tile_walk && b == 0 && trace0_wide && B > 1) ? 1 : 0;
+                fp.frame_bundle = (frame_bundle && b == 0 && trace0_wide && B > 1) ? 1 : 0;
                 if (fp.frame_bundle) {
                     fp.bundle_groups = ((uint32_t)B + 7u) / 8u; fp.bundle_w = ((uint32_t)B + fp.bundle_groups - 1u) / fp.bundle_groups;
                     fp.bundle_per_wave = 64u / fp.bundle_w; fp.bundle_magic = (65536u + fp.bundle_w - 1u) / fp.bundle_w;
-                    if (frame_bundle >= 2 && !two_level && fp.bundle_w == 8u) fp.frame_bundle = 2;
                 }
                 fp.halton_tab = nullptr; fp.halton_w0 = 0; fp.halton_n = 0;
                 if (b == 0 && fp.frame_bundle && fp.bundle_w >= 4u && halton_table) {          // a wave reads bundle_w consecutive values per load: the table pays from four on
@@ -1599,21 +1057,28 @@ int Renderer::render(int n_frames) {                                   // Render
                     fp.halton_tab = halton_tab.p; fp.halton_w0 = halton_w0; fp.halton_n = HALTON_TAB_SPAN;
                 }
                 const dim3 gs = b == 0 ? (fp.frame_bundle ? dim3(cdiv(cdiv((size_t)capacity * fp.bundle_groups, fp.bundle_per_wave) * 64, SHADE_THREADS), 1) : dim3(grid_shade, B)) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
-                auto shade_kernel = pack ? (materials ? k_shade<true, false, false, 0, false, true>
-                                                : pairs_pass ? k_shade<false, true, true, 0, true, true>
-                                                : planes_pass ? k_shade<false, true, true, 0, false, true>
-                                                : fp.chain ? k_shade<false, true, false, 0, false, true> : k_shade<false, false, false, 0, false, true>)
-                                              : materials ? k_shade<true, false>
-                                              : (pairs_pass && b > 0) ? k_shade<false, true, true, 0, true>
-                                              : (trace0_wide && b == 0 && two_level) ? k_shade<false, true, true, 3>
-                                              : (trace0_wide && b == 0) ? k_shade<false, true, true, 2>
-                                              : (trace0_pass && b == 0) ? k_shade<false, true, true, 1>
-                                              : planes_pass ? k_shade<false, true, true>
-                                              : fp.chain ? k_shade<false, true> : k_shade<false, false>;
+                using ShadeKernel = void (*)(SceneView, FrameParams, const uint32_t *, const float4 *, const float4 *, const float4 *, const float4 *, const unsigned long long *, uint32_t, float4 *, float4 *, float4 *, float4 *, float4 *, float4 *,
+                                             unsigned long long *, float4 *, float4 *, uint32_t *);
+                const ShadeKernel shade_kernel = pack ? (materials ? (ShadeKernel)k_shade_pack<true, false, false, false>
+                                                          : pairs_pass ? (ShadeKernel)k_shade_pack<false, true, true, true>
+                                                          : planes_pass ? (ShadeKernel)k_shade_pack<false, true, true, false>
+                                                          : fp.chain ? (ShadeKernel)k_shade_pack<false, true, false, false> : (ShadeKernel)k_shade_pack<false, false, false, false>)
+                                                  : materials ? (ShadeKernel)k_shade<true, false, false, false>
+                                                  : (pairs_pass && b > 0) ? (ShadeKernel)k_shade<false, true, true, true>
+                                                  : (trace0_wide && b == 0 && two_level) ? (ShadeKernel)k_shade_primary<3>
+                                                  : (trace0_wide && b == 0) ? (ShadeKernel)k_shade_primary<2>
+                                                  : (trace0_pass && b == 0) ? (ShadeKernel)k_shade_primary<1>
+                                                  : planes_pass ? (ShadeKernel)k_shade<false, true, true, false>
+                                                  : fp.chain ? (ShadeKernel)k_shade<false, true, false, false> : (ShadeKernel)k_shade<false, false, false, false>;
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
-                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + ((tile_walk || MRT_LANE_HIT_LDS) ? 1024 : 0)) : 0, st, sv, fp, seeds_p, L.rayA[1 - q].p, L.rayB[1 - q].p, (pairs_pass && b > 0 && MRT_TL_HITUV) ? L.hituv.p : L.thr[1 - q].p, L.hits.p, cin, capacity,
-                             L.rayA[q].p, L.rayB[q].p, L.thr[q].p, L.srayA.p, L.srayB.p, con_b, bc + b, b == 0 ? L.sample.p : (float4 *)nullptr, L.sample.p, (b == 0 && trace0_pass && trace0_hint) ? hint.p : (uint32_t *)nullptr);
+                ShadeIO io{};
+                io.seeds = seeds_p; io.rayA = L.rayA[1 - q].p; io.rayB = L.rayB[1 - q].p; io.thr = L.thr[1 - q].p; io.hits = L.hits.p; io.count_in = cin; io.capacity = capacity;
+                io.nrayA = L.rayA[q].p; io.nrayB = L.rayB[q].p; io.nthr = L.thr[q].p; io.srayA = L.srayA.p; io.srayB = L.srayB.p; io.scon = con_b; io.count_out = bc + b;
+                io.sample_primary = b == 0 ? L.sample.p : nullptr; io.sample = L.sample.p; io.hint = (b == 0 && trace0_pass && trace0_hint) ? hint.p : nullptr;
+                const size_t shade_lds = (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (MRT_LANE_HIT_LDS ? 1024 : 0)) : 0;
+                launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), shade_lds, st, sv, fp, io.seeds, io.rayA, io.rayB, io.thr, io.hits, io.count_in, io.capacity, io.nrayA, io.nrayB, io.nthr, io.srayA, io.srayB, io.scon,
+                             io.count_out, io.sample_primary, io.sample, io.hint);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 // [r3] smaller launches pull as well when five or more passes are in flight (6 lanes x one-frame passes: 9.33 against 8.76 Grays/s; a rank of eight over 240 frames
@@ -1631,13 +1096,13 @@ int Renderer::render(int n_frames) {                                   // Render
                     // few instances: the TLAS pass without a tree (every lane visits every instance: nothing diverges); many: the stream walk of the 8-wide TLAS
                     if (sv.num_inst <= TL_FLAT_MAX_INSTANCES && tl_pairs != 2)
                         launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top_flat, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, 64), 2 * grid_slots))), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                     (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4), L.hituv.p);
+                                     (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
                     else
                     launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top, dim3(waves), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                 (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4), L.hituv.p);
+                                 (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
                     // the pairs' count is on the device: the launch has the wave slots it may use and the surplus leaves at once
                     launch_timed(timed(MRT_KERNEL_TRACE), k_tl_blas, dim3((uint32_t)grid_slots), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used, L.hituv.p);
+                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used);
                 }
                 else if (on_wide && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most
@@ -1655,46 +1120,23 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
                     const uint32_t chunk_arg = chunk;
 #endif
-                    if (!two_level && planes_pass && pool) {
-                        const size_t lds_p = (size_t)POOL_WORDS * 4 + stack_bytes;
-                        if (slots_x_key != -2 - (int)(lds_p & 0xFFFFF)) {
-                            int per_cu = 0, dev = 0; hipDeviceProp_t prop;
-                            MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
-                            MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_pool, 64, lds_p));
-                            if (per_cu < 1) { set_error("pool: the traversal kernel does not fit a compute unit with " + std::to_string(lds_p) + " bytes of LDS"); return MRT_ERR_UNSUPPORTED; }
-                            wave_slots_x = per_cu * prop.multiProcessorCount; slots_x_key = -2 - (int)(lds_p & 0xFFFFF);
-                        }
-                        const size_t ws = wave_slots_user ? (size_t)wave_slots : (size_t)wave_slots_x;
-                        const uint32_t chunk_x = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / (ws * 4) / 64 * 64));
-                        const size_t grid_slots_x = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? std::max<size_t>(1, ws / 2) : ws;
-                        const uint32_t waves_x = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk_x), grid_slots_x));
-                        launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_pool, dim3(waves_x), dim3(64), lds_p, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p,
-                                     (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_x, lit_b, xcd_counters ? (uint32_t)B : 0u);
-                    }
-                    else if (!two_level && planes_pass && (hit_lds || lds_top)) {
-                        // the variant with LDS extras: its own workgroup shape, LDS size and wave slots
-                        const int WV = lds_top >= 2 ? 4 : 1;
-                        const bool TOPX = lds_top >= 1 && lds_top <= 3;
-                        const uint32_t top_n = !TOPX ? 0u : lds_top == 2 ? scene->wide_level_end[2] : scene->wide_level_end[1];
-                        const uint32_t stack_words = (uint32_t)(stack_bytes / 4);
-                        const size_t lds_x = (size_t)top_n * WNODE_STRIDE * 16 + (size_t)WV * ((hit_lds ? HIT_LDS_WORDS * 4 : 0) + stack_bytes);
-                        using KX = void (*)(SceneView, const float4 *, const float4 *, float4 *, const float4 *, const float4 *, const unsigned long long *, uint32_t *, uint32_t, uint8_t *, uint32_t, uint32_t, uint32_t);
-                        const KX kx = WV == 4 ? (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, true, true> : (KX)k_trace_mixed_wide_persist_x<4, true, false>) : (TOPX ? (KX)k_trace_mixed_wide_persist_x<4, false, true> : (KX)k_trace_mixed_wide_persist_x<4, false, false>))
-                                              : (hit_lds ? (TOPX ? (KX)k_trace_mixed_wide_persist_x<1, true, true> : (KX)k_trace_mixed_wide_persist_x<1, true, false>) : (KX)k_trace_mixed_wide_persist_x<1, false, true>);
-                        const int key = (int)(lds_x & 0xFFFFFF) * 64 + hit_lds * 8 + lds_top;
+                    if (!two_level && planes_pass && hit_lds) {
+                        // the variant with the hit words in LDS: its own LDS size, hence its own count of wave slots
+                        const size_t lds_x = (size_t)HIT_LDS_WORDS * 4 + stack_bytes;
+                        const int key = (int)(lds_x & 0xFFFFFF);
                         if (slots_x_key != key) {
                             int per_cu = 0, dev = 0; hipDeviceProp_t prop;
                             MRT_HIP(hipGetDevice(&dev)); MRT_HIP(hipGetDeviceProperties(&prop, dev));
-                            MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kx, 64 * WV, lds_x));
-                            if (per_cu < 1) { set_error("lds_top / hit_lds: the traversal kernel does not fit a compute unit with " + std::to_string(lds_x) + " bytes of LDS"); return MRT_ERR_UNSUPPORTED; }
-                            wave_slots_x = per_cu * WV * prop.multiProcessorCount; slots_x_key = key;
+                            MRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mixed_wide_persist_x, 64, lds_x));
+                            if (per_cu < 1) { set_error("hit_lds: the traversal kernel does not fit a compute unit with " + std::to_string(lds_x) + " bytes of LDS"); return MRT_ERR_UNSUPPORTED; }
+                            wave_slots_x = per_cu * prop.multiProcessorCount; slots_x_key = key;
                         }
                         const size_t ws = wave_slots_user ? (size_t)wave_slots : (size_t)wave_slots_x;
                         const uint32_t chunk_x = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(128, slots / (ws * 4) / 64 * 64));
                         const size_t grid_slots_x = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? std::max<size_t>(1, ws / 2) : ws;
                         const uint32_t waves_x = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk_x), grid_slots_x));
-                        launch_timed(timed(MRT_KERNEL_TRACE), kx, dim3((waves_x + WV - 1) / WV), dim3(64 * WV), lds_x, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p,
-                                     (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_x, lit_b, xcd_counters ? (uint32_t)B : 0u, top_n, stack_words);
+                        launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist_x, dim3(waves_x), dim3(64), lds_x, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p,
+                                     (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_x, lit_b, xcd_counters ? (uint32_t)B : 0u);
                     }
                     else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_persist<true>, dim3(std::max(1u, waves)), dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p,
                                  (const unsigned long long *)(bc + b), L.sample.p, reinterpret_cast<uint32_t *>(bc + WORK_COUNTERS + (size_t)b * WORK_COUNTERS_PER_BOUNCE), chunk_arg, lit_b, xcd_counters ? (uint32_t)B : 0u);
@@ -1898,11 +1340,7 @@ int query_stream_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *
     MRT_HIP(d_r.alloc(n)); MRT_HIP(d_o.alloc(8 * nwaves));
     MRT_HIP(hipMemsetAsync(d_o.p, 0, 32 * nwaves, stream));
     MRT_HIP(hipMemcpyAsync(d_r.p, rays, n * sizeof(MRTRay), hipMemcpyHostToDevice, stream));
-#ifdef MRT_STATS_POOL
-    const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : (size_t)POOL_WORDS * 4);
-#else
     const size_t lds = (size_t)sc.wide_depth * WIDE_STACK_LEVEL_BYTES + (sc.num_inst ? WIDE_WORLD_RAY_BYTES : 0);
-#endif
     if (sc.num_inst) hipLaunchKernelGGL(k_query_stream_stats<true>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     else hipLaunchKernelGGL(k_query_stream_stats<false>, dim3((uint32_t)nwaves), dim3(64), lds, stream, sc.view(), d_r.p, (uint32_t)n, any, per_wave, (uint32_t)sc.wide_depth, d_o.p);
     MRT_HIP(hipMemcpyAsync(out8, d_o.p, 32 * nwaves, hipMemcpyDeviceToHost, stream));

@@ -41,20 +41,11 @@ constexpr uint32_t NODE_INDEX_MASK = 0x00FFFFFFu;
 //   f4 2: qlo_x[8] qlo_y[8]      f4 3: qlo_z[8] qhi_x[8]      f4 4: qhi_y[8] qhi_z[8]      (empty slot: qlo=255, qhi=0)
 // Slot bit k set = the child lies on the + side of the node centre along axis k, so children are entered
 // front to back in the order of (slot ^ ray octant).
-// -DMRT_WIDE6=1 (A/B variant, flattened scenes only): SIX children per node in 64 bytes = 4 x float4, one half of a 128-byte line, never straddling two:
-//   f4 0: as above (imask stays in slot space: eight virtual slots order the children front to back, at most six are occupied)
-//   f4 1: child_base (24 bits) | meta of child 5 << 24,  tri_base,  meta of children 0..4 (6 bits each),  plane word 0
-//   f4 2, 3: plane words 1..8.   meta of physical child j = slot (3 bits) | triangle count << 3 (3 bits); its packet offset is the sum of the counts before it.
-//   plane words per axis a = x, y, z:  [3a] = lo bytes of children 0..3,  [3a + 1] = lo4 | lo5 << 8 | hi4 << 16 | hi5 << 24,  [3a + 2] = hi bytes of children 0..3
-#ifndef MRT_WIDE6
-#define MRT_WIDE6 0
-#endif
+// (A six-children-in-64-bytes variant of this node, -DMRT_WIDE6, measured worse in round 4 and was removed in round 6: profiles/r04_wide6_ab.txt.)
 #ifndef MRT_WNODE_STRIDE
-#define MRT_WNODE_STRIDE (MRT_WIDE6 ? 4 : 5)
+#define MRT_WNODE_STRIDE 5
 #endif
-constexpr int WIDE_N = MRT_WIDE6 ? 6 : 8;                      // children per wide node
-constexpr int WNODE_N4 = MRT_WIDE6 ? 3 : 4;                    // index of the node's last float4 (the traversal loops name five: the 64-byte node's fifth is its fourth again)
-constexpr uint32_t WNODE_BASE_MASK = MRT_WIDE6 ? 0x00FFFFFFu : 0xFFFFFFFFu;
+constexpr int WIDE_N = 8;                             // children per wide node
 constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wide nodes in HBM (5 = packed 80 B; 8 = one 128-B line each)
 #ifndef MRT_WPACKET_STRIDE
 #define MRT_WPACKET_STRIDE 3
@@ -96,8 +87,6 @@ struct SceneView {           // passed by value to kernels
     const float4 *packets;       // 3 x float4 per triangle, leaf order
     const uint4 *tri_shade;      // per gid
     const float4 *normals;       // object space, concatenated over meshes (float3 stride 16, Mesh.swift:27-29)
-    const float4 *tri_fat;       // per shading record 3 x float4 {n0.xyz | tri_shade.w}, {n1.xyz | -}, {n2.xyz | -}: the record's three vertex normals beside its instance / geometry word, so that
-                                 // shading follows ONE gather from the hit instead of tri_shade -> three normals (scene option fat_shade; nullptr = not built)
     const float4 *base_color;    // per resource slot = instance*max_sub + geometry (Renderer.swift:139)
     const float4 *materials;     // per resource slot, 3 x float4: baseColor | dissolve, specular | specularExponent, emission | refractionIndex (materials extension)
     const float4 *inst_cols;     // 3 x float4 per instance: columns 0..2 of the 4x3 transform
@@ -207,7 +196,6 @@ struct BuildOptions {
     float wide_cost_node = 1.0f, wide_cost_tri = 0.5f;      // its constants: a node visit (eight box tests + an iteration) against one triangle test — ~250 against ~125 VALU instructions in the stream loop; 0.3 until round 5
                                                             // (0.45 ... 1.0 measured +1 ... +2 % on DragonScene, 0.5 against 0.3: garden 4K +1 %, dragon x 4 +3 ... +4 %, hostile +1.5 %, Cornell 256^2 +8 ... +13 %; profiles/r05_wide_cost_tri.txt)
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
-    int fat_shade = 0;        // 1: also keep, per triangle, its three vertex normals beside its instance / geometry word (48 B; SceneView::tri_fat): k_shade then needs one dependent gather per hit instead of two.  Measured (profiles/r05_lds_top_ab.txt): the shade launches alone 0.772 against 0.777 ms, the frame within noise — off by default (it would add 42 MB to DragonScene's 70)
     int refit = 1;            // a commit after mrt_scene_update_mesh alone (same topology, new vertex positions / normals) REFITS the 8-wide tree of a flattened scene — packets rewritten, boxes recomputed bottom-up, the tree's shape kept — instead of building it again; 0: always build
     int refit_fenced = 0;     // 1: the bottom-up pass of the build with __threadfence() hand-offs instead of write-through stores (the slow reference form; same tree bit for bit)
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
@@ -218,7 +206,6 @@ struct BuildOptions {
 struct DeviceScene {
     DevBuf<float4> nodes, packets, normals, base_color, materials, inst_cols, wnodes, wpackets;
     uint32_t num_wnodes = 0; int wide_depth = 0;
-    uint32_t wide_level_end[4] = {0, 0, 0, 0};   // flattened scenes: nodes of the 8-wide tree in levels 0..k (BFS numbering: wnodes[0 .. wide_level_end[k]) ARE those levels) — what the traversal stages in LDS (renderer option lds_top)
     std::vector<uint32_t> wide_levels;           // flattened scenes: nodes per level of the 8-wide tree (BFS numbering) — what a refit walks bottom-up (build_flat, refit)
     uint32_t refits = 0;                         // commits served by a refit since the last build
     uint64_t refit_triangles = 0;                // triangles of the build that made the 8-wide layout (a refit needs the same count)
@@ -226,7 +213,6 @@ struct DeviceScene {
     uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
     size_t packets_offset = 0;       // packets start at nodes.p + packets_offset (float4 units); `packets` itself is unused
     DevBuf<uint4> tri_shade;
-    DevBuf<float4> tri_fat;          // 3 x float4 per shading record (SceneView::tri_fat); empty when scene option fat_shade = 0
     DevBuf<uint32_t> geom_base;
     DevBuf<LightDev> lights;
     int light_count = 0;
@@ -250,7 +236,6 @@ struct DeviceScene {
 void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
-int build_fat_shade(DeviceScene &out, const BuildOptions &opt, hipStream_t stream);      // tri_fat from tri_shade + normals (flattened scenes and single BLASes: vertex ids are absolute in `normals`)
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false, bool only_vertices_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
 void host_sah_topology(const float4 *lo, const float4 *hi, uint32_t n, std::vector<uint32_t> &order, std::vector<uint32_t> &left, std::vector<uint32_t> &right, std::vector<uint32_t> &parent);
@@ -259,7 +244,8 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched
-int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only);      // every index of the 8-wide layout / instance rows inside its array; MRT_ERR_STATE + message otherwise
+int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only, const float4 *wnodes_override = nullptr);      // wnodes_override: a device copy of the 8-wide nodes to check in place of the scene's (mrt_debug_validate_patched)
+         // every index of the 8-wide layout / instance rows inside its array; MRT_ERR_STATE + message otherwise
 int upload_lights(const MRTLight *lights, int count, hipStream_t stream, DeviceScene &out);
 
 }  // namespace mrt

@@ -72,92 +72,16 @@ MRT_DEV void wstack_pop(const uint32_t *stack, uint32_t sp, uint32_t lane, uint3
 // The comparison is strict because both ends clamp to the same value when the box lies behind the origin (far = 0 = near) or beyond the
 // limit (near >= 1 = far); for a box that the exact test accepts the widened far side is strictly beyond the near side.  Per node this costs
 // v_med3 + v_mul + v_rcp + 3 v_mul and saves 8 x (v_max + v_min).
-// NHLUT (the stream kernels with LDS extras, MRT_NH_LUT): the per-child `bit (slot ^ octant) of the internal children` — a bit-field extract, an xor and a shift-or per child,
-// two of them half-rate — becomes one `or` with a literal per child (raw hit bits by slot) and, per node, two byte reads of a 128-byte table in LDS:
-// nh_lut[o << 4 | n] = the bits of nibble n moved to (position ^ o); the high nibble's bits 4 + j go to (4 ^ (o & 4)) + (j ^ (o & 3)) — the same table at octant o ^ 4.
-#ifndef MRT_NH_LUT
-#define MRT_NH_LUT 0
-#endif
 // MRT_ROOT_AT_FETCH (the stream kernels with LDS extras): every ray's walk begins with the SAME node.  The batch prefetch — 64 rays, one per lane, every lane busy — tests the root's
 // eight boxes for its rays there (the root's words are wave-uniform loads) and leaves the hit bits in LDS; a lane that takes a ray starts with the root's children as its group
 // instead of spending its first iteration — a round trip, and a node test at the loop's ~55 % of the lanes — on node 0.
 #ifndef MRT_ROOT_AT_FETCH
 #define MRT_ROOT_AT_FETCH 1
 #endif
-constexpr uint32_t NH_LUT_WORDS = 32;
-MRT_DEV uint32_t lds_u8(const uint8_t *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)p);
-#else
-    return *p;
-#endif
-}
-// the wave writes its table: lane l < 32 holds entries 4 l .. 4 l + 3 (octant l >> 2, nibbles 4 (l & 3) ..)
-MRT_DEV void nh_lut_fill(uint32_t *lut_words) {
-    const uint32_t l = threadIdx.x & 63u;
-    if (l < NH_LUT_WORDS) {
-        const uint32_t o = l >> 2; uint32_t w = 0;
-        for (uint32_t e = 0; e < 4u; e++) {
-            const uint32_t n = 4u * (l & 3u) + e; uint32_t r = 0;
-            for (uint32_t j = 0; j < 4u; j++) if ((n >> j) & 1u) r |= 1u << (j ^ o);
-            w |= r << (8u * e);
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(lut_words + l)) = w;      // (a ds_write, ordered with the ds_reads of the table)
-#else
-        lut_words[l] = w;
-#endif
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-template <bool SCALED = false, bool NHLUT = false>
+template <bool SCALED = false>
 MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const float4 n4, const f3 o,
                             float ix, float iy, float iz, const bool nx, const bool ny, const bool nz, const uint32_t oct,
-                            const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits, const uint8_t *nh_lut = nullptr) {
-#if MRT_WIDE6
-    {   // six children in 64 bytes (scene_device.h): physical child j carries its slot and its triangle count; its packets follow those of the children before it
-        const uint32_t ew = __float_as_uint(n0.w);
-        const uint32_t imask = ew >> 24;
-        if (SCALED) {
-            const float S = __builtin_amdgcn_rcpf(__builtin_amdgcn_fmed3f(tmax, 1e-6f, 1e30f) * 1.0000005f);
-            ix *= S; iy *= S; iz *= S;
-        }
-        const float ax = __builtin_ldexpf(ix, (int)(int8_t)(ew & 0xFFu)), ay = __builtin_ldexpf(iy, (int)(int8_t)((ew >> 8) & 0xFFu)), az = __builtin_ldexpf(iz, (int)(int8_t)((ew >> 16) & 0xFFu));
-        const float bx = (n0.x - o.x) * ix, by = (n0.y - o.y) * iy, bz = (n0.z - o.z) * iz;
-        const uint32_t w[9] = {__float_as_uint(n1.w), __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w),
-                               __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w)};
-        // near / far bytes per axis: children 0..3 from the lo / hi word, children 4, 5 from the two halves of the middle word
-        const uint32_t nrx[2] = {nx ? w[2] : w[0], nx ? w[1] >> 16 : w[1]}, frx[2] = {nx ? w[0] : w[2], nx ? w[1] : w[1] >> 16};
-        const uint32_t nry[2] = {ny ? w[5] : w[3], ny ? w[4] >> 16 : w[4]}, fry[2] = {ny ? w[3] : w[5], ny ? w[4] : w[4] >> 16};
-        const uint32_t nrz[2] = {nz ? w[8] : w[6], nz ? w[7] >> 16 : w[7]}, frz[2] = {nz ? w[6] : w[8], nz ? w[7] : w[7] >> 16};
-        const uint32_t m04 = __float_as_uint(n1.z), m5 = __float_as_uint(n1.x) >> 24;
-        uint32_t nh = 0, th = 0, off = 0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const int wq = j >> 2, k = j & 3;
-            const uint32_t meta6 = j < 5 ? (m04 >> (6 * j)) & 63u : m5 & 63u;
-            const uint32_t slot = meta6 & 7u, cnt = meta6 >> 3;
-            float tn, tf;
-            if (SCALED) {
-                tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(nry[wq], k), ay, by)),
-                           __builtin_amdgcn_fmed3f(__builtin_fmaf(ubyte_f(nrz[wq], k), az, bz), 0.0f, 1.0f));
-                tf = __builtin_amdgcn_fmed3f(fminf(fminf(__builtin_fmaf(ubyte_f(frx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(fry[wq], k), ay, by)),
-                                                   __builtin_fmaf(ubyte_f(frz[wq], k), az, bz)) * 1.0000005f, 0.0f, 1.0f);
-            } else {
-                tn = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nrx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(nry[wq], k), ay, by)),
-                           fmaxf(__builtin_fmaf(ubyte_f(nrz[wq], k), az, bz), tmin));
-                tf = fminf(fminf(fminf(__builtin_fmaf(ubyte_f(frx[wq], k), ax, bx), __builtin_fmaf(ubyte_f(fry[wq], k), ay, by)),
-                                 __builtin_fmaf(ubyte_f(frz[wq], k), az, bz)) * 1.0000005f, tmax);
-            }
-            if (SCALED ? tn < tf : tn <= tf) {
-                nh |= ((imask >> slot) & 1u) << (slot ^ oct);
-                th |= bfm_b32(cnt, off);
-            }
-            off += cnt;
-        }
-        node_hits = nh; tri_hits = th;
-    }
-#else
+                            const float tmin, const float tmax, uint32_t &node_hits, uint32_t &tri_hits) {
     const uint32_t ew = __float_as_uint(n0.w);
     const uint32_t imask = ew >> 24;
     if (SCALED) {
@@ -193,16 +117,11 @@ MRT_DEV void wide_node_test(const float4 n0, const float4 n1, const float4 n2, c
         }
         if (SCALED ? tn < tf : tn <= tf) {
             // no inner branch: an internal child's meta byte is 0 (empty triangle range), a leaf child's imask bit is 0
-            if (NHLUT) nh |= 1u << i; else nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
+            nh |= ((imask >> i) & 1u) << ((uint32_t)i ^ oct);
             th |= bfm_b32((meta[w] >> (8 * k + 5)) & 7u, meta[w] >> (8 * k));       // v_bfm_b32 reads the low 5 bits of the offset operand
         }
     }
-    if (NHLUT) {
-        const uint32_t x = nh & imask, o4 = oct << 4;
-        nh = lds_u8(nh_lut + (o4 | (x & 15u))) | lds_u8(nh_lut + ((o4 | (x >> 4)) ^ 64u));
-    }
     node_hits = nh; tri_hits = th;
-#endif
 }
 
 // stack: depth x WIDE_STACK_LEVEL_BYTES of LDS for the wave (depth = the scene's wide-tree depth, <= WIDE_STACK)
@@ -247,7 +166,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
             }
         } else {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[WNODE_N4];
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
             have_pending = false;
             uint32_t node_hits, tri_hits;
             wide_node_test(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, tmin, h.t, node_hits, tri_hits);
@@ -263,7 +182,7 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
                 if (tn > h.t) tc->stale++;
             }
             if ((g_mask >> 8) != 0) { wstack_push(stack, sp, lane, g_base, g_mask); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
@@ -273,13 +192,11 @@ MRT_DEV bool traverse_wide(const SceneView &s, f3 o, f3 d, float tmin, float tma
 // One ray per lane on the 8-wide layout, closest hit, the stream loop's iteration (node and triangle fetched in one round trip, scaled box test) without
 // refill: for COHERENT rays — the primary rays of an 8x8 tile, traced inside k_shade<.., TRACE0 = 2> — whose lanes stay in step by themselves.
 // SEED: `seed_pk` is a packet the caller has already tested (distance in tmax); the walk starts with it as its closest hit.  h.pk = packet of the final hit.
-// ROOTS (traverse_wide_tile.h): the walk starts not at node 0 but at the nodes of `front` — nroots pairs {node, lower bound of the distance at which any ray of the tile enters it (float bits)},
-// nearest first — taking the next one whenever its own stack runs empty and skipping those that lie beyond its closest hit.
 #ifndef MRT_LANE_HIT_LDS
 #define MRT_LANE_HIT_LDS 1      // 1: the lane walk keeps U, V, |det|, id of its closest hit in four words of LDS (`hitw`, [4][64] behind the caller's stack) instead of testing the winner again at the end
 #endif
-template <bool SEED, bool ROOTS = false>
-MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */, const uint32_t *front = nullptr, uint32_t nroots = 0, float *hitw = nullptr, const TravHit *seed_hit = nullptr) {
+template <bool SEED>
+MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, float tmax, uint32_t seed_pk, TravHit &h, uint32_t *stack /* depth x WIDE_STACK_LEVEL_BYTES of LDS, this wave's */, float *hitw = nullptr, const TravHit *seed_hit = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     const float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
     const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
@@ -288,8 +205,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
     if (MRT_LANE_HIT_LDS && hitw) {          // the seed's own U, V, |det|, id (the caller tested it) are the closest hit so far
         if (SEED && seed_hit && seed_pk != 0xFFFFFFFFu) { hitw[lane] = seed_hit->U; hitw[64u + lane] = seed_hit->V; hitw[128u + lane] = seed_hit->ad; hitw[192u + lane] = __uint_as_float(seed_hit->gid); }
     }
-    uint32_t g_base = 0, g_mask = (!ROOTS && s.num_wnodes != 0) ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
-    uint32_t cursor = 0;                 // ROOTS: next entry of `front`
+    uint32_t g_base = 0, g_mask = s.num_wnodes != 0 ? 0x100u : 0u, t_base = 0, t_mask = 0;      // the root as the only hit child of a pseudo group; g_mask: imask | hit bits << 8 | stack depth << 16
     for (;;) {
         const bool has_tri = t_mask != 0;
         const uint32_t t_rest = t_mask & (t_mask - 1u);
@@ -298,14 +214,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
         if (want_node) {
             if ((g_mask & 0xFF00u) == 0) {
                 const uint32_t sp = g_mask >> 16;
-                if (sp == 0) {
-                    bool got = false;
-                    if (ROOTS) while (cursor < nroots) {          // the next subtree of the tile's front that this ray can still reach
-                        const uint32_t r = front[2u * cursor]; const float enter = __uint_as_float(front[2u * cursor + 1u]); cursor++;
-                        if (enter <= best_t) { g_base = r; g_mask = 0x100u; got = true; break; }
-                    }
-                    if (!got) { want_node = false; if (!has_tri) break; }
-                }
+                if (sp == 0) { want_node = false; if (!has_tri) break; }
                 else { wstack_pop(stack, sp - 1u, lane, g_base, g_mask); g_mask |= (sp - 1u) << 16; }
             }
             if (want_node) {
@@ -329,7 +238,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
         if (has_tri) {
             float t, U, V, ad;
@@ -344,7 +253,7 @@ MRT_DEV bool traverse_wide_lane(const SceneView &s, const f3 o, const f3 d, floa
             wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
             uint32_t sp = g_mask >> 16;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
         else if (t_rest == 0u) break;        // no node left and this was the last pending triangle
@@ -438,7 +347,7 @@ MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const
         }
         if (want_node) {
             const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
         if (has_tri) {
             float t, U, V, ad;
@@ -454,7 +363,7 @@ MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const
             uint32_t sp = (g_mask >> 16) & 0xFFu;
             const uint32_t isp = g_mask & 0xFF000000u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }
-            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             t_base = __float_as_uint(n1.y); t_mask = tri_hits;
         }
     }
@@ -569,24 +478,16 @@ struct XcdRegions {
 // Two-level scenes, binned form (renderer option tl_pairs).  The TLAS pass — this loop with a PairQueue — tests instances of at most eight triangles in place and,
 // instead of entering a larger one, appends {ray, instance} to a queue; a second launch walks every pair in object space with the FLATTENED loop (TWO_LEVEL = false, per-ray root:
 // ROOTS), its lanes never changing level, and folds the hits into the rays' results with atomics.  When the queue is full a lane enters the instance in place, as without a queue.
-#ifndef MRT_TL_FAT
-#define MRT_TL_FAT 0      // two-level scenes, binned walk, A/B (tools/build_variant.sh): 1 = a pair carries its ray in the instance's OBJECT space (48 B, written and read coalesced) instead of {ray, instance} (16 B + two scattered ray
-                          // records, the instance row and the transform again in the BLAS pass).  Measured on dragon x 4: 8.0-8.2 against 8.3-8.4 Grays/s — the TLAS pass's 32 more bytes per pair cost more than the BLAS pass's gathers (profiles/r05_two_level_ab.txt)
-#endif
-#ifndef MRT_TL_HITUV
-#define MRT_TL_HITUV 0    // a hit found by the TLAS or the BLAS pass leaves {u, v, global triangle id, t} beside its ray's key; k_shade<.., PAIRS> takes the barycentrics when the id matches the key's instead of testing the winning triangle again.
-                          // Measured on dragon x 4 (thin pairs both ways): 8.2-8.3 against 8.4-8.5 Grays/s — the scattered 16-byte store per hit in the BLAS pass costs more (its launches 1.02 against 0.93 ms) than the re-test saves k_shade (1.02 against 1.04 ms)
-#endif
 struct NoPairs { static constexpr bool on = false; };
 struct PairQueue {
     static constexpr bool on = true;
-    static constexpr uint32_t WORDS = MRT_TL_FAT ? 3u : 1u;      // float4 per pair: {object-space origin | bound} {object-space direction | report tag} {ray, instance, BLAS root, -} — or {ray, instance, bound, report tag}
+    static constexpr uint32_t WORDS = 1u;             // float4 per pair: {ray, instance, bound, report tag}
     static constexpr uint32_t BLOCK = 256;            // pair slots a wave reserves at a time: ONE atomic on the queue's counter per 256 pairs (a counter word sustains ~88 returning
                                                       // atomics per microsecond; one per wave and iteration — the first form — made the TLAS pass five times slower than the walk it replaces)
     uint4 *__restrict__ pairs; uint32_t *__restrict__ count; uint32_t cap;
     uint32_t *cursor;                                 // LDS, two words of this wave: {next free slot, end of the wave's block}; both 0 at the start
     // called by the lanes that reached a large instance in this iteration (a divergent branch: the ballot sees exactly them); true = the pair is stored
-    MRT_DEV bool push(uint32_t ray_index, uint32_t inst, float tmax, uint32_t tagw, const f3 oo = mk3(0, 0, 0), const f3 dd = mk3(0, 0, 1), uint32_t root = 0) const {
+    MRT_DEV bool push(uint32_t ray_index, uint32_t inst, float tmax, uint32_t tagw) const {
         const unsigned long long m = __ballot(1);
         const int leader = __ffsll((long long)m) - 1;
         const uint32_t lane = threadIdx.x & 63, n = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -605,48 +506,29 @@ struct PairQueue {
         if (rank < fits) slot = cur + rank;
         else if (fresh != 0xFFFFFFFFu) slot = fresh + (rank - fits);
         else return false;
-#if MRT_TL_FAT
-        float4 *const rec = reinterpret_cast<float4 *>(pairs) + 3 * (size_t)slot;      // (written once, read once by the next launch)
-        qstore(rec, make_float4(oo.x, oo.y, oo.z, tmax)); qstore(rec + 1, make_float4(dd.x, dd.y, dd.z, __uint_as_float(tagw))); qstore(rec + 2, make_float4(__uint_as_float(ray_index), __uint_as_float(inst), __uint_as_float(root), 0.0f));
-#else
         qstore(reinterpret_cast<float4 *>(&pairs[slot]), make_float4(__uint_as_float(ray_index), __uint_as_float(inst), tmax, __uint_as_float(tagw)));      // (written once, read once by the next launch)
-#endif
         return true;
     }
     // the whole wave, when it has no rays left: the unused rest of its block becomes pairs that name no ray (the BLAS pass skips them)
     MRT_DEV void close() const {
         const uint32_t lane = threadIdx.x & 63, cur = cursor[0], end = cursor[1];
-        for (uint32_t k = cur + lane; k < end; k += 64) qstore(reinterpret_cast<float4 *>(pairs) + (size_t)WORDS * k + (WORDS - 1u), make_float4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f));
+        for (uint32_t k = cur + lane; k < end; k += 64) qstore(reinterpret_cast<float4 *>(pairs) + k, make_float4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f));
         cursor[0] = end;
     }
 };
 
-// Optional LDS extras of the stream walk (flattened scenes; renderer options hit_lds / lds_top):
-//   hit_lds   the lane's closest hit so far keeps its U, V, |det| and triangle id in four words of LDS, written when a closer hit is found, so that a finished ray is
-//             reported from LDS instead of fetching the winning packet again and re-running its triangle test at refill time (a dependent round trip and ~100 VALU
-//             instructions at a quarter of the lanes, three to four times per 64 rays);
-//   top_lds   the first top_n nodes of wnodes — BFS numbering: the top levels of the tree — are read from a copy in LDS (the workgroup's, loaded at kernel start)
-//             instead of through the vector memory path.  BASELINE.json's "LDS-staged BVH nodelets".
-// a float4 read from an address KNOWN to be in LDS, through an LDS pointer by type (ds_read_b128): with a generic pointer the compiler merges an "LDS or global" choice into one flat load
-MRT_DEV float4 lds_f4(const float4 *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(3))) const float4 lds_t;
-    const lds_t *q = (const lds_t *)p;
-    return make_float4(q->x, q->y, q->z, q->w);
-#else
-    return *p;
-#endif
-}
-struct NoExt { static constexpr bool hit_lds = false, top_lds = false, nh_lut = false, root_pre = false; float *hit = nullptr; const float4 *top = nullptr; uint32_t top_n = 0; const uint8_t *nh = nullptr; uint32_t *root = nullptr; };      // (members never read: every use sits behind one of the two flags)
-template <bool HIT, bool TOP> struct StreamExt {
-    static constexpr bool hit_lds = HIT, top_lds = TOP, nh_lut = HIT && MRT_NH_LUT != 0, root_pre = HIT && MRT_ROOT_AT_FETCH != 0;
-    float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far; MRT_NH_LUT: followed by the wave's 128-byte table (wide_node_test<.., NHLUT>)
-    const float4 *top;      // TOP: wnodes[0 .. top_n) in LDS
-    uint32_t top_n;
-    const uint8_t *nh = nullptr;
+// Optional LDS extra of the stream walk (flattened scenes; renderer option hit_lds, docs/HISTORY.md round 5): the lane's closest hit so far keeps its U, V, |det| and
+// triangle id in four words of LDS, written when a closer hit is found, so that a finished ray is reported from LDS instead of fetching the winning packet again and
+// re-running its triangle test at refill time (a dependent round trip and ~100 VALU instructions at a quarter of the lanes, three to four times per 64 rays).
+// (Staging the top levels of the tree in LDS beside it — BASELINE.json's "LDS-staged BVH nodelets" — measured -5 ... -8 % in four forms and was removed in round 6:
+// those nodes already hit L1 and the kernel is issue-bound; profiles/r05_lds_top_ab.txt, docs/HISTORY.md.)
+struct NoExt { static constexpr bool hit_lds = false, root_pre = false; float *hit = nullptr; uint32_t *root = nullptr; };      // (members never read: every use sits behind a flag)
+template <bool HIT> struct StreamExt {
+    static constexpr bool hit_lds = HIT, root_pre = HIT && MRT_ROOT_AT_FETCH != 0;
+    float *hit;             // HIT: [4][64] words of this wave: U, V, |det|, triangle id (bits) of the lane's closest hit so far
     uint32_t *root = nullptr;      // MRT_ROOT_AT_FETCH: [2][64] words of this wave: the root's {internal-child hits, leaf-triangle hits} of the prefetched batch's rays
 };
-constexpr uint32_t HIT_LDS_WORDS = 256u + (MRT_NH_LUT ? NH_LUT_WORDS : 0u) + (MRT_ROOT_AT_FETCH ? 128u : 0u);      // per wave, in front of its stack
+constexpr uint32_t HIT_LDS_WORDS = 256u + (MRT_ROOT_AT_FETCH ? 128u : 0u);      // per wave, in front of its stack
 //
 // TWO_LEVEL (scenes committed with instancing = 1, two_level.hip): wnodes[0 ..] is an 8-wide TLAS whose leaf children are single instances
 // (the "packet" tri_base + k is an entry of wtlas_index), followed by the BLASes' nodes with absolute indices.  The same loop walks both levels on
@@ -730,7 +612,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 if constexpr (Ext::root_pre) {
                     if (batch_n != 0u && s.num_wnodes != 0) {          // (wave-uniform) the root against every ray of the batch, here
                         const float4 *__restrict__ nd = s.wnodes;
-                        const float4 r0_ = nd[0], r1_ = nd[1], r2_ = nd[2], r3_ = nd[3], r4_ = nd[WNODE_N4];
+                        const float4 r0_ = nd[0], r1_ = nd[1], r2_ = nd[2], r3_ = nd[3], r4_ = nd[4];
                         if (lane < batch_n) {
                             const f3 o_ = mk3(pA.x, pA.y, pA.z);
                             const float ix_ = box_inv(pB.x), iy_ = box_inv(pB.y), iz_ = box_inv(pB.z);
@@ -763,7 +645,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     if constexpr (Ext::root_pre) {
                         if (s.num_wnodes != 0) {          // the root was tested when the batch was fetched: its children are the lane's first group
                             const float4 q1_ = s.wnodes[1];
-                            g_base = __float_as_uint(q1_.x) & WNODE_BASE_MASK; g_mask = (ext.root[sl] << 8) | (__float_as_uint(s.wnodes[0].w) >> 24);
+                            g_base = __float_as_uint(q1_.x); g_mask = (ext.root[sl] << 8) | (__float_as_uint(s.wnodes[0].w) >> 24);
                             t_base = __float_as_uint(q1_.y); t_mask = ext.root[64u + (uint32_t)sl];
                         }
                     }
@@ -847,12 +729,7 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                     uint32_t id = s.wtlas_index[tl_slot];
                     MRT_BOUND(id, s.num_inst, 4);
                     if (s.inst[id].ntri > 8u && !pq_refused) {
-#if MRT_TL_FAT
-                        const InstanceDev &I_ = s.inst[id];
-                        const bool pushed = pq.push(qi, id, best_t, tagw, to_object_point(I_, o), to_object_dir(I_, d), I_.wroot);
-#else
                         const bool pushed = pq.push(qi, id, best_t, tagw);
-#endif
                         if (!pushed) { pq_refused = true; keep |= 1u << k; }      // refused (the queue is full): this lane walks its large instances in place from here on
                     }
                     else keep |= 1u << k;
@@ -937,13 +814,8 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
         if (want_node) {
             MRT_BOUND(pending, s.num_wnodes, 1);
-            if (Ext::top_lds && pending < ext.top_n) {          // a node of the top levels: from the workgroup's copy in LDS
-                const float4 *nd = ext.top + WNODE_STRIDE * pending;
-                n0 = lds_f4(nd); n1 = lds_f4(nd + 1); n2 = lds_f4(nd + 2); n3 = lds_f4(nd + 3); n4 = lds_f4(nd + WNODE_N4);
-            } else {
-                const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
-                n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[WNODE_N4];
-            }
+            const float4 *__restrict__ nd = s.wnodes + WNODE_STRIDE * (size_t)pending;
+            n0 = nd[0]; n1 = nd[1]; n2 = nd[2]; n3 = nd[3]; n4 = nd[4];
         }
         auto consider = [&](const float4 q0, const float4 q1, const float4 q2, const uint32_t pk_index) {
             float t, U, V, ad;
@@ -998,11 +870,11 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
         if (want_node && live) {
             uint32_t node_hits, tri_hits;
-            wide_node_test<MRT_WIDE_SCALED != 0, Ext::nh_lut>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits, ext.nh);
+            wide_node_test<MRT_WIDE_SCALED != 0>(n0, n1, n2, n3, n4, o, ix, iy, iz, nx, ny, nz, oct, 0.0f, best_t, node_hits, tri_hits);
             uint32_t sp = TWO_LEVEL ? (g_mask >> 16) & 0xFFu : g_mask >> 16;
             const uint32_t isp = TWO_LEVEL ? g_mask & 0xFF000000u : 0u;
             if ((g_mask & 0xFF00u) != 0) { wstack_push(stack, sp, lane, g_base, g_mask & 0xFFFFu); sp++; }     // siblings still to visit
-            g_base = __float_as_uint(n1.x) & WNODE_BASE_MASK; g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
+            g_base = __float_as_uint(n1.x); g_mask = isp | (sp << 16) | (node_hits << 8) | (__float_as_uint(n0.w) >> 24);
             if (SPEC && t_mask != 0u) { u_base = __float_as_uint(n1.y); u_mask = tri_hits; }      // (u is empty here: the lane asked for a node with t_rest != 0 only then)
             else { t_base = __float_as_uint(n1.y); t_mask = tri_hits; }
         }

@@ -284,7 +284,8 @@ __global__ void k_validate_wide(const float4 *__restrict__ wnodes, uint32_t firs
 // query after a commit: an index outside its array is now refused HERE, with a message, instead of being dereferenced by a
 // kernel.  Cost: one download of the nodes checked (80 B each) and a host loop — about a millisecond per 100 K nodes, once per commit; a
 // TLAS-only update re-checks only the TLAS slots, the instance rows and the index arrays (microseconds).
-int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only) {
+int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only, const float4 *wnodes_override) {
+    const float4 *const wnodes = wnodes_override ? wnodes_override : sc.wnodes.p;
     auto bad = [&](const std::string &what) { set_error("scene layout validation failed: " + what); return MRT_ERR_STATE; };
     const bool two = sc.num_inst > 0;
     const uint32_t NW = sc.num_wnodes;
@@ -331,7 +332,7 @@ int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only) {
     const uint32_t tl_last = two ? std::min(NW, sc.tlas_wcap) : 0u;
     if (tl_last) {
         std::vector<float4> wn(5 * (size_t)tl_last);
-        MRT_HIP(hipMemcpyAsync(wn.data(), sc.wnodes.p, wn.size() * 16, hipMemcpyDeviceToHost, stream));
+        MRT_HIP(hipMemcpyAsync(wn.data(), wnodes, wn.size() * 16, hipMemcpyDeviceToHost, stream));
         MRT_HIP(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < tl_last; i++) {
             uint32_t w0[4], w1[4]; memcpy(w0, &wn[5 * (size_t)i], 16); memcpy(w1, &wn[5 * (size_t)i + 1], 16);
@@ -357,7 +358,7 @@ int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only) {
     if (last > first) {
         DevBuf<unsigned long long> d_err; MRT_HIP(d_err.alloc(1));
         MRT_HIP(hipMemsetAsync(d_err.p, 0xFF, 8, stream));
-        hipLaunchKernelGGL(k_validate_wide, dim3((last - first + 255) / 256), dim3(256), 0, stream, (const float4 *)sc.wnodes.p, first, last, NW, sc.tlas_wcap, two ? 1u : 0u, (unsigned long long)packets, d_err.p);
+        hipLaunchKernelGGL(k_validate_wide, dim3((last - first + 255) / 256), dim3(256), 0, stream, wnodes, first, last, NW, sc.tlas_wcap, two ? 1u : 0u, (unsigned long long)packets, d_err.p);
         unsigned long long e = 0;
         MRT_HIP(hipMemcpyAsync(&e, d_err.p, 8, hipMemcpyDeviceToHost, stream));
         MRT_HIP(hipStreamSynchronize(stream));
@@ -476,9 +477,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.bpackets_offset = 4 * nodes_total;
     MRT_HIP(out.tri_shade.alloc(std::max<size_t>(ts_total, 1)));
     MRT_HIP(out.normals.alloc(std::max<size_t>(V_total, 1)));
-    if (opt.fat_shade && ts_total) MRT_HIP(out.tri_fat.alloc(3 * ts_total)); else out.tri_fat.release();      // a BLAS's fat shading records (its own vertex ids resolved by build_flat), concatenated like tri_shade
     for (size_t b = 0; b < B; b++) {
-        if (out.tri_fat.n > 1 && blas[b].stats.triangles) MRT_HIP(hipMemcpyAsync(out.tri_fat.p + 3 * (size_t)ts_base[b], blas[b].tri_fat.p, (size_t)blas[b].stats.triangles * 48, hipMemcpyDeviceToDevice, stream));
         const size_t nn = blas[b].rope_nodes, nt = blas[b].stats.triangles, nv = meshes[blas_src[b]].positions.size() / 3;
         if (nn) MRT_HIP(hipMemcpyAsync(out.bnodes.p + 4 * (size_t)node_base[b], blas[b].nodes.p, nn * 64, hipMemcpyDeviceToDevice, stream));
         if (nt) MRT_HIP(hipMemcpyAsync(out.bnodes.p + out.bpackets_offset + 3 * (size_t)packet_base[b], blas[b].nodes.p + blas[b].packets_offset, nt * 48, hipMemcpyDeviceToDevice, stream));
@@ -540,7 +539,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
-    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (out.tri_fat.n > 1 ? (uint64_t)ts_total * 48 : 0) + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
+    out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
     out.validated_blas = false;            // the BLAS part of wnodes is new: update_tlas checks all of it this time
     return update_tlas(meshes, stream, out);
 }

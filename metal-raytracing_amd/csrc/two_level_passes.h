@@ -13,7 +13,7 @@
 // k_shade<.., PAIRS> of the next bounce turns a key back into a hit record (the winning triangle re-tested in object space: the traversal's own arithmetic).
 __global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
                                                                  const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                 uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words, float4 *__restrict__ hituv) {
+                                                                 uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n_shadow = (uint32_t)(c >> 32), n = n_next + n_shadow;
@@ -32,7 +32,6 @@ __global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s,
             if (is_any) { if (!hit) lit[4 * (size_t)j] = 1; }          // not occluded at the TLAS level: lit unless one of its pairs finds an occluder
             else {
                 __builtin_nontemporal_store(hit ? ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | h.gid : ~0ull, &keys[j]);      // (+ 0.0f: a distance of -0 must order as 0)
-                if (MRT_TL_HITUV && hit) qstore(&hituv[j], make_float4(h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid), h.t));      // the hit's barycentrics beside its key (k_shade<.., PAIRS> takes them when the id matches the key's)
             }
         }, nullptr, pq);
     pq.close();
@@ -43,13 +42,9 @@ __global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s,
 // before that bound.  A refused pair (queue full) is walked here, one ray per lane (traverse_wide from the BLAS root).  Pairs leave instance-major, so the BLAS pass's waves see one
 // instance at a time.  The stream walk of the 8-wide TLAS (k_tl_top) spent 1.16 ms per launch on the 12 M rays of an 8-frame pass of dragon x 4, refilling lanes every other iteration; this takes them in 0.53 ms (profiles/r04_two_level_binned_ab.txt).
 constexpr uint32_t TL_FLAT_MAX_INSTANCES = 64;
-#ifndef MRT_TL_WORLD_BOX
-#define MRT_TL_WORLD_BOX 0      // 1: the flat TLAS pass queues a pair on the instance's WORLD box (one reciprocal per ray, ~16 instructions per instance) and the BLAS pass tests the BLAS's own box in object space when it fetches the pair.  Measured on dragon x 4: 9.12-9.18 against 9.29-9.34 Grays/s, the passes alone 1.00 against 0.95 ms per launch — the looser boxes queue more pairs than the cheaper test saves (profiles/r05_two_level_ab.txt)
-#endif
-static_assert(!(MRT_TL_WORLD_BOX == 1 && MRT_TL_FAT), "fat pairs carry the object-space ray: they need the TLAS pass's transform");
 __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
                                                     const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                    uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words, float4 *__restrict__ hituv) {
+                                                    uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t stack_words) {
     extern __shared__ uint32_t stk_dyn[];
     const unsigned long long c = *counts;
     const uint32_t n_next = (uint32_t)c, n = n_next + (uint32_t)(c >> 32);
@@ -66,7 +61,6 @@ __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *_
     const f3 o = mk3(A), d = mk3(B);
     const uint32_t tagw = sh ? (__float_as_uint(B.w) | 0x80000000u) : j;      // what the BLAS pass reports to: the pixel's byte (shadow) / the ray's key
     float best_t = A.w; uint32_t best_gid = 0xFFFFFFFFu; bool done = !active;
-    float best_U = 0.0f, best_V = 0.0f, best_ad = 1.0f;          // (MRT_TL_HITUV) of the closest hit so far
     for (uint32_t id = 0; id < s.num_inst; id++) {                  // the small instances, in place
         const InstanceDev &I = s.inst[id];
         if (I.ntri == 0u || I.ntri > 8u || s.inst_box[4 * id].x > s.inst_box[4 * id + 1].x) continue;          // (wave-uniform)
@@ -78,65 +72,10 @@ __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *_
             if (!done && tri_test(q0, q1, q2, oo, dd, 0.0f, best_t, t, U, V, ad)) {
                 const uint32_t gid = I.gid_base + __float_as_uint(q0.w);
                 if (sh) done = true;                                // occluded: lit stays 0
-                else if (t < best_t || gid < best_gid) { best_t = t; best_gid = gid; best_U = U; best_V = V; best_ad = ad; }      // (t <= best_t here: ties go to the lowest global id)
+                else if (t < best_t || gid < best_gid) { best_t = t; best_gid = gid; }      // (t <= best_t here: ties go to the lowest global id)
             }
         }
     }
-#if MRT_TL_WORLD_BOX == 2
-    // the large instances [r5], candidates first: the instances whose WORLD box the ray enters before its bound (wave-uniform boxes, one reciprocal direction per ray) as a
-    // bit mask per lane; then every lane takes ITS candidates in turn — its own instance row, the ray in object space, the BLAS's own box, the push — so the ~100
-    // instructions of that second test run max-over-lanes(candidates) times instead of once per instance
-    {
-    const float wix = box_inv(d.x), wiy = box_inv(d.y), wiz = box_inv(d.z);
-    const float wox = -(o.x * wix), woy = -(o.y * wiy), woz = -(o.z * wiz);
-    unsigned long long cand = 0ull;
-    for (uint32_t id = 0; id < s.num_inst; id++) {
-        const float4 wlo = s.inst_box[4 * id + 2], whi = s.inst_box[4 * id + 3];
-        if (s.inst[id].ntri <= 8u || wlo.x > whi.x) continue;          // (wave-uniform)
-        if (!done && rope_box_hit(wlo, whi, wix, wiy, wiz, wox, woy, woz, 0.0f, best_t)) cand |= 1ull << id;
-    }
-    while (cand != 0ull) {          // (divergent: a lane leaves when it has no candidate left)
-        const uint32_t id = (uint32_t)__ffsll((long long)cand) - 1u; cand &= cand - 1ull;
-        const InstanceDev &I = s.inst[id];
-        const float4 blo = s.inst_box[4 * id], bhi = s.inst_box[4 * id + 1];
-        const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
-        const float ix = box_inv(dd.x), iy = box_inv(dd.y), iz = box_inv(dd.z);
-        if (!done && rope_box_hit(blo, bhi, ix, iy, iz, -(oo.x * ix), -(oo.y * iy), -(oo.z * iz), 0.0f, best_t)) {
-            if (!pq.push(i, id, best_t, tagw, oo, dd, I.wroot)) {                    // the queue is full: this instance is walked here
-                TravHit h;
-                if (traverse_wide<false, false, true>(s, oo, dd, 0.0f, best_t, h, stk_dyn, nullptr, sh, I.wroot)) {
-                    if (sh) done = true;
-                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; best_U = h.U; best_V = h.V; best_ad = h.ad; } }
-                }
-            }
-        }
-    }
-    }
-#elif MRT_TL_WORLD_BOX
-    // the large instances [r5]: a pair where the ray enters the instance's WORLD box before its bound — one reciprocal direction per ray and a slab test per instance against
-    // wave-uniform boxes (~16 instructions) instead of a transform, three reciprocals and the test against the BLAS's own box in object space (~100) for every instance and ray;
-    // the BLAS pass, which takes the ray into object space anyway, makes that second test when it fetches the pair (k_tl_blas) and drops the pair there
-    {
-    const float wix = box_inv(d.x), wiy = box_inv(d.y), wiz = box_inv(d.z);
-    const float wox = -(o.x * wix), woy = -(o.y * wiy), woz = -(o.z * wiz);
-    for (uint32_t id = 0; id < s.num_inst; id++) {
-        const InstanceDev &I = s.inst[id];
-        const float4 wlo = s.inst_box[4 * id + 2], whi = s.inst_box[4 * id + 3];
-        if (I.ntri <= 8u || wlo.x > whi.x) continue;          // (wave-uniform)
-        const bool enters = !done && rope_box_hit(wlo, whi, wix, wiy, wiz, wox, woy, woz, 0.0f, best_t);
-        if (enters) {
-            if (!pq.push(i, id, best_t, tagw)) {                    // the queue is full: this instance is walked here
-                const f3 oo = to_object_point(I, o), dd = to_object_dir(I, d);
-                TravHit h;
-                if (traverse_wide<false, false, true>(s, oo, dd, 0.0f, best_t, h, stk_dyn, nullptr, sh, I.wroot)) {
-                    if (sh) done = true;
-                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; best_U = h.U; best_V = h.V; best_ad = h.ad; } }
-                }
-            }
-        }
-    }
-    }
-#else
     for (uint32_t id = 0; id < s.num_inst; id++) {                  // the large instances: a pair where the ray enters the BLAS's box before its bound
         const InstanceDev &I = s.inst[id];
         const float4 blo = s.inst_box[4 * id], bhi = s.inst_box[4 * id + 1];
@@ -145,21 +84,19 @@ __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *_
         const float ix = box_inv(dd.x), iy = box_inv(dd.y), iz = box_inv(dd.z);
         const bool enters = !done && rope_box_hit(blo, bhi, ix, iy, iz, -(oo.x * ix), -(oo.y * iy), -(oo.z * iz), 0.0f, best_t);
         if (enters) {
-            if (!pq.push(i, id, best_t, tagw, oo, dd, I.wroot)) {                    // the queue is full: this instance is walked here
+            if (!pq.push(i, id, best_t, tagw)) {                    // the queue is full: this instance is walked here
                 TravHit h;
                 if (traverse_wide<false, false, true>(s, oo, dd, 0.0f, best_t, h, stk_dyn, nullptr, sh, I.wroot)) {
                     if (sh) done = true;
-                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; best_U = h.U; best_V = h.V; best_ad = h.ad; } }
+                    else { const uint32_t gid = I.gid_base + h.gid; if (h.t < best_t || gid < best_gid) { best_t = h.t; best_gid = gid; } }
                 }
             }
         }
     }
-#endif
     if (active) {
         if (sh) { if (!done) lit[4 * (size_t)(tagw & 0x7FFFFFFFu)] = 1; }          // not occluded so far: lit unless one of its pairs finds an occluder
         else {
             __builtin_nontemporal_store(best_gid != 0xFFFFFFFFu ? ((unsigned long long)__float_as_uint(best_t + 0.0f) << 32) | best_gid : ~0ull, &keys[j]);
-            if (MRT_TL_HITUV && best_gid != 0xFFFFFFFFu) qstore(&hituv[j], make_float4(best_U / best_ad, best_V / best_ad, __uint_as_float(best_gid), best_t));
         }
     }
     }
@@ -167,21 +104,12 @@ __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *_
 }
 __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
                                                                    const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap, float4 *__restrict__ hituv) {
+                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
     extern __shared__ uint32_t stk_dyn[];
     const uint32_t n_next = (uint32_t)*counts, np = min(*pair_count, pair_cap / PairQueue::BLOCK * PairQueue::BLOCK);        // whole blocks only (blocks beyond the capacity were refused — their rays walked in place — but counted)
     if (blockIdx.x * chunk >= np) return;
     traverse_wide_stream<false, false, true>(s, SharedCounter{work, np, chunk}, stk_dyn,
         [&](uint32_t k, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, uint32_t &root) {
-#if MRT_TL_FAT
-            // the pair IS the ray, in its instance's object space (direction not renormalised: t stays the world distance), with the bound its ray had when the TLAS pass queued it
-            const float4 *const rec = reinterpret_cast<const float4 *>(pairs) + 3 * (size_t)k;
-            const float4 P0 = qload(rec), P1 = qload(rec + 1), P2 = qload(rec + 2);
-            tag = k;
-            if (__float_as_uint(P2.x) == 0xFFFFFFFFu) { A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); is_any = 1u; root = 0u; return; }      // the unused rest of a wave's block: a ray that cannot hit anything
-            A = P0; B = make_float4(P1.x, P1.y, P1.z, 0.0f); is_any = __float_as_uint(P1.w) >> 31; root = __float_as_uint(P2.z);
-            return;
-#endif
             const float4 Pf = qload(reinterpret_cast<const float4 *>(&pairs[k]));
             const uint32_t i = __float_as_uint(Pf.x), id = __float_as_uint(Pf.y);
             if (i == 0xFFFFFFFFu) {          // the unused rest of a wave's block: a ray that cannot hit anything
@@ -194,35 +122,16 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView
             const f3 o = to_object_point(I, mk3(Aw)), d = to_object_dir(I, mk3(Bw));        // direction not renormalised: t stays the world distance
             float tmax = Aw.w;
             if (!sh) { const unsigned long long key = keys[j]; tmax = key == ~0ull ? __builtin_inff() : __uint_as_float((uint32_t)(key >> 32)); }      // what the ray has so far (TLAS-level hits; other pairs of the same ray may shorten it further while this one walks)
-#if MRT_TL_WORLD_BOX == 1
-            {   // the pair was queued on the instance's world box: the BLAS's own box, in object space, now that the ray is there (a pair it drops becomes a ray that cannot hit)
-                const float4 blo = s.inst_box[4 * id], bhi = s.inst_box[4 * id + 1];
-                const float ix = box_inv(d.x), iy = box_inv(d.y), iz = box_inv(d.z);
-                if (!rope_box_hit(blo, bhi, ix, iy, iz, -(o.x * ix), -(o.y * iy), -(o.z * iz), 0.0f, tmax)) tmax = -1.0f;
-            }
-#endif
             A = make_float4(o.x, o.y, o.z, tmax); B = make_float4(d.x, d.y, d.z, 0.0f);
             tag = k; is_any = sh ? 1u : 0u; root = I.wroot;
         },
         [&](uint32_t k, bool is_any, bool hit, const TravHit &h) {
             if (!hit) return;
-#if MRT_TL_FAT
-            const float4 *const rec = reinterpret_cast<const float4 *>(pairs) + 3 * (size_t)k;
-            if (is_any) { lit[4 * (size_t)(__float_as_uint(rec[1].w) & 0x7FFFFFFFu)] = 0; return; }          // occluded inside this instance
-            const float4 P2 = rec[2];
-            const uint32_t j = __float_as_uint(P2.x), gid = s.inst[__float_as_uint(P2.y)].gid_base + h.gid;      // (h.gid: the triangle's id inside its BLAS)
-            atomicMin(&keys[j], ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | (unsigned long long)gid);
-            // the barycentrics of THIS hit, with its id: if another pair of the same ray wins the key, or writes later, k_shade sees the ids differ and tests the winner itself
-            if (MRT_TL_HITUV) qstore(&hituv[j], make_float4(h.U / h.ad, h.V / h.ad, __uint_as_float(gid), h.t));
-            return;
-#endif
             const uint4 P = pairs[k];
             if (is_any) lit[4 * (size_t)(P.w & 0x7FFFFFFFu)] = 0;          // occluded inside this instance
             else {
                 const uint32_t gid = s.inst[P.y].gid_base + h.gid;      // (h.gid: the triangle's id inside its BLAS)
                 atomicMin(&keys[P.x], ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | (unsigned long long)gid);
-                // the barycentrics of THIS hit, with its id: if another pair of the same ray wins the key, or writes later, k_shade sees the ids differ and tests the winner itself
-                if (MRT_TL_HITUV) qstore(&hituv[P.x], make_float4(h.U / h.ad, h.V / h.ad, __uint_as_float(gid), h.t));
             }
         });
 }

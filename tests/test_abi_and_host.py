@@ -15,15 +15,20 @@ RES = os.path.join(ROOT, "assets", "Resources")
 
 
 def test_library_exports_every_declared_symbol(mrt):
-    hdr = open(os.path.join(ROOT, "include", "mrt_abi.h")).read()
+    # the host contract (mrt_abi.h) and the diagnostics header beside it (mrt_debug.h: tests, tools, bench.py — not installed with the ABI header)
+    hdr = open(os.path.join(ROOT, "include", "mrt_abi.h")).read() + open(os.path.join(ROOT, "include", "mrt_debug.h")).read()
+    hdr = re.sub(r"#ifdef MRT_DIAGNOSTICS.*?#endif", "", hdr, flags=re.S)          # (what only a diagnostics build exports)
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 40
+    abi_only = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mrt_abi.h")).read(), flags=re.S)
+    assert not re.findall(r"\bmrt_debug_[a-z0-9_]+\s*\(", abi_only), "mrt_debug_* entry points belong in mrt_debug.h"
     raw = C.CDLL(mrt.LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(raw, name), f"{name} declared in mrt_abi.h but not exported"
+        assert hasattr(raw, name), f"{name} declared in include/ but not exported"
     from metal_raytracing_amd import _ffi
-    assert declared == set(_ffi.SIGNATURES), "ctypes table and header disagree"
+    assert declared == set(_ffi.SIGNATURES), "ctypes table and headers disagree"
+    assert not hasattr(raw, "mrt_debug_poke_wnode"), "the release library must not export the node-poking aid (MRT_DIAGNOSTICS builds only)"
     assert mrt.lib.mrt_abi_version() == 2
 
 

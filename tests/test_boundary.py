@@ -20,7 +20,7 @@ def test_header_is_plain_c_and_cxx(tmp_path, compiler, std):
     if shutil.which(compiler) is None:
         pytest.skip(compiler + " not installed")
     src = tmp_path / ("t.c" if compiler == "gcc" else "t.cpp")
-    src.write_text('#include "mrt_abi.h"\n'
+    src.write_text('#include "mrt_abi.h"\n#include "mrt_debug.h"\n'
                    "int main(void) { MRTUniforms u; MRTLight l; MRTRenderStats s; (void)u; (void)l; (void)s;\n"
                    "  return (sizeof(MRTCamera) == 64 && sizeof(MRTLight) == 128 && sizeof(MRTUniforms) == 96 && sizeof(MRTMaterial) == 64 && sizeof(MRTRay) == 32 && sizeof(MRTIntersection) == 32) ? 0 : 1; }\n")
     exe = tmp_path / "t"

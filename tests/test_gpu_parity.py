@@ -378,14 +378,15 @@ def test_1080p_accumulation_identity(mrt, gpu_ctx, dragon1080):
 # ---------------------------------------------------------------- alternative traversal backends
 @pytest.mark.parametrize("backend", ["default", "rope_only", "wide_primary_stream", "rope_primary_in_shade", "rope_bounce", "one_frame_in_flight", "eight_frames_in_flight", "one_frame_per_pass", "three_frames_per_pass", "eight_frames_per_pass",
                                      "no_primary_hint", "persistent_always", "persistent_never", "small_persistent_grid", "one_work_counter",
-                                     "fat_shading_records", "no_hit_lds", "no_hit_lds_static_split", "lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid", "pooled_triangle_tests", "pooled_triangle_tests_small_grid", "pooled_triangle_tests_one_frame_passes", "primary_tile_walk", "primary_tile_walk_no_hint", "unpacked_shade", "packed_shade_one_frame_passes", "no_frame_bundle", "no_halton_table", "frame_bundle_passes_of_three", "frame_bundle_no_hint", "frame_bundle_walk", "frame_bundle_walk_passes_of_three", "frame_bundle_walk_no_hint", "stream_stride_static_split"])
+                                     "no_hit_lds", "no_hit_lds_static_split", "hit_lds_small_grid", "unpacked_shade", "packed_shade_one_frame_passes", "no_frame_bundle", "no_halton_table", "frame_bundle_passes_of_three", "frame_bundle_no_hint",
+                                     "stream_stride_static_split"])
 def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     """Every path a scene or option can reach must give the oracle's image: the default (every ray on the 8-wide layout; primary rays traced inside
     shade(0)), a scene without the 8-wide layout (rope kernels for everything), the primary rays on the 8-wide stream kernel / on the rope layout
     inside shade(0), bounce and shadow rays on the rope kernels (scene option rope = 1), and any pass shape / number of passes in flight."""
     w, h = 256, 144
     sc = mrt.DragonScene((w, h))
-    sopt = {"wide": 0} if backend.startswith("rope_only") else {"rope": 1} if backend in ("rope_bounce", "rope_primary_in_shade") else {"fat_shade": 1} if backend == "fat_shading_records" else None      # (fat_shade = 1: a 48-byte shading record per triangle holds its three normals: one gather per hit instead of tri_shade -> three normals)
+    sopt = {"wide": 0} if backend.startswith("rope_only") else {"rope": 1} if backend in ("rope_bounce", "rope_primary_in_shade") else None
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options=sopt)
     assert r.device_scene.stats.wide_layout == (0 if backend.startswith("rope_only") else 1)
     if backend == "wide_primary_stream": r.set_option("primary_wide", 1)
@@ -396,33 +397,21 @@ def test_traversal_backends_agree_with_oracle(mrt, orc, gpu_ctx, backend):
     if backend == "persistent_never": r.set_option("persistent", 0)
     if backend == "one_work_counter": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("xcd_counters", 0)      # (default: one counter and one eighth of every sub-frame's rays per XCD)
     if backend == "small_persistent_grid": r.set_option("persistent", 1); r.set_option("wave_slots", 96)      # a long drain phase on few waves
-    # the pulling launch with LDS extras (traverse_wide.h StreamExt): a finished ray reported from LDS; the top of the tree staged in LDS, per wave or per 256-thread workgroup
+    # the pulling launch reports a finished ray from LDS (traverse_wide.h StreamExt, the default)
     if backend == "no_hit_lds": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("hit_lds", 0)      # the pulling launch without LDS extras (round 4's kernel)
-    # triangle tests pooled across the lanes of a wave (traverse_wide_pool.h): the pulling launch; a few waves (long drains: the ring runs nearly empty); one-frame passes on three lanes
-    if backend.startswith("pooled_triangle_tests"):
-        r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("pool", 1)
-        if backend.endswith("small_grid"): r.set_option("wave_slots", 96)
-        if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 3)
-    if backend.startswith("primary_tile_walk"):              # the 64 primary rays of a tile walk the top of the tree together (traverse_wide_tile.h)
-        r.set_option("tile_walk", 1)
-        if backend.endswith("no_hint"): r.set_option("primary_hint", 0)
-    if backend.startswith("packed_shade"):                  # k_shade of bounces 1, 2 compacts the hits of its queue in LDS and shades them on full waves (k_shade<.., PACK>)
+    if backend.startswith("packed_shade"):                  # k_shade of bounces 1, 2 compacts the hits of its queue in LDS and shades them on full waves (k_shade_pack)
         r.set_option("shade_pack", 1)          # (the default)
         if backend.endswith("one_frame_passes"): r.set_option("frame_batch", 1); r.set_option("frames_in_flight", 2)
     if backend == "no_halton_table": r.set_option("halton_table", 0)          # bounce 0's Halton values by the recurrence (default: a bundled pass reads them from the renderer's table, FrameParams::halton_tab)
     if backend == "no_frame_bundle": r.set_option("frame_bundle", 0)          # shade(0): a wave = the 64 pixels of one tile in one sub-frame (round 4's form)
     if backend.startswith("frame_bundle"):                  # shade(0) of a multi-frame pass: a wave takes 8 slots x 8 sub-frames (FrameParams::frame_bundle); 5 frames: three lanes of every eight idle
-        r.set_option("frame_bundle", 2 if "walk" in backend else 1)          # 1: the default; 2: and the eight rays of a slot walk the tree as one bundle, eight lanes per node (traverse_wide_bundle.h)
+        r.set_option("frame_bundle", 1)          # (the default)
         if backend.endswith("passes_of_three"): r.set_option("frame_batch", 3)
         if backend.endswith("no_hint"): r.set_option("primary_hint", 0)
     if backend == "stream_stride_static_split": r.set_option("persistent", 0); r.set_option("stream_stride", 1)      # the static split deals 64-ray batches round-robin to the waves (traverse_wide.h BatchStride)
     if backend == "unpacked_shade": r.set_option("shade_pack", 0)          # one queue entry per thread, hit or miss (round 4's form)
     if backend == "no_hit_lds_static_split": r.set_option("persistent", 0); r.set_option("hit_lds", 0)              # the static split without them (persistent_never runs it with them: the default)
-    if backend in ("lds_top_per_wave", "lds_top_workgroup", "lds_top_workgroup_two_levels", "workgroup_of_four_waves", "hit_lds_lds_top_small_grid"):
-        r.set_option("persistent", 1); r.set_option("persist_chunk", 64)
-        r.set_option("hit_lds", 1 if backend.startswith("hit_lds") else 0)          # (hit_lds = 1 is the default: these switch it off beside lds_top)
-        r.set_option("lds_top", {"hit_lds": 0, "lds_top_per_wave": 1, "lds_top_workgroup": 2, "lds_top_workgroup_two_levels": 3, "workgroup_of_four_waves": 4, "hit_lds_lds_top_small_grid": 2}[backend])
-        if backend == "hit_lds_lds_top_small_grid": r.set_option("wave_slots", 96)      # few waves: a long drain phase, where idle lanes test a straggler's triangles and hand their hit to its owner
+    if backend == "hit_lds_small_grid": r.set_option("persistent", 1); r.set_option("persist_chunk", 64); r.set_option("wave_slots", 96)      # few waves: a long drain phase, where idle lanes help a straggler and hand their hit to its owner
     if backend == "one_frame_in_flight": r.set_option("frames_in_flight", 1)
     if backend == "eight_frames_in_flight": r.set_option("frames_in_flight", 8)
     if backend.endswith("_per_pass"): r.set_option("frame_batch", {"one": 1, "three": 3, "eight": 8}[backend.split("_")[0]])   # default 8: 5 frames = one pass; three: 3 + 2
@@ -468,7 +457,7 @@ def test_tile_groups_render_the_same_image(mrt, orc, gpu_ctx, groups, size):
 
 @pytest.mark.parametrize("scene_name,size", [("dragon", (333, 187)), ("cornell", (64, 64)), ("cornell", (1000, 3)), ("garden", (257, 129)), ("dragon_hostile", (320, 180))])
 def test_packed_shade_at_ragged_sizes_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size):
-    """k_shade<.., PACK> (renderer option shade_pack) where the queue's length is no multiple of anything, on all four light types and on the hostile stand-in."""
+    """k_shade_pack (renderer option shade_pack) where the queue's length is no multiple of anything, on all four light types and on the hostile stand-in."""
     w, h = size
     sc = mrt.SCENES[scene_name]((w, h))
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
@@ -480,31 +469,15 @@ def test_packed_shade_at_ragged_sizes_and_other_scenes(mrt, orc, gpu_ctx, scene_
     r.close()
 
 
-@pytest.mark.parametrize("scene_name,size", [("dragon", (333, 187)), ("cornell", (64, 64)), ("cornell", (1000, 3)), ("garden", (257, 129)), ("dragon_hostile", (320, 180))])
-def test_primary_tile_walk_at_ragged_sizes_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size):
-    """The tile walk of the primary rays (renderer option tile_walk) where tiles are partial (lanes outside the image take part in the wave's steps), where a tile's
-    directions change sign (the image centre: those tiles walk from the root), on the garden's many instances and on the hostile stand-in: the oracle's image and counts."""
-    w, h = size
-    sc = mrt.SCENES[scene_name]((w, h))
-    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
-    r.set_option("tile_walk", 1)
-    r.draw(3, wait=True); r.draw(2, wait=True)
-    ref, cnt = oracle_render(orc, mrt, sc, w, h, 5)
-    assert_parity(r.accumulation(), ref)
-    assert (r.stats.closest_rays, r.stats.shadow_rays) == cnt
-    r.close()
-
-
-@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("scene_name,size,batch", [("dragon", (333, 187), 8), ("cornell", (64, 64), 12), ("cornell", (1000, 3), 5), ("garden", (257, 129), 8), ("dragon_hostile", (320, 180), 6), ("dragon4", (192, 108), 7)])
-def test_frame_bundle_at_ragged_sizes_batches_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size, batch, level):
+def test_frame_bundle_at_ragged_sizes_batches_and_other_scenes(mrt, orc, gpu_ctx, scene_name, size, batch):
     """shade(0) with eight sub-frames of a slot side by side in a wave (renderer option frame_bundle): passes of more than eight frames (two groups per slot), of fewer
     (idle lanes), partial tiles, the image's centre row and column (bundles whose directions change sign walk one ray per lane), the hostile stand-in and a two-level scene
-    (dragon x 4 as instances) must give the oracle's image and counts — with the one-ray-per-lane walk (level 1) and with the bundle walk (level 2, traverse_wide_bundle.h)."""
+    (dragon x 4 as instances) must give the oracle's image and counts."""
     w, h = size
     sc = mrt.SCENES[scene_name]((w, h))
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1} if scene_name == "dragon4" else None)
-    r.set_option("frame_bundle", level); r.set_option("frame_batch", batch)          # (level 2 on the two-level scene: the mapping alone — the bundle walk is for flattened scenes)
+    r.set_option("frame_bundle", 1); r.set_option("frame_batch", batch)
     n = batch + 2
     r.draw(batch, wait=True); r.draw(2, wait=True)
     if scene_name == "dragon4":          # a two-level scene's rays are tested in object space: its oracle is the two-level one

@@ -265,14 +265,11 @@ def test_commit_validates_every_index_of_the_layout(mrt, gpu_ctx, instancing):
     sc = _scene(mrt, (64, 48))
     ds = mrt.DeviceScene(gpu_ctx, sc, {"instancing": instancing})
     assert lib.mrt_debug_validate(ds.handle) == 0
-    old = C.c_uint32()
     # word 4 = child_base, word 5 = tri_base of node 0: the flattened scene's root has internal children, the 6-instance TLAS root only leaf children
     cases = [(0, 5, 0x7FFFFFF0, "outside")] if instancing else [(0, 4, 0x00FFFFF0, "outside"), (0, 4, 0, "after their parent")]
     for node, word, value, what in cases:
-        assert lib.mrt_debug_poke_wnode(ds.handle, node, word, value, C.byref(old)) == 0
-        rc = lib.mrt_debug_validate(ds.handle)
+        rc = lib.mrt_debug_validate_patched(ds.handle, node, word, value)          # the validator on a copy of the nodes with that word replaced: the scene's own arrays stay as committed
         msg = lib.mrt_last_error().decode()
-        assert lib.mrt_debug_poke_wnode(ds.handle, node, word, old.value, None) == 0
         assert rc == 5 and "validation failed" in msg and what in msg, (rc, msg)
     assert lib.mrt_debug_validate(ds.handle) == 0
     ds.close()
