@@ -398,6 +398,13 @@ MRT_DEV bool traverse_wide_lane_two_level(const SceneView &s, const f3 wo, const
 #ifndef MRT_WIDE_REFILL_AT
 #define MRT_WIDE_REFILL_AT 16
 #endif
+// waves per SIMD the stream kernels are compiled for
+#ifndef MRT_TWO_LEVEL_WAVES
+#define MRT_TWO_LEVEL_WAVES 6
+#endif
+#ifndef MRT_WIDE_STREAM_WAVES
+#define MRT_WIDE_STREAM_WAVES (MRT_WIDE_SPEC ? 6 : 7)      // the second triangle group costs two registers: 80 instead of 72 (no spills); the frame rate does not depend on 6 or 7 waves per SIMD (docs/HISTORY.md §6)
+#endif
 constexpr int WIDE_REFILL_AT = MRT_WIDE_REFILL_AT;
 
 struct StreamStats {
