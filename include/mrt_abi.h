@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 2      /* 2: MRTSceneStats grew (wide_layout, wide_depth); the renderer's option keys split into mrt_renderer_set_option (six host keys) and mrt_debug_renderer_set_option */
+#define MRT_ABI_VERSION 3      /* 3: MRTSceneStats grew (wide_cost, wide_cost_built, refits: what a refit did to the tree); 2: (wide_layout, wide_depth), the renderer's option keys split into mrt_renderer_set_option (six host keys) and mrt_debug_renderer_set_option */
 
 /* ---------------------------------------------------------------- status codes */
 enum {
@@ -107,7 +107,7 @@ typedef struct {
     uint64_t bvh_leaves;
     uint64_t scene_bytes;      /* device bytes of nodes + triangle packets + shading tables    */
     float    build_ms;         /* device time of the last mrt_scene_commit                     */
-    float    sah_cost;         /* SAH cost of the emitted tree (Ct=1, Ci=1)                    */
+    float    sah_cost;         /* SAH cost of the emitted tree (Ct=1, Ci=1); after a refit: the build's figure x wide_cost / wide_cost_built */
     int32_t  instances;
     int32_t  max_submeshes;    /* resource-table stride (Renderer.swift:128-139)               */
     int32_t  max_leaf_tris;
@@ -117,6 +117,13 @@ typedef struct {
                                   the binary rope walk — about a third of the rate                                                        */
     int32_t  wide_depth;       /* levels of the 8-wide tree (two-level scenes: TLAS levels + 1 + the deepest BLAS); the traversal kernels'
                                   LDS stack is sized from it at every launch: 320 B per wave and level                                     */
+    float    wide_cost;        /* SAH cost of the 8-wide tree AS IT LIES IN MEMORY, per unit of root area: sum over child boxes (decoded as the
+                                  traversal decodes them) of area x (node cost | triangle cost x triangles).  Recomputed by every build and every
+                                  refit; two-level scenes: mean over the BLASes.  0 without the 8-wide layout                              */
+    float    wide_cost_built;  /* the same as the last BUILD left it: wide_cost / wide_cost_built is how much refits have loosened the tree —
+                                  the signal to build again (scene option "refit_max_cost_ratio" does it by itself)                         */
+    uint32_t refits;           /* commits served by a refit since the last build                                                          */
+    uint32_t _pad;
 } MRTSceneStats;
 
 typedef struct {

@@ -198,6 +198,7 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value) {
     else if (k == "wide_cost_tri") { REQUIRE(value > 0, "wide_cost_tri must be positive"); scene->opt.wide_cost_tri = (float)value; }
     else if (k == "instancing") { REQUIRE(value == 0 || value == 1, "instancing must be 0 (flatten) or 1 (two-level: shared BLAS per mesh + TLAS)"); scene->opt.instancing = (int)value; }
     else if (k == "refit") scene->opt.refit = value != 0;
+    else if (k == "refit_max_cost_ratio") { REQUIRE(value == 0 || value >= 1, "refit_max_cost_ratio must be 0 (off) or >= 1"); scene->opt.refit_max_cost_ratio = (float)value; }
     else if (k == "ploc_radius") { REQUIRE(value >= 1 && value <= 256, "ploc_radius must be in [1,256]"); scene->opt.ploc_radius = (int)value; }
     else { mrt::set_error("mrt_scene_set_option: unknown key " + k); return MRT_ERR_INVALID_ARGUMENT; }
     scene->committed = false; scene->only_transforms_changed = false; scene->only_vertices_changed = false;
@@ -210,6 +211,7 @@ int mrt_scene_commit(MRTScene scene) {
     int rc = bind_device(scene->ctx); if (rc) return rc;
     if (scene->only_transforms_changed && scene->opt.instancing && scene->dev.num_inst == scene->meshes.size())
         rc = mrt::update_tlas(scene->meshes, scene->ctx->stream, scene->dev);         // instance rows + TLAS; the BLASes stay (the refit of an animated scene)
+    else if (scene->only_vertices_changed && scene->opt.instancing && scene->opt.refit && (rc = mrt::refit_two_level(scene->meshes, scene->opt, scene->ctx->stream, scene->dev)) != MRT_ERR_UNSUPPORTED) {}      // the changed meshes' BLASes refitted in place + the TLAS
     else rc = mrt::build_scene(scene->meshes, scene->opt, scene->ctx->stream, scene->dev, scene->only_transforms_changed && !scene->opt.instancing, scene->only_vertices_changed && !scene->opt.instancing);
     if (rc) return rc;
     scene->only_transforms_changed = false; scene->only_vertices_changed = false;

@@ -984,6 +984,86 @@ __global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------ refit of a rope layout (the BLASes of a two-level scene keep one: the query API and the in-place fallbacks walk it)
+// Same topology, new boxes: every internal node notes itself as its children's parent; then one thread per LEAF takes its box from its triangles' padded boxes (by the id each
+// packet carries) and climbs — the second thread to arrive at a node (a counter per node) unions the children's boxes and goes on.  The hand-off is k_refit's: 16-byte
+// write-through stores, drained before the agent-scope arrival, sc1 loads after it.  Escape links and near-child masks are the build's: order, not correctness.
+__global__ void k_rope_refit(float4 *nodes, uint32_t n, const float4 *__restrict__ packets, const float4 *__restrict__ tri_lo, const float4 *__restrict__ tri_hi,
+                             const uint32_t *__restrict__ parent, const uint2 *__restrict__ ab /* per node: its {a, b} words, copied before the pass */, uint32_t *__restrict__ arrived) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint2 w = ab[i];
+    if (!(w.x & NODE_LEAF)) return;
+    const __amdgpu_buffer_rsrc_t rn = refit_rsrc(nodes);
+    const float BIG = 3.0e38f;
+    float4 lo = make_float4(BIG, BIG, BIG, 0.0f), hi = make_float4(-BIG, -BIG, -BIG, 0.0f);
+    for (uint32_t r = 0; r < w.y; r++) {
+        const uint32_t gid = __float_as_uint(packets[3 * (size_t)((w.x & 0x7FFFFFFFu) + r)].w);
+        const float4 l = tri_lo[gid], h = tri_hi[gid];
+        lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z); hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+    }
+    for (;;) {
+        lo.w = __uint_as_float(w.x); hi.w = __uint_as_float(w.y);
+        refit_st_wt(rn, 4u * i, lo); refit_st_wt(rn, 4u * i + 1u, hi);
+        const uint32_t p = parent[i];
+        if (p == NONE) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   // this node's stores have left the CU ...
+        const uint32_t old = __hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before the arrival is counted
+        if (old == 0u) return;                       // the sibling subtree finishes this node
+        asm volatile("" ::: "memory");
+        w = ab[p];
+        const uint32_t l = w.x, r = w.y & NODE_INDEX_MASK;
+        const float4 llo = refit_ld_wt(rn, 4u * l), lhi = refit_ld_wt(rn, 4u * l + 1u), rlo = refit_ld_wt(rn, 4u * r), rhi = refit_ld_wt(rn, 4u * r + 1u);
+        lo = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
+        hi = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+        i = p;
+    }
+}
+// {a, b} of every rope node, and its children's parent links, in one pass
+__global__ void k_rope_prepare(const float4 *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ parent, uint2 *__restrict__ ab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = __float_as_uint(nodes[4 * (size_t)i].w), b = __float_as_uint(nodes[4 * (size_t)i + 1].w);
+    ab[i] = make_uint2(a, b);
+    if (i == 0) parent[0] = NONE;
+    if (!(a & NODE_LEAF)) { parent[a] = i; parent[b & NODE_INDEX_MASK] = i; }
+}
+
+// SAH cost of the 8-wide tree AS IT LIES IN MEMORY — what a refit changes and the build's sah_cost (the binary tree's) cannot show: the sum over all child boxes, decoded from
+// their planes as the traversal decodes them, of area x (c_node for an internal child: one more node visit; c_tri per triangle for a leaf child).  The root's own visit and the
+// normalisation by the root's area are the host's (wide_tree_cost).  *sum = that sum; rbox[0 .. 5] = the box of node `root` (the union of its children's boxes), as order-preserving
+// uints (f2ord) through atomicMin / atomicMax.
+__global__ void k_wide_cost(const float4 *__restrict__ wnodes, uint32_t first, uint32_t count, uint32_t root, float c_node, float c_tri, double *__restrict__ sum, uint32_t *__restrict__ rbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    double mine = 0.0;
+    if (i < count) {
+        const size_t w = WNODE_STRIDE * (size_t)(first + i);
+        const float4 n0 = wnodes[w], n1 = wnodes[w + 1], p2 = wnodes[w + 2], p3 = wnodes[w + 3], p4 = wnodes[w + 4];
+        const uint32_t ew = __float_as_uint(n0.w), imask = ew >> 24, meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
+        const float org[3] = {n0.x, n0.y, n0.z};
+        const uint32_t pl[6][2] = {{__float_as_uint(p2.x), __float_as_uint(p2.y)}, {__float_as_uint(p2.z), __float_as_uint(p2.w)}, {__float_as_uint(p3.x), __float_as_uint(p3.y)},
+                                   {__float_as_uint(p3.z), __float_as_uint(p3.w)}, {__float_as_uint(p4.x), __float_as_uint(p4.y)}, {__float_as_uint(p4.z), __float_as_uint(p4.w)}};
+        float st[3];
+        for (int a = 0; a < 3; a++) st[a] = __builtin_ldexpf(1.0f, (int)(int8_t)((ew >> (8 * a)) & 0xFFu));
+        for (int sl = 0; sl < 8; sl++) {
+            const uint32_t m = (meta[sl >> 2] >> (8 * (sl & 3))) & 0xFFu, cnt = m >> 5;
+            const bool inner = ((imask >> sl) & 1u) != 0u;
+            if (!inner && cnt == 0u) continue;
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                lo[a] = __builtin_fmaf((float)((pl[a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu), st[a], org[a]);
+                hi[a] = __builtin_fmaf((float)((pl[3 + a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu), st[a], org[a]);
+            }
+            const float dx = fmaxf(hi[0] - lo[0], 0.0f), dy = fmaxf(hi[1] - lo[1], 0.0f), dz = fmaxf(hi[2] - lo[2], 0.0f);
+            const float area = 2.0f * (dx * dy + dy * dz + dz * dx);
+            mine += (double)area * (inner ? (double)c_node : (double)c_tri * (double)cnt);
+            if (first + i == root) for (int a = 0; a < 3; a++) { atomicMin(&rbox[a], f2ord(lo[a])); atomicMax(&rbox[3 + a], f2ord(hi[a])); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine != 0.0) atomicAdd(sum, mine);
+}
+
 // diagnostics: how full are the 8-wide nodes?  out[c] = nodes with c children (c = 0..8), out[9] = internal children, out[10] = leaf children, out[11] = triangles
 __global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, uint32_t *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -997,6 +1077,91 @@ __global__ void k_wide_histogram(const float4 *__restrict__ wnodes, uint32_t n, 
 }
 
 }  // namespace
+
+// cost of the subtree of 8-wide nodes [first, first + count) rooted at `root`, per unit of the root's area: (c_node x area(root) + k_wide_cost's sum) / area(root).  Blocks.
+int wide_tree_cost(const float4 *wnodes, uint32_t first, uint32_t count, uint32_t root, float c_node, float c_tri, hipStream_t stream, float *out) {
+    *out = 0.0f;
+    if (count == 0) return MRT_OK;
+    DevBuf<double> d_sum; DevBuf<uint32_t> d_box;
+    MRT_HIP(d_sum.alloc(1)); MRT_HIP(d_box.alloc(6));
+    const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    MRT_HIP(hipMemsetAsync(d_sum.p, 0, 8, stream));
+    MRT_HIP(hipMemcpyAsync(d_box.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_wide_cost, dim3(cdiv(count, 256)), dim3(256), 0, stream, wnodes, first, count, root, c_node, c_tri, d_sum.p, d_box.p);
+    double h_sum = 0.0; uint32_t h_box[6];
+    MRT_HIP(hipMemcpyAsync(&h_sum, d_sum.p, 8, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipMemcpyAsync(h_box, d_box.p, sizeof h_box, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    float b[6];
+    for (int k = 0; k < 6; k++) b[k] = ord2f(h_box[k]);
+    const double dx = std::max(0.0f, b[3] - b[0]), dy = std::max(0.0f, b[4] - b[1]), dz = std::max(0.0f, b[5] - b[2]);
+    const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+    *out = area > 0.0 ? (float)((c_node * area + h_sum) / area) : 0.0f;
+    return MRT_OK;
+}
+
+// Refit of ONE BLAS of a two-level scene in the scene's shared arrays (two_level.hip refit_two_level): the mesh's new object-space triangles (k_flatten under the identity),
+// the BLAS's packets of both layouts rewritten by the id each carries, its 8-wide nodes [wnode_base, + wnodes) bottom-up level by level (k_refit_wide_level: child and packet
+// indices in there are absolute, the triangle arrays are the BLAS's own), its rope nodes by k_rope_refit, its normals.  Leaves the BLAS's root box (object space) in root_lo / root_hi.
+int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out) {
+    const size_t nv = g.positions.size() / 3, T = br.ntri;
+    if (T == 0 || br.wnodes == 0 || g.normals.size() != g.positions.size()) { set_error("refit_blas: nothing to refit"); return MRT_ERR_STATE; }
+    static_assert(WPK == 3, "k_refit_wide_packets serves both packet arrays at a stride of three float4");
+    std::vector<SubRec> recs; std::vector<uint32_t> idx; idx.reserve(3 * T);
+    size_t tb = 0;
+    for (size_t s = 0; s < g.sub_indices.size(); s++) {
+        const auto &ix = g.sub_indices[s];
+        if (ix.empty()) continue;
+        recs.push_back(SubRec{(uint32_t)tb, (uint32_t)(ix.size() / 3), (uint32_t)idx.size(), 0u, 0u, (uint32_t)s});
+        idx.insert(idx.end(), ix.begin(), ix.end()); tb += ix.size() / 3;
+    }
+    if (tb != T) { set_error("refit_blas: the mesh's triangle count changed"); return MRT_ERR_STATE; }
+    std::vector<float4> h_nrm(nv);
+    for (size_t v = 0; v < nv; v++) h_nrm[v] = make_float4(g.normals[3 * v], g.normals[3 * v + 1], g.normals[3 * v + 2], 0.0f);
+    const float4 ident[4] = {make_float4(1, 0, 0, 0), make_float4(0, 1, 0, 0), make_float4(0, 0, 1, 0), make_float4(0, 0, 0, 0)};
+    ScratchArena arena; arena.chunk_bytes = ((size_t)T * (48 + 16 + 32 + 12) + nv * 12 + (size_t)out.wnodes.n / WNODE_STRIDE * 32 + (size_t)br.rope_nodes * 16 + ((size_t)1 << 20) + 255) & ~(size_t)255;
+    DevBuf<float> d_pos; DevBuf<uint32_t> d_idx, d_recs, cbounds, parent, arrived; DevBuf<uint2> ab; DevBuf<float4> cols, tri_world, tri_lo, tri_hi, nbox; DevBuf<uint4> ts_tmp; DevBuf<uint8_t> dirty;
+    MRT_HIP(d_pos.alloc_in(arena, 3 * nv)); MRT_HIP(d_idx.alloc_in(arena, idx.size())); MRT_HIP(d_recs.alloc_in(arena, 6 * recs.size())); MRT_HIP(cbounds.alloc_in(arena, 6)); MRT_HIP(cols.alloc_in(arena, 4));
+    MRT_HIP(tri_world.alloc_in(arena, 3 * T)); MRT_HIP(tri_lo.alloc_in(arena, T)); MRT_HIP(tri_hi.alloc_in(arena, T)); MRT_HIP(ts_tmp.alloc_in(arena, T));
+    MRT_HIP(nbox.alloc_in(arena, 2 * (out.wnodes.n / WNODE_STRIDE))); MRT_HIP(dirty.alloc_in(arena, 4));
+    MRT_HIP(parent.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1))); MRT_HIP(arrived.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1))); MRT_HIP(ab.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1)));
+    struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;
+    MRT_HIP(hipEventCreate(&evs.a)); MRT_HIP(hipEventCreate(&evs.b));
+    MRT_HIP(hipMemcpyAsync(d_pos.p, g.positions.data(), 12 * nv, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(d_recs.p, recs.data(), recs.size() * sizeof(SubRec), hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemcpyAsync(cols.p, ident, sizeof ident, hipMemcpyHostToDevice, stream));
+    MRT_HIP(hipMemsetAsync(dirty.p, 1, 4, stream));                       // the one "instance" of the BLAS's own triangle arrays moved
+    MRT_HIP(hipMemsetAsync(cbounds.p, 0, 24, stream));
+    MRT_HIP(hipMemsetAsync(arrived.p, 0, arrived.bytes(), stream));
+    MRT_HIP(hipEventRecord(evs.a, stream));
+    const uint32_t T32 = (uint32_t)T;
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, reinterpret_cast<const SubRec *>(d_recs.p), (int)recs.size(), d_pos.p, d_idx.p, cols.p, T32, tri_world.p, ts_tmp.p, tri_lo.p, tri_hi.p, cbounds.p);
+    // 8-wide layout
+    hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(T32, 256)), dim3(256), 0, stream, tri_world.p, out.wpackets.p + WPK * (size_t)br.packet_base, T32);
+    std::vector<uint32_t> first(br.wide_levels.size(), br.wnode_base);
+    for (size_t L = 1; L < br.wide_levels.size(); L++) first[L] = first[L - 1] + br.wide_levels[L - 1];
+    for (size_t L = br.wide_levels.size(); L-- > 0;)
+        hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(br.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, ts_tmp.p, dirty.p, nbox.p, first[L], br.wide_levels[L]);
+    // rope layout
+    float4 *const rn = out.bnodes.p + 4 * (size_t)br.node_base, *const rp = out.bnodes.p + out.bpackets_offset + 3 * (size_t)br.packet_base;
+    hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(T32, 256)), dim3(256), 0, stream, tri_world.p, rp, T32);
+    if (br.rope_nodes) {
+        hipLaunchKernelGGL(k_rope_prepare, dim3(cdiv(br.rope_nodes, 256)), dim3(256), 0, stream, (const float4 *)rn, br.rope_nodes, parent.p, ab.p);
+        hipLaunchKernelGGL(k_rope_refit, dim3(cdiv(br.rope_nodes, 256)), dim3(256), 0, stream, rn, br.rope_nodes, (const float4 *)rp, tri_lo.p, tri_hi.p, (const uint32_t *)parent.p, (const uint2 *)ab.p, arrived.p);
+    }
+    MRT_HIP(hipEventRecord(evs.b, stream));
+    MRT_HIP(hipMemcpyAsync(out.normals.p + br.vbase, h_nrm.data(), nv * 16, hipMemcpyHostToDevice, stream));
+    float4 h_box[2];
+    MRT_HIP(hipMemcpyAsync(h_box, nbox.p + 2 * (size_t)br.wnode_base, sizeof h_box, hipMemcpyDeviceToHost, stream));
+    MRT_HIP(hipStreamSynchronize(stream));
+    MRT_HIP(hipGetLastError());
+    float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, evs.a, evs.b));
+    if (ms_out) *ms_out = ms;
+    root_lo[0] = h_box[0].x; root_lo[1] = h_box[0].y; root_lo[2] = h_box[0].z; root_hi[0] = h_box[1].x; root_hi[1] = h_box[1].y; root_hi[2] = h_box[1].z;
+    return MRT_OK;
+}
 
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]) {
     memset(out12, 0, 48);
@@ -1264,11 +1429,18 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(hipStreamSynchronize(stream));
         MRT_HIP(hipGetLastError());
         float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-        out.stats = stats_before;          // the tree's shape, and what was measured on it (sah_cost is the build's: a refit does not re-evaluate it)
+        out.stats = stats_before;          // the tree's shape, and what was measured on it
         out.stats.build_ms = ms;
+        // what the refit did to the tree: the 8-wide tree's cost as it lies now against the build's (MRTSceneStats.wide_cost / wide_cost_built); sah_cost — the build's binary-tree figure — scaled alike
+        if (int rc = wide_tree_cost(out.wnodes.p, 0, out.num_wnodes, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc;
+        if (out.stats.wide_cost_built > 0.0f) out.stats.sah_cost = out.sah_cost_built * (out.stats.wide_cost / out.stats.wide_cost_built);
+        out.stats.refits = out.refits + 1;
         out.root_lo[0] = h_box[0].x; out.root_lo[1] = h_box[0].y; out.root_lo[2] = h_box[0].z; out.root_hi[0] = h_box[1].x; out.root_hi[1] = h_box[1].y; out.root_hi[2] = h_box[1].z;
         out.commit_ms[2] = since(tw2);
         out.refits++;
+        // scene option refit_max_cost_ratio: a tree that refits have loosened beyond that factor of its build-time cost is built again, here (the commit then costs a build)
+        if (opt.refit_max_cost_ratio > 0.0f && out.stats.wide_cost_built > 0.0f && out.stats.wide_cost > opt.refit_max_cost_ratio * out.stats.wide_cost_built)
+            return build_flat(refs, opt, stream, out, stage, false, false);
         return MRT_OK;
     }
     // ---- references: the build's leaves.  One per triangle, or several for a triangle much longer than the mean (k_split_emit)
@@ -1422,7 +1594,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
     out.stats.bvh_nodes = h_size; out.rope_nodes = 0;
     out.stats.bvh_leaves = h_stat[1];
     out.stats.max_depth = (int32_t)h_stat[0];
-    out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f;
+    out.stats.sah_cost = area > 0 ? h_cost / area : 0.0f; out.sah_cost_built = out.stats.sah_cost;
     out.stats.build_ms = ms;
     out.stats.scene_bytes = (uint64_t)T * 16 + (uint64_t)V * 16 + (uint64_t)I * max_sub * 20 + (uint64_t)I * 64;
     out.num_wnodes = 0; out.wide_depth = 0;
@@ -1470,7 +1642,9 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         out.stats.build_ms += wms;
         out.wide_depth = depth;
         out.wide_levels.assign(h_lv.begin(), h_lv.begin() + depth); out.refit_triangles = T;
-        if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
+        if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;
+        if (int rc = wide_tree_cost(out.wnodes.p, 0, total, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc;
+        out.stats.wide_cost_built = out.stats.wide_cost; out.sah_cost_built = out.stats.sah_cost;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;

@@ -197,10 +197,23 @@ struct BuildOptions {
                                                             // (0.45 ... 1.0 measured +1 ... +2 % on DragonScene, 0.5 against 0.3: garden 4K +1 %, dragon x 4 +3 ... +4 %, hostile +1.5 %, Cornell 256^2 +8 ... +13 %; profiles/r05_wide_cost_tri.txt)
     float presplit = 4.0f;    // > 0: a triangle whose box is longer than presplit x the mean triangle extent enters the build as several references (k_split_emit); 0 = off
     int refit = 1;            // a commit after mrt_scene_update_mesh alone (same topology, new vertex positions / normals) REFITS the 8-wide tree of a flattened scene — packets rewritten, boxes recomputed bottom-up, the tree's shape kept — instead of building it again; 0: always build
+    float refit_max_cost_ratio = 0.0f;      // > 0: a commit whose refit leaves MRTSceneStats.wide_cost above this factor of wide_cost_built builds the tree again instead (0 = the caller decides, from those two numbers)
     int refit_fenced = 0;     // 1: the bottom-up pass of the build with __threadfence() hand-offs instead of write-through stores (the slow reference form; same tree bit for bit)
     int validate = 1;         // check every index of the committed layout on the host (validate_layout), once per commit
     int instancing = 0;       // 0: flatten every instance into one world-space BVH (default; the reference never shares a primitive AS);
                               // 1: two-level — a BLAS per distinct mesh shared by its instances + a TLAS; transform changes rebuild only the TLAS
+};
+
+// One BLAS of a two-level scene inside the scene's shared arrays: what a refit of that BLAS (mrt_scene_update_mesh on its mesh + commit) needs to find it again
+struct BlasRange {
+    uint32_t src_mesh = 0;                                   // the mesh it was built from (index into the scene's mesh list)
+    uint32_t wnode_base = 0, wnodes = 0;                     // its 8-wide nodes in `wnodes` (absolute child / packet indices inside)
+    uint32_t packet_base = 0, ntri = 0;                      // its packets in `wpackets` and in `bpackets` (one per triangle: BLASes are built without pre-splitting)
+    uint32_t node_base = 0, rope_nodes = 0;                  // its rope nodes in `bnodes`
+    uint32_t ts_base = 0, vbase = 0;
+    std::vector<uint32_t> wide_levels;                       // nodes per level of its 8-wide tree (BFS numbering)
+    float wide_cost_built = 0.0f, sah_cost_built = 0.0f;     // as its build left them (MRTSceneStats)
+    float wide_cost = 0.0f;
 };
 
 struct DeviceScene {
@@ -208,6 +221,7 @@ struct DeviceScene {
     uint32_t num_wnodes = 0; int wide_depth = 0;
     std::vector<uint32_t> wide_levels;           // flattened scenes: nodes per level of the 8-wide tree (BFS numbering) — what a refit walks bottom-up (build_flat, refit)
     uint32_t refits = 0;                         // commits served by a refit since the last build
+    float sah_cost_built = 0.0f;                 // stats.sah_cost as the last build left it (a refit scales it by the 8-wide tree's cost ratio)
     uint64_t refit_triangles = 0;                // triangles of the build that made the 8-wide layout (a refit needs the same count)
     uint32_t num_packets = 0;        // triangle packets per layout = build references (stats.triangles, or more when long triangles were pre-split)
     uint32_t rope_nodes = 0;         // surviving rope nodes (stats.bvh_nodes reports the 8-wide node count when that layout is built)
@@ -223,6 +237,8 @@ struct DeviceScene {
     uint32_t tlas_wcap = 0; int blas_wdepth = 0;               // 8-wide layout: node slots reserved for the TLAS in front of the BLASes, deepest BLAS (0: rope only)
     size_t bpackets_offset = 0; uint32_t num_inst = 0;
     std::vector<InstanceDev> h_inst;                           // host copy: transform updates rewrite the rows and rebuild the TLAS only
+    std::vector<BlasRange> blas_ranges;                        // per BLAS: where it lies in the shared arrays (refit_two_level)
+    bool blas_all_wide = false;                                // every BLAS has the 8-wide layout (the shared wnodes / wpackets exist)
     std::vector<float> blas_lo, blas_hi;                       // per BLAS root box (object space), 3 floats each
     float tlas_ms = 0;                                         // host + upload time of the last TLAS build
     bool validate = true, validated_blas = false;              // commit-time index validation (two_level.hip validate_layout); BLAS part already checked
@@ -235,6 +251,7 @@ struct DeviceScene {
 // bvh_build.hip
 void pack_material(const MRTMaterial &m, float4 *out3);
 int wide_histogram(const DeviceScene &sc, hipStream_t stream, uint32_t out12[12]);      // diagnostics: children per 8-wide node
+int wide_tree_cost(const float4 *wnodes, uint32_t first, uint32_t count, uint32_t root, float c_node, float c_tri, hipStream_t stream, float *out);      // SAH cost of the 8-wide subtree [first, first + count) rooted at `root`, as it lies in memory, per unit of root area
 int layout_limits(uint64_t triangles, uint64_t nodes);    // MRT_OK, or MRT_ERR_UNSUPPORTED when the traversal layouts cannot address such a scene
 int build_scene(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, bool only_transforms_changed = false, bool only_vertices_changed = false);      // only_transforms_changed: same meshes, submeshes and options as the commit before (flattened scenes keep their geometry on the device)
 // bvh_host_sah.cpp (builder = 2): binned-SAH topology over n reference boxes, built on the host
@@ -243,6 +260,8 @@ struct MeshRef { const HostMesh *g; const float *xf; };         // geometry + ob
 int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage = nullptr, bool geometry_unchanged = false, bool refit = false);      // stage: the upload staging to use instead of out.stage (the BLAS builds of a two-level scene share their scene's)
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
+int refit_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);      // after mrt_scene_update_mesh alone: the BLASes of the updated meshes refitted in place (both layouts) + the TLAS; MRT_ERR_UNSUPPORTED (no message): the scene cannot be refitted, build it
+int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out);      // bvh_build.hip
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched
 int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only, const float4 *wnodes_override = nullptr);      // wnodes_override: a device copy of the 8-wide nodes to check in place of the scene's (mrt_debug_validate_patched)
          // every index of the 8-wide layout / instance rows inside its array; MRT_ERR_STATE + message otherwise

@@ -458,8 +458,9 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     size_t nodes_total = 0, packets_total = 0, ts_total = 0;
     const size_t tlas_wcap = std::max<size_t>(I, 1);                      // an 8-wide TLAS over I single-instance leaves has at most max(1, I - 1) nodes
     size_t wnodes_total = tlas_wcap; bool all_wide = B > 0; int blas_wdepth = 0;
-    float build_ms = 0; double sah = 0; uint64_t leaves = 0;
+    float build_ms = 0; double sah = 0, wcost = 0; uint64_t leaves = 0;
     out.blas_lo.assign(3 * B, 0.0f); out.blas_hi.assign(3 * B, 0.0f);
+    out.blas_ranges.assign(B, BlasRange{});
     for (size_t b = 0; b < B; b++) {
         const HostMesh &g = meshes[blas_src[b]];
         std::vector<MeshRef> one{MeshRef{&g, identity}};
@@ -469,7 +470,12 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
         wnode_base[b] = (uint32_t)wnodes_total; wnodes_total += blas[b].num_wnodes;
         if (blas[b].stats.triangles > 0) { all_wide = all_wide && blas[b].num_wnodes > 0; blas_wdepth = std::max(blas_wdepth, blas[b].wide_depth); }
         nodes_total += blas[b].rope_nodes; packets_total += blas[b].stats.triangles; ts_total += blas[b].stats.triangles; V_total += g.positions.size() / 3;
-        build_ms += blas[b].stats.build_ms; sah += blas[b].stats.sah_cost; leaves += blas[b].stats.bvh_leaves;
+        build_ms += blas[b].stats.build_ms; sah += blas[b].stats.sah_cost; wcost += blas[b].stats.wide_cost; leaves += blas[b].stats.bvh_leaves;
+        {   // where this BLAS will lie in the shared arrays: what a refit of it needs (refit_two_level)
+            BlasRange &r = out.blas_ranges[b];
+            r.src_mesh = (uint32_t)blas_src[b]; r.wnode_base = wnode_base[b]; r.wnodes = blas[b].num_wnodes; r.packet_base = packet_base[b]; r.ntri = ntri[b]; r.node_base = node_base[b]; r.rope_nodes = blas[b].rope_nodes;
+            r.ts_base = ts_base[b]; r.vbase = vbase[b]; r.wide_levels = blas[b].wide_levels; r.wide_cost_built = r.wide_cost = blas[b].stats.wide_cost; r.sah_cost_built = blas[b].stats.sah_cost;
+        }
         for (int k = 0; k < 3; k++) { out.blas_lo[3 * b + k] = blas[b].root_lo[k]; out.blas_hi[3 * b + k] = blas[b].root_hi[k]; }
     }
     if (int rc = layout_limits(packets_total, nodes_total)) return rc;      // the shared arrays obey the same 24-bit / 32-bit addressing as one flat tree
@@ -539,9 +545,38 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
+    out.stats.wide_cost = out.stats.wide_cost_built = (B && all_wide) ? (float)(wcost / (double)B) : 0.0f; out.sah_cost_built = out.stats.sah_cost; out.refits = 0; out.blas_all_wide = all_wide;
     out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
     out.validated_blas = false;            // the BLAS part of wnodes is new: update_tlas checks all of it this time
     return update_tlas(meshes, stream, out);
+}
+
+// mrt_scene_update_mesh + commit on a two-level scene (Renderer.swift:193-213 is the instance-based API this stands for; Metal would refit the primitive acceleration structures of
+// the changed meshes and rebuild the instance structure): every BLAS whose mesh changed is refitted IN PLACE in the shared arrays — both layouts: the 8-wide one the render kernels
+// walk, the rope one the query API and the in-place fallbacks walk (bvh_build.hip refit_blas) — its instances share the result; then the TLAS is rebuilt from the new BLAS boxes
+// (update_tlas).  MRT_ERR_UNSUPPORTED without a message: this scene cannot be refitted (no 8-wide layout, another mesh list) — the caller builds it.
+int refit_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
+    if (!out.blas_all_wide || out.num_inst != meshes.size() || out.blas_ranges.empty() || out.h_inst.size() != meshes.size()) return MRT_ERR_UNSUPPORTED;
+    for (const BlasRange &r : out.blas_ranges) if (r.src_mesh >= meshes.size() || (meshes[r.src_mesh].dirty && (r.wnodes == 0 || r.wide_levels.empty() || meshes[r.src_mesh].positions.size() / 3 == 0))) return MRT_ERR_UNSUPPORTED;
+    float ms_total = 0; double sah = 0, wcost = 0;
+    for (size_t b = 0; b < out.blas_ranges.size(); b++) {
+        BlasRange &r = out.blas_ranges[b];
+        if (meshes[r.src_mesh].dirty && r.ntri != 0) {
+            float ms = 0;
+            if (int rc = refit_blas(meshes[r.src_mesh], r, stream, out, &out.blas_lo[3 * b], &out.blas_hi[3 * b], &ms)) return rc;
+            if (int rc = wide_tree_cost(out.wnodes.p, r.wnode_base, r.wnodes, r.wnode_base, opt.wide_cost_node, opt.wide_cost_tri, stream, &r.wide_cost)) return rc;
+            ms_total += ms;
+        }
+        wcost += r.wide_cost; sah += r.wide_cost_built > 0.0f ? r.sah_cost_built * (r.wide_cost / r.wide_cost_built) : r.sah_cost_built;
+    }
+    const MRTSceneStats before = out.stats;
+    // scene option refit_max_cost_ratio: the refits have loosened the BLASes beyond that factor of their build-time cost — the caller builds the scene again
+    if (opt.refit_max_cost_ratio > 0.0f && before.wide_cost_built > 0.0f && (float)(wcost / (double)out.blas_ranges.size()) > opt.refit_max_cost_ratio * before.wide_cost_built) return MRT_ERR_UNSUPPORTED;
+    if (int rc = update_tlas(meshes, stream, out)) return rc;          // the instances' world boxes follow their BLAS's new root box
+    const size_t B = out.blas_ranges.size();
+    out.stats.build_ms = ms_total; out.stats.wide_cost = (float)(wcost / (double)B); out.stats.wide_cost_built = before.wide_cost_built; out.stats.sah_cost = (float)(sah / (double)B);
+    out.refits++; out.stats.refits = out.refits;
+    return MRT_OK;
 }
 
 }  // namespace mrt

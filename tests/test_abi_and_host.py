@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(mrt):
     from metal_raytracing_amd import _ffi
     assert declared == set(_ffi.SIGNATURES), "ctypes table and headers disagree"
     assert not hasattr(raw, "mrt_debug_poke_wnode"), "the release library must not export the node-poking aid (MRT_DIAGNOSTICS builds only)"
-    assert mrt.lib.mrt_abi_version() == 2
+    assert mrt.lib.mrt_abi_version() == 3
 
 
 def test_struct_layout_matches_shader_types(mrt):

@@ -67,16 +67,91 @@ def test_refit_gives_the_image_of_a_fresh_build_and_of_the_oracle(mrt, orc, gpu_
     ref.close(); r.close()
 
 
+def _deformed_instanced(mrt, size, amp, phase):
+    """Dragon x 4 as ONE mesh + four instances (the shared-BLAS scene), the mesh's vertices pushed along their normals by a wave."""
+    sc = mrt.InstancedDragonScene(size)
+    meshes = mrt.flatten_scene(sc, share=True)
+    out = []
+    for (pos, nrm, xf, subs, source) in meshes:
+        pos = np.asarray(pos, np.float32).copy(); nrm = np.asarray(nrm, np.float32).copy()
+        if len(pos) > 100000:        # the dragon mesh and its instances (the same arrays: the oracle takes each entry's own)
+            wv = (amp * np.sin(9.0 * pos[:, 1] + phase) * np.cos(7.0 * pos[:, 0] - phase)).astype(np.float32)
+            pos = (pos + nrm * wv[:, None]).astype(np.float32)
+            t = (nrm + np.float32(0.3) * wv[:, None] * np.array([1, 0, 0], np.float32)).astype(np.float32)
+            nrm = (t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+        out.append((pos, nrm, xf, subs, source))
+    return sc, out
+
+
+def test_two_level_refit_gives_the_image_of_a_fresh_build_and_of_the_oracle(mrt, orc, gpu_ctx):
+    """mrt_scene_update_mesh + commit on a TWO-LEVEL scene (Renderer.swift:193-213 is the instance-based API): the changed mesh's BLAS is refitted in place — the 8-wide layout the
+    render kernels walk AND the rope copy the query API walks — its four instances share the result, the TLAS follows the new BLAS box.  Same image as a fresh two-level build of
+    the deformed scene and as the two-level oracle, bit for bit; both intersectors answer like the oracle's brute force; MRTSceneStats shows what the refit did to the tree."""
+    w, h = 192, 108
+    sc0, base = _deformed_instanced(mrt, (w, h), 0.0, 0.0)
+    big = [k for k, m in enumerate(base) if len(m[0]) > 100000 and m[4] < 0]          # the mesh itself; its instances (source >= 0) carry the same arrays
+    assert len(big) == 1 and sum(1 for m in base if m[4] == big[0]) >= 3
+    r = mrt.Renderer((w, h), sc0, ctx=gpu_ctx, scene_options={"instancing": 1})
+    ds = r.device_scene
+    r.draw(3, wait=True)
+    st0 = ds.stats
+    assert ds.refits == 0 and st0.refits == 0 and st0.wide_cost > 0 and st0.wide_cost == st0.wide_cost_built
+    costs = []
+    for step, (amp, phase) in enumerate([(0.02, 0.3), (0.05, 1.1)]):
+        _, meshes = _deformed_instanced(mrt, (w, h), amp, phase)
+        ds.update_mesh(big[0], meshes[big[0]][0], meshes[big[0]][1]); ds.commit()
+        st = ds.stats
+        assert ds.refits == step + 1 and st.refits == step + 1, "the commit after update_mesh alone must refit the BLAS, not build"
+        assert st.build_ms < st0.build_ms, (st.build_ms, st0.build_ms)
+        assert st.wide_cost_built == st0.wide_cost_built and st.wide_cost > st.wide_cost_built, "a deformed mesh on the build's tree: the boxes loosen, and the statistics say so"
+        assert st.sah_cost > st0.sah_cost          # the build's figure scaled by each BLAS's own cost ratio (mean over the BLASes)
+        costs.append(st.wide_cost)
+        r.frameIndex = 0; r.reset_stats(); r.draw(4, wait=True)
+        img = r.accumulation().copy(); cnt = (r.stats.closest_rays, r.stats.shadow_rays)
+        r2 = mrt.Renderer((w, h), sc0, ctx=gpu_ctx, scene_options={"instancing": 1, "refit": 0})          # the same calls build
+        r2.device_scene.update_mesh(big[0], meshes[big[0]][0], meshes[big[0]][1]); r2.device_scene.commit()
+        assert r2.device_scene.refits == 0
+        r2.draw(4, wait=True)
+        assert np.array_equal(img.view(np.uint32), r2.accumulation().view(np.uint32)), "refit and fresh build must render the same image"
+        assert cnt == (r2.stats.closest_rays, r2.stats.shadow_rays)
+        osc = orc.OracleScene(meshes, sc0.lights, instancing=True)
+        o = orc.OracleRenderer(osc, w, h, seed=1, max_bounces=3, camera=sc0.camera); o.render(4)
+        assert np.array_equal(img.view(np.uint32), o.accumulation().view(np.uint32)), "and the two-level oracle's"
+        assert cnt == o.counters()
+        rng = np.random.default_rng(11 + step)
+        rays = np.zeros((3000, 8), np.float32); rays[:, 0:3] = rng.uniform([-1.5, 0.1, 0.5], [1.5, 1.5, 4.0], (3000, 3)); d = rng.normal(size=(3000, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = np.inf
+        b = osc.intersect_closest(rays)
+        for g in (ds.intersect_closest(rays), ds.intersect_stream(rays)):          # the rope copy (query API) and the 8-wide layout (the render kernels' walk)
+            for f in ("type", "primitive_id", "geometry_id", "instance_id"): assert np.array_equal(g[f], b[f]), f
+            assert np.array_equal(g["distance"].view(np.uint32), b["distance"].view(np.uint32))
+        rays[:, 7] = 2.0
+        assert np.array_equal(ds.intersect_any(rays), osc.intersect_any(rays))
+        r2.close()
+    assert costs[1] > costs[0]
+    # a transform changing with the vertices: a build; and scene option refit_max_cost_ratio builds by itself once the refits have loosened the tree that far
+    ds.update_mesh(big[0], base[big[0]][0], base[big[0]][1]); ds.set_instance_transform(big[0], np.asarray(base[big[0]][2], np.float32)); ds.commit()
+    assert ds.refits == 0 and ds.stats.wide_cost == ds.stats.wide_cost_built
+    r.close()
+    for inst in (0, 1):
+        ds2 = mrt.DeviceScene(gpu_ctx, sc0, {"instancing": inst, "refit_max_cost_ratio": 1.02})
+        _, m1 = _deformed_instanced(mrt, (w, h), 0.002, 0.3); _, m2 = _deformed_instanced(mrt, (w, h), 0.05, 1.1)
+        ds2.update_mesh(big[0], m1[big[0]][0], m1[big[0]][1]); ds2.commit()
+        assert ds2.refits == 1 and ds2.stats.wide_cost <= 1.02 * ds2.stats.wide_cost_built, (inst, ds2.stats.wide_cost, ds2.stats.wide_cost_built)
+        ds2.update_mesh(big[0], m2[big[0]][0], m2[big[0]][1]); ds2.commit()
+        assert ds2.refits == 0 and ds2.stats.wide_cost == ds2.stats.wide_cost_built, "beyond the ratio: built again"
+        ds2.close()
+
+
 def test_refit_argument_checks_and_fallbacks(mrt, gpu_ctx):
     w, h = 64, 64
     sc = mrt.CornellScene((w, h))
     meshes = mrt.flatten_scene(sc, share=True)
-    # a two-level scene builds again (the BLAS refit is not implemented): the image still follows the vertices
+    # a two-level scene refits the changed mesh's BLAS in place (round 6)
     ds = mrt.DeviceScene(gpu_ctx, sc, {"instancing": 1})
     k = max(range(len(meshes)), key=lambda i: len(meshes[i][0]) if meshes[i][4] < 0 else -1)
     pos, nrm = np.asarray(meshes[k][0], np.float32), np.asarray(meshes[k][1], np.float32)
     ds.update_mesh(k, pos * np.float32(1.01), nrm); ds.commit()
-    assert ds.refits == 0
+    assert ds.refits == 1
     with pytest.raises(mrt.MRTError): ds.update_mesh(k, pos[:-1], nrm[:-1])          # the vertex count must stay
     with pytest.raises(mrt.MRTError): ds.update_mesh(len(meshes) + 3, pos, nrm)
     with pytest.raises(mrt.MRTError): ds.update_mesh(k, pos, nrm[:-1])              # fewer normals than positions: refused by the wrapper before the C side reads past the array (ADVICE r5)
