@@ -207,10 +207,13 @@ int mrt_scene_set_option(MRTScene scene, const char *key, double value);
  * world-space BVH on the device (the reference would refit/rebuild its instance AS, Renderer.swift:205-213).   */
 int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const float *transform_colmajor_4x4);
 /* Deforming geometry: new object-space positions and normals for the vertices of one mesh (same count, same submesh indices: the topology is kept).  The library copies
- * the arrays.  Takes effect at the next mrt_scene_commit.  When nothing else changed since the last commit, a flattened scene with the 8-wide layout REFITS its tree — every
- * triangle packet rewritten, the boxes recomputed bottom-up, the tree's shape (and MRTSceneStats.sah_cost) as built — in a fraction of a build's time; the image is the one a
- * fresh build of the deformed scene gives (the closest hit does not depend on the tree).  Two-level scenes, scenes on the rope layout and scene option refit = 0 build again.
- * The reference builds its acceleration structures once (Renderer.swift:184-214) and never deforms a mesh; this is the counterpart of Metal's refit of a primitive AS.   */
+ * the arrays.  Takes effect at the next mrt_scene_commit.  When nothing else changed since the last commit, a scene with the 8-wide layout REFITS — a flattened scene its tree,
+ * a two-level scene (instancing = 1) the BLAS of every changed mesh in place, in both layouts, and then its TLAS: every triangle packet rewritten, the boxes recomputed
+ * bottom-up, the tree's shape as built — in a fraction of a build's time; the image is the one a fresh build of the deformed scene gives (the closest hit does not depend on
+ * the tree).  The boxes of a tree that keeps its shape loosen with the deformation: MRTSceneStats.wide_cost against wide_cost_built says by how much (sah_cost follows), and
+ * scene option "refit_max_cost_ratio" = r makes a commit build again by itself once wide_cost > r x wide_cost_built.  Flattened scenes on the rope layout and scene option
+ * refit = 0 build again.  The reference builds its acceleration structures once (Renderer.swift:184-214) and never deforms a mesh; this is the counterpart of Metal's refit
+ * of a primitive acceleration structure.                                                                                                                              */
 int mrt_scene_update_mesh(MRTScene scene, int32_t mesh_id, const float *positions, size_t pos_stride_bytes,
                           const float *normals, size_t nrm_stride_bytes, size_t vertex_count);
 int mrt_scene_stats(MRTScene scene, MRTSceneStats *out);
