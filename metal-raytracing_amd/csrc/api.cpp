@@ -317,7 +317,8 @@ int mrt_debug_intersect_stream(MRTScene scene, const MRTRay *rays, size_t n, int
 }
 
 #ifdef MRT_WAVE_TIMES
-extern "C++" { namespace mrt { int read_wave_times(unsigned long long *out); int read_wave_iters(uint32_t *out); } }
+extern "C++" { namespace mrt { int read_wave_times(unsigned long long *out); int read_wave_iters(uint32_t *out); int read_drain_probe(unsigned long long *out18, int reset); } }
+extern "C" int mrt_debug_drain_probe(unsigned long long *out18, int reset) { return mrt::read_drain_probe(out18, reset); }
 extern "C" int mrt_debug_wave_times(unsigned long long *out16384) { return mrt::read_wave_times(out16384); }
 extern "C" int mrt_debug_wave_iters(uint32_t *out32768) { return mrt::read_wave_iters(out32768); }
 #endif

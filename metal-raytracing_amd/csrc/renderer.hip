@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(64, TWO_LEVEL ? MRT_TWO_LEVEL_WAVES : MRT_WIDE
 #ifdef MRT_WAVE_TIMES      // diagnostics build (tools/archive/wave_times.py): when does every wave of the first traversal launch of a pass start and end?
 __device__ unsigned long long g_wave_times[2 * 8192];
 __device__ uint32_t g_wave_iters[4 * 8192];      // per wave of that launch: iterations | drain iterations + longest iteration << 12 | live lanes summed over the drain iterations | drain start tick
+__device__ unsigned long long g_drain_probe[2][9];      // StreamStats::dr_*, summed over the waves of that launch: [at most 16 | at most 4 live lanes][6 stack-depth bins, hit children pending, triangles pending, samples]
 #endif
 // Persistent variant: the grid is the number of wave slots of the chip (or fewer for a small queue) and every wave pulls
 // `chunk` consecutive rays of the combined queue at a time from `work` (zeroed by k_accumulate at the end of the previous pass).
@@ -272,7 +273,9 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_trace_mixed_wide_
     StreamStats wst{0, 0, 0, 0, 0, 0};
     struct WT { unsigned long long t0; uint32_t tag; StreamStats &st; __device__ ~WT() { if ((threadIdx.x & 63) == 0 && tag == 0 && blockIdx.x < 8192) {
         g_wave_times[2 * blockIdx.x] = t0; g_wave_times[2 * blockIdx.x + 1] = wall_clock64();
-        g_wave_iters[4 * blockIdx.x] = st.iters | (st.drain_le8 << 16); g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; } } } wt{(unsigned long long)wall_clock64(), wt_tag, wst};
+        g_wave_iters[4 * blockIdx.x] = st.iters | (st.drain_le8 << 16); g_wave_iters[4 * blockIdx.x + 1] = st.drain_iters | (st.maxdt << 12); g_wave_iters[4 * blockIdx.x + 2] = st.drain_live; g_wave_iters[4 * blockIdx.x + 3] = (uint32_t)st.drain_t0; }
+        if ((threadIdx.x & 63) == 0 && tag == 0) for (int c_ = 0; c_ < 2; c_++) { for (int d_ = 0; d_ < 6; d_++) atomicAdd(&g_drain_probe[c_][d_], (unsigned long long)st.dr_hist[c_][d_]);
+            atomicAdd(&g_drain_probe[c_][6], (unsigned long long)st.dr_kids[c_]); atomicAdd(&g_drain_probe[c_][7], (unsigned long long)st.dr_tris[c_]); atomicAdd(&g_drain_probe[c_][8], (unsigned long long)st.dr_n[c_]); } } } wt{(unsigned long long)wall_clock64(), wt_tag, wst};
     StreamStats *const wss = wt_tag == 0 ? &wst : nullptr;
 #else
     StreamStats *const wss = nullptr;
@@ -635,6 +638,11 @@ static inline void launch_timed(EvPair *ev, void (*kernel)(KArgs...), dim3 grid,
 #ifdef MRT_WAVE_TIMES
 int read_wave_times(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(g_wave_times)) == hipSuccess ? MRT_OK : MRT_ERR_HIP; }
 int read_wave_iters(uint32_t *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_iters), sizeof(g_wave_iters)) == hipSuccess ? MRT_OK : MRT_ERR_HIP; }
+int read_drain_probe(unsigned long long *out18, int reset) {
+    if (hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_drain_probe), sizeof(g_drain_probe)) != hipSuccess) return MRT_ERR_HIP;
+    if (reset) { static const unsigned long long z[18] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_drain_probe), z, sizeof z) != hipSuccess) return MRT_ERR_HIP; }
+    return MRT_OK;
+}
 #endif
 
 // ====================================================================== Renderer (host)

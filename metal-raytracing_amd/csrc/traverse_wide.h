@@ -415,6 +415,9 @@ struct StreamStats {
 #endif
 #ifdef MRT_WAVE_TIMES
     uint32_t drain_iters = 0, drain_live = 0, maxdt = 0, drain_le8 = 0; unsigned long long prev = 0ull, drain_t0 = 0ull;
+    // what the last live lanes of a draining wave still hold (could an idle lane take a subtree off them? round 6): over the drain iterations with at most 16 ([0]) / at most 4 ([1])
+    // live lanes, per live lane: histogram of its stack depth (0, 1, 2, 3, 4, >= 5 parked sibling groups), the hit children still to visit in those groups and in its current one, samples
+    uint32_t dr_hist[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}, dr_kids[2] = {0, 0}, dr_n[2] = {0, 0}, dr_tris[2] = {0, 0};
 #endif
 };
 
@@ -674,7 +677,20 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
         }
 #ifdef MRT_WAVE_TIMES
         if (ss) {
-            if (draining) { const uint32_t nl_ = (uint32_t)__popcll(__ballot(live)); ss->drain_iters++; ss->drain_live += nl_; if (nl_ <= 8u) ss->drain_le8++; }
+            if (draining) {
+                const uint32_t nl_ = (uint32_t)__popcll(__ballot(live)); ss->drain_iters++; ss->drain_live += nl_; if (nl_ <= 8u) ss->drain_le8++;
+                if (!TWO_LEVEL && nl_ <= 16u) {          // (flattened scenes) every live lane's pending work, summed over the wave by ballots / shuffles; lane 0's copy of `ss` is the one reported
+                    const uint32_t sp_ = live ? g_mask >> 16 : 0u;
+                    uint32_t kids_ = live ? (uint32_t)__popc((g_mask >> 8) & 0xFFu) : 0u;
+                    for (uint32_t l_ = 0; l_ < sp_; l_++) kids_ += (uint32_t)__popc(stack[l_ * (WIDE_STACK_LEVEL_BYTES / 4u) + lane] & 0xFFu);
+                    uint32_t tris_ = live ? (uint32_t)__popc(t_mask) + (uint32_t)__popc(u_mask) : 0u;
+                    for (int o_ = 32; o_ > 0; o_ >>= 1) { kids_ += (uint32_t)__shfl_xor((int)kids_, o_); tris_ += (uint32_t)__shfl_xor((int)tris_, o_); }
+                    for (int c_ = 0; c_ < 2; c_++) if (c_ == 0 || nl_ <= 4u) {
+                        for (uint32_t d_ = 0; d_ < 6u; d_++) ss->dr_hist[c_][d_] += (uint32_t)__popcll(__ballot(live && (d_ < 5u ? sp_ == d_ : sp_ >= 5u)));
+                        ss->dr_kids[c_] += kids_; ss->dr_tris[c_] += tris_; ss->dr_n[c_] += nl_;
+                    }
+                }
+            }
             const unsigned long long now_ = wall_clock64(); const uint32_t dt_ = (uint32_t)(now_ - ss->prev);
             if (ss->prev != 0ull && dt_ > ss->maxdt) ss->maxdt = dt_;
             ss->prev = now_; if (draining && ss->drain_t0 == 0ull) ss->drain_t0 = now_;
