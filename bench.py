@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on one GPU box (ranks share GPUs, reduce on host)")
     ap.add_argument("--group-devices", default=None, help="--gpus N without torch.distributed.run: device ids of the C-ABI device group (default 0..N-1; '0,0' rehearses N = 2 on a one-GPU box)")
+    ap.add_argument("--assemble", default="reduce", choices=["reduce", "compact"], help="N > 1, tile sharding: how the image is assembled on rank 0 — the ONE reduce(sum) of the whole RGBA32F buffers (north_star, default) or the compact form: every rank ships only the tiles it owns")
+    ap.add_argument("--steady-steps", type=int, default=240, help="N > 1: after the timed region, one more leg of this many steps (not part of value / ms_per_step) reported as \"steady\": the regime a long run reaches, beside the launch-bound figure of a short --steps (0 = skip)")
     ap.add_argument("--png", default=None, help="write the tonemapped image here (rank 0)")
     ap.add_argument("--dump-accum", default=None, help="write the assembled RGBA32F accumulation buffer (warm-up + timed frames) here as .npy (rank 0)")
     return ap.parse_args()
@@ -228,6 +230,8 @@ def main_group(a):
         k, v = kv.split("="); g.set_option(k, float(v))
     if a.frames_in_flight is not None:
         g.set_option("frames_in_flight", a.frames_in_flight)
+    if a.assemble == "compact":
+        g.set_reduce_mode(2)
     g.draw(a.warmup); g.gather(to_host=False)              # warm-up: W untimed steps and one reduce (communicator set-up is not timed)
     first = g.stats
     torch.cuda.synchronize()
@@ -254,6 +258,15 @@ def main_group(a):
            "roofline": None, "cpu_baseline": None}
     if a.dump_accum:
         np.save(a.dump_accum, g.gather())
+    if a.steady_steps > 0 and a.gpus > 1:          # one more leg, not part of value: the regime a long run reaches
+        before = g.stats
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        g.draw(a.steady_steps); g.wait(); t_r = time.perf_counter() - t1
+        g.gather(to_host=False); dts = time.perf_counter() - t1
+        s2 = g.stats
+        out["steady"] = {"steps": a.steady_steps, "value": round((s2.closest_rays - before.closest_rays + s2.shadow_rays - before.shadow_rays) / dts / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dts * 1e3 / a.steady_steps, 4),
+                         "per_rank": {"ms_gpu_timed_draw": [round(g.rank_stats(k).ms_gpu_last, 4) for k in range(a.gpus)], "render_wall_ms": round(t_r * 1e3, 4), "gather_wall_ms": round((dts - t_r) * 1e3, 4)},
+                         "note": "a second leg after the timed region, same group, its own assemble: not part of value"}
     print(json.dumps(out), flush=True)
     g.close()
 
@@ -324,36 +337,57 @@ def main():
         sr.gather()
     r.reset_stats()
     sync()
-    # ---- timed region: exactly K steps (+ the one reduce of the output image for N > 1)
-    t0 = time.perf_counter()
-    sr.draw(a.steps)                 # all K steps are enqueued at once; the first 512 launches carry their own start/stop events
-    r.wait()
-    t_render = time.perf_counter() - t0
-    if world > 1:
-        sr.gather()
-    t_gather = time.perf_counter() - t0 - t_render
-    sync()
-    dt = time.perf_counter() - t0
-    st = r.stats
-    kt = r.kernel_times
-    per_rank = None
-    if world > 1:                    # (outside the timed region) every rank's own device time, wall time to its last frame and time inside the reduce: what a SCALE record is diagnosed with
-        mine = torch.tensor([st.ms_gpu_last, t_render * 1e3, t_gather * 1e3], dtype=torch.float64)
-        if a.dist_backend == "nccl":
-            mine = mine.cuda()
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = {"ms_gpu_timed_draw": [round(float(x[0]), 4) for x in allr], "render_wall_ms": [round(float(x[1]), 4) for x in allr], "gather_wall_ms": [round(float(x[2]), 4) for x in allr],
-                    "note": "per rank: device time of the timed draw (its own events), wall time until its last frame was done, wall time inside the one reduce of the image (a rank that arrives early waits there for the slowest)"}
-    rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    if world > 1:
-        if a.dist_backend == "nccl":
-            rays = rays.cuda(); tmax = tmax.cuda()
-        dist.all_reduce(rays); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rays = rays.cpu(); tmax = tmax.cpu()
-    dt = float(tmax[0])
+    compact = a.assemble == "compact" and a.shard == "tile"
+
+    def timed_leg(steps):
+        """`steps` steps bracketed by barrier + synchronize on both sides (+ the one assemble of the output image for N > 1); the MAX over ranks is the leg's time."""
+        t0 = time.perf_counter()
+        sr.draw(steps)                   # all steps are enqueued at once; the first 512 launches carry their own start/stop events
+        r.wait()
+        t_render = time.perf_counter() - t0
+        if world > 1:
+            sr.gather(compact=compact)
+        t_gather = time.perf_counter() - t0 - t_render
+        sync()
+        dt = time.perf_counter() - t0
+        st = r.stats
+        kt = r.kernel_times
+        per_rank = None
+        if world > 1:                    # (outside the timed region) every rank's own device time, wall time to its last frame and time inside the assemble: what a SCALE record is diagnosed with
+            mine = torch.tensor([st.ms_gpu_last, t_render * 1e3, t_gather * 1e3], dtype=torch.float64)
+            if a.dist_backend == "nccl":
+                mine = mine.cuda()
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = {"ms_gpu_timed_draw": [round(float(x[0]), 4) for x in allr], "render_wall_ms": [round(float(x[1]), 4) for x in allr], "gather_wall_ms": [round(float(x[2]), 4) for x in allr],
+                        "assemble": "compact (owned tiles only: dist.gather of 1/N of the image per rank)" if compact else "reduce(sum) of the whole RGBA32F buffer",
+                        "note": "per rank: device time of the timed draw (its own events), wall time until its last frame was done, wall time inside the one assemble of the image (a rank that arrives early waits there for the slowest)"}
+        rays = torch.tensor([st.closest_rays, st.shadow_rays, st.primary_rays], dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        if world > 1:
+            if a.dist_backend == "nccl":
+                rays = rays.cuda(); tmax = tmax.cuda()
+            dist.all_reduce(rays); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            rays = rays.cpu(); tmax = tmax.cpu()
+        return float(tmax[0]), st, kt, per_rank, rays
+
+    # ---- timed region: exactly K steps (+ the one assemble of the output image for N > 1)
+    dt, st, kt, per_rank, rays = timed_leg(a.steps)
     closest, shadow, primary = (float(x) for x in rays)
+    # ---- N > 1: one more leg, NOT part of value / ms_per_step — the driver's short --steps is launch-bound on a rank of N (a few ms of work in ~20 dependent launches);
+    # a long draw shows what the partition itself scales to (DESIGN.md §7)
+    steady = None
+    dump_img = sr.buffer.cpu().numpy().copy() if (world > 1 and rank == 0 and a.dump_accum) else None      # the timed region's image: the steady leg goes on accumulating
+    if world > 1 and a.steady_steps > 0:
+        if a.shard == "tile":            # the pass size a run of that length takes (ShardedRenderer sized it for warm-up + timed steps); one untimed pass so that the queues are re-sized outside the leg
+            from metal_raytracing_amd.distributed import shard_frame_batch
+            fbs = shard_frame_batch(world, a.steady_steps)
+            if fbs != int(r.get_option("frame_batch")):
+                r.set_option("frame_batch", fbs); sr.draw(fbs); r.wait()
+        r.reset_stats(); sync()
+        dts, _, _, prs, rs = timed_leg(a.steady_steps)
+        steady = {"steps": a.steady_steps, "frame_batch": int(r.get_option("frame_batch")), "value": round(float(rs[0] + rs[1]) / dts / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dts * 1e3 / a.steady_steps, 4), "per_rank": prs,
+                  "note": "a second leg after the timed region, same renderer, same barriers, its own assemble: not part of value"}
     steps_total = a.steps * (world if a.shard == "sample" and world > 1 else 1)
 
     if rank == 0:
@@ -426,8 +460,10 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if steady is not None:
+            out["steady"] = steady
         if a.dump_accum:
-            np.save(a.dump_accum, sr.buffer.cpu().numpy() if world > 1 else r.accumulation())
+            np.save(a.dump_accum, dump_img if world > 1 else r.accumulation())
         if a.png:
             if world > 1:
                 r.write_accum_from(sr.buffer.data_ptr(), w * h * 16)      # show the assembled image, not this rank's shard

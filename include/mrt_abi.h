@@ -296,6 +296,15 @@ int mrt_renderer_read_accum(MRTRenderer r, float *rgba, size_t nbytes);
 /* Same data copied device→device into caller memory (e.g. a torch tensor for the RCCL reduce). */
 int mrt_renderer_copy_accum_to_device(MRTRenderer r, void *device_ptr, size_t nbytes);
 int mrt_renderer_write_accum_from_device(MRTRenderer r, const void *device_ptr, size_t nbytes);
+/* The compact assemble of a tile-sharded image (beside the reduce(sum) of whole buffers that BASELINE.json's north_star prescribes and mrt_group_gather defaults to): a rank
+ * ships only the pixels it owns — 1 / world of the image — and the root writes them in place.  A compact buffer is tiles x 64 RGBA32F pixels, device memory: tile lt of shard
+ * (rank, world) is tile lt * world + rank of the image (8 x 8 tiles, row-major over the image), its pixels row-major, pixels outside the image 0.
+ *   _shard_tiles   tiles of this renderer's image that shard (rank, world) owns
+ *   _pack_owned    this renderer's accumulation buffer -> the compact buffer of ITS shard (mrt_renderer_set_shard), enqueued on its stream
+ *   _unpack_tiles  the compact buffer of shard (rank, world) -> this renderer's accumulation buffer, at those tiles' pixels                                          */
+int mrt_renderer_shard_tiles(MRTRenderer r, int32_t rank, int32_t world, uint64_t *tiles);
+int mrt_renderer_pack_owned_tiles(MRTRenderer r, void *device_ptr, size_t nbytes);
+int mrt_renderer_unpack_tiles(MRTRenderer r, const void *device_ptr, size_t nbytes, int32_t rank, int32_t world);
 /* fragmentShader (Shaders.metal:39-52): Reinhard c/(1+c), top row first (flipped), RGBA8.      */
 int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbytes);
 int mrt_renderer_stats(MRTRenderer r, MRTRenderStats *out);
@@ -312,7 +321,8 @@ int mrt_group_create(const int *device_ids, int32_t n, MRTGroup *out);
 int mrt_group_destroy(MRTGroup g);
 int mrt_group_size(MRTGroup g, int32_t *n);
 int mrt_group_context(MRTGroup g, int32_t rank, MRTContext *ctx);                  /* borrowed: the group owns its contexts            */
-/* mode: 0 = ncclReduce(sum, float32, root 0), 1 = peer copies into the root device + add; note: why (may be NULL).                  */
+/* mode: 0 = ncclReduce(sum, float32, root 0) of the whole buffers, 1 = peer copies of the whole buffers into the root device + add, 2 = compact: every rank packs the tiles it
+ * owns (1 / n of the image) and the root receives them (ncclSend / ncclRecv, or peer copies) and writes them in place; note: why (may be NULL).  Same image bit for bit.        */
 int mrt_group_reduce_mode(MRTGroup g, int32_t *mode, char *note, size_t note_len);
 int mrt_group_set_reduce_mode(MRTGroup g, int32_t mode);
 /* Renderer.init for the whole group: `scene` (any context; committed or not) is the template — its meshes, lights and build options are

@@ -171,6 +171,9 @@ SIGNATURES = {
     "mrt_renderer_read_accum": (C.c_int, [_P, _P, _SZ]),
     "mrt_renderer_copy_accum_to_device": (C.c_int, [_P, _P, _SZ]),
     "mrt_renderer_write_accum_from_device": (C.c_int, [_P, _P, _SZ]),
+    "mrt_renderer_shard_tiles": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_uint64)]),
+    "mrt_renderer_pack_owned_tiles": (C.c_int, [_P, _P, _SZ]),
+    "mrt_renderer_unpack_tiles": (C.c_int, [_P, _P, _SZ, _I32, _I32]),
     "mrt_renderer_read_tonemapped_rgba8": (C.c_int, [_P, _P, _SZ]),
     "mrt_renderer_stats": (C.c_int, [_P, C.POINTER(RenderStats)]),
     "mrt_renderer_reset_stats": (C.c_int, [_P]),

@@ -617,6 +617,25 @@ int mrt_renderer_write_accum_from_device(MRTRenderer r, const void *dptr, size_t
     return r->r.write_accum_from_device(dptr, nbytes);
     MRT_CATCH
 }
+int mrt_renderer_shard_tiles(MRTRenderer r, int32_t rank, int32_t world, uint64_t *tiles) {
+    REQUIRE(r && tiles && world >= 1 && rank >= 0 && rank < world, "mrt_renderer_shard_tiles: bad argument");
+    *tiles = mrt::shard_tiles(r->r.width, r->r.height, rank, world);
+    return MRT_OK;
+}
+int mrt_renderer_pack_owned_tiles(MRTRenderer r, void *dptr, size_t nbytes) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_pack_owned_tiles")
+    REQUIRE(dptr || nbytes == 0, "mrt_renderer_pack_owned_tiles: NULL pointer");
+    return r->r.pack_owned_tiles(dptr, nbytes);
+    MRT_CATCH
+}
+int mrt_renderer_unpack_tiles(MRTRenderer r, const void *dptr, size_t nbytes, int32_t rank, int32_t world) {
+    MRT_TRY
+    RENDERER_PROLOGUE("mrt_renderer_unpack_tiles")
+    REQUIRE(dptr || nbytes == 0, "mrt_renderer_unpack_tiles: NULL pointer");
+    return r->r.unpack_tiles(dptr, nbytes, rank, world);
+    MRT_CATCH
+}
 int mrt_renderer_read_tonemapped_rgba8(MRTRenderer r, uint8_t *rgba, size_t nbytes) {
     MRT_TRY
     RENDERER_PROLOGUE("mrt_renderer_read_tonemapped_rgba8")

@@ -31,6 +31,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;          // (optional: the compact assemble falls back to peer copies without them)
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
     bool load() {
@@ -46,6 +48,7 @@ struct Rccl {
         GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
         Reduce = (decltype(Reduce))dlsym(handle, "ncclReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        Send = (decltype(Send))dlsym(handle, "ncclSend"); Recv = (decltype(Recv))dlsym(handle, "ncclRecv");
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !GetErrorString) { why = "librccl.so.1 lacks an entry point"; handle = nullptr; return false; }
         return true;
     }
@@ -118,7 +121,7 @@ public:
 
 }  // namespace
 
-enum { MRT_REDUCE_RCCL = 0, MRT_REDUCE_PEER_COPY = 1 };
+enum { MRT_REDUCE_RCCL = 0, MRT_REDUCE_PEER_COPY = 1, MRT_REDUCE_COMPACT = 2 };
 
 struct MRTGroup_ {
     std::vector<int> devices;
@@ -135,6 +138,7 @@ struct MRTGroupRenderer_ {
     std::vector<hipEvent_t> done;         // per rank: recorded on its stream before the gather
     int width = 0, height = 0;
     mrt::DevBuf<float4> gathered, staging;   // on the root device
+    std::vector<std::unique_ptr<mrt::DevBuf<float4>>> packed;      // reduce mode 2: per rank >= 1, on its own device: the compact buffer of its tiles
 };
 
 extern "C" {
@@ -180,7 +184,7 @@ int mrt_group_context(MRTGroup g, int32_t rank, MRTContext *ctx) {
     *ctx = g->ctx[(size_t)rank];
     return MRT_OK;
 }
-// how the group assembles an image: 0 = ncclReduce, 1 = peer copies + add; the text says why
+// how the group assembles an image: 0 = ncclReduce, 1 = peer copies + add, 2 = compact (owned tiles only); the text says why
 int mrt_group_reduce_mode(MRTGroup g, int32_t *mode, char *note, size_t note_len) {
     REQUIRE(g && mode, "mrt_group_reduce_mode: bad argument");
     *mode = g->reduce;
@@ -188,7 +192,12 @@ int mrt_group_reduce_mode(MRTGroup g, int32_t *mode, char *note, size_t note_len
     return MRT_OK;
 }
 int mrt_group_set_reduce_mode(MRTGroup g, int32_t mode) {
-    REQUIRE(g && (mode == MRT_REDUCE_RCCL || mode == MRT_REDUCE_PEER_COPY), "mrt_group_set_reduce_mode: mode must be 0 (RCCL) or 1 (peer copies)");
+    REQUIRE(g && (mode == MRT_REDUCE_RCCL || mode == MRT_REDUCE_PEER_COPY || mode == MRT_REDUCE_COMPACT), "mrt_group_set_reduce_mode: mode must be 0 (RCCL reduce), 1 (peer copies + add) or 2 (compact: owned tiles only)");
+    if (mode == MRT_REDUCE_COMPACT) {          // the transport is what the group has: ncclSend / ncclRecv with communicators, peer copies without
+        g->reduce = mode;
+        g->reduce_note = std::string("compact: every rank ships the tiles it owns (1/n of the image), the root writes them in place; transport: ") + ((!g->comms.empty() && g_rccl.Send && g_rccl.Recv) ? "ncclSend / ncclRecv" : "peer copies");
+        return MRT_OK;
+    }
     if (mode == MRT_REDUCE_RCCL && g->comms.empty()) {
         // a one-device group has no communicator until it is asked for one (ncclReduce over one rank is a copy: it exercises the RCCL path on a one-GPU box)
         const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == g->devices.size();
@@ -297,7 +306,50 @@ int mrt_group_gather(MRTGroupRenderer gr, float *rgba, size_t nbytes) {
     const int n = (int)gr->r.size();
     hipStream_t s0 = g->ctx[0]->stream;
     auto src = [&](int rank) { mrt::Renderer &R = gr->r[(size_t)rank]->r; return R.accum[R.cur].p; };
-    if (g->reduce == MRT_REDUCE_RCCL && !g->comms.empty()) {
+    if (g->reduce == MRT_REDUCE_COMPACT) {
+        // every rank >= 1 packs the tiles it owns on its own device and stream (behind its frames); the root takes its own buffer whole (its other pixels are 0 and are
+        // overwritten), receives the n - 1 compact buffers side by side in its staging area and writes each shard's tiles in place
+        const bool rccl = !g->comms.empty() && g_rccl.Send && g_rccl.Recv;
+        if (gr->packed.size() != (size_t)n) { gr->packed.clear(); for (int k = 0; k < n; k++) gr->packed.emplace_back(new mrt::DevBuf<float4>()); }
+        std::vector<size_t> off((size_t)n + 1, 0);
+        for (int rank = 1; rank < n; rank++) off[(size_t)rank + 1] = off[(size_t)rank] + (size_t)mrt::shard_tiles(gr->width, gr->height, rank, n) * 64;
+        for (int rank = 1; rank < n; rank++) {
+            const size_t cnt = off[(size_t)rank + 1] - off[(size_t)rank];
+            MRT_HIP(hipSetDevice(g->devices[(size_t)rank]));
+            MRT_HIP(gr->packed[(size_t)rank]->alloc(std::max<size_t>(cnt, 1)));
+            int rc = gr->r[(size_t)rank]->r.pack_owned_tiles(gr->packed[(size_t)rank]->p, cnt * sizeof(float4)); if (rc) return rc;
+            MRT_HIP(hipEventRecord(gr->done[(size_t)rank], g->ctx[(size_t)rank]->stream));
+        }
+        MRT_HIP(hipSetDevice(g->devices[0]));
+        MRT_HIP(hipMemcpyAsync(gr->gathered.p, src(0), bytes, hipMemcpyDeviceToDevice, s0));
+        if (n > 1 && gr->staging.n < std::max<size_t>(off[(size_t)n], 1)) MRT_HIP(gr->staging.alloc(std::max<size_t>(off[(size_t)n], 1)));
+        if (rccl && n > 1) {
+            MRT_RCCL(g_rccl.GroupStart());
+            for (int rank = 1; rank < n; rank++) {
+                const size_t cnt = off[(size_t)rank + 1] - off[(size_t)rank];
+                if (!cnt) continue;
+                MRT_HIP(hipSetDevice(g->devices[(size_t)rank]));
+                ncclResult_t e = g_rccl.Send(gr->packed[(size_t)rank]->p, cnt * 4, ncclFloat, 0, g->comms[(size_t)rank], g->ctx[(size_t)rank]->stream);
+                if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(e, "ncclSend"); }
+                MRT_HIP(hipSetDevice(g->devices[0]));
+                e = g_rccl.Recv(gr->staging.p + off[(size_t)rank], cnt * 4, ncclFloat, rank, g->comms[0], s0);
+                if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return rccl_fail(e, "ncclRecv"); }
+            }
+            MRT_RCCL(g_rccl.GroupEnd());
+            for (int rank = 1; rank < n; rank++) { MRT_HIP(hipSetDevice(g->devices[(size_t)rank])); MRT_HIP(hipStreamSynchronize(g->ctx[(size_t)rank]->stream)); }
+            MRT_HIP(hipSetDevice(g->devices[0]));
+        } else {
+            for (int rank = 1; rank < n; rank++) {
+                const size_t cnt = off[(size_t)rank + 1] - off[(size_t)rank];
+                MRT_HIP(hipStreamWaitEvent(s0, gr->done[(size_t)rank], 0));
+                if (cnt) MRT_HIP(hipMemcpyPeerAsync(gr->staging.p + off[(size_t)rank], g->devices[0], gr->packed[(size_t)rank]->p, g->devices[(size_t)rank], cnt * sizeof(float4), s0));
+            }
+        }
+        for (int rank = 1; rank < n; rank++) {
+            const size_t cnt = off[(size_t)rank + 1] - off[(size_t)rank];
+            int rc = mrt::unpack_tiles_into(gr->gathered.p, gr->width, gr->height, gr->staging.p + off[(size_t)rank], cnt * sizeof(float4), rank, n, s0); if (rc) return rc;
+        }
+    } else if (g->reduce == MRT_REDUCE_RCCL && !g->comms.empty()) {
         MRT_RCCL(g_rccl.GroupStart());
         for (int rank = 0; rank < n; rank++) {
             MRT_HIP(hipSetDevice(g->devices[(size_t)rank]));

@@ -133,10 +133,14 @@ struct Renderer {
     int copy_accum_to_device(void *dptr, size_t nbytes);
     int write_accum_from_device(const void *dptr, size_t nbytes);
     int read_tonemapped(uint8_t *rgba, size_t nbytes);
+    int pack_owned_tiles(void *dptr, size_t nbytes);                                   // accum -> compact [tiles_local][64] buffer of this renderer's shard (device pointer; on `stream`)
+    int unpack_tiles(const void *dptr, size_t nbytes, int rank, int world);            // compact buffer of shard (rank, world) -> accum at those tiles' pixels
     int stats(MRTRenderStats *out);
     int reset_stats();
 };
 
+uint32_t shard_tiles(int width, int height, int rank, int world);                     // 8 x 8 tiles of the image that shard (rank, world) owns: tile_id % world == rank
+int unpack_tiles_into(float4 *image, int width, int height, const void *compact, size_t nbytes, int rank, int world, hipStream_t st);
 int query_closest(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, MRTIntersection *out);
 int query_any(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int32_t *out);
 int query_stats(const DeviceScene &sc, hipStream_t stream, const MRTRay *rays, size_t n, int any, uint32_t *out4);

@@ -487,6 +487,20 @@ __global__ void __launch_bounds__(64) k_accumulate_planes_group(FrameParams fp, 
     q2store(&dst[pix], make_float4(c.x, c.y, c.z, 1.0f));
 }
 
+// A shard's own pixels as a compact buffer, and back (the compact assemble of a tile-sharded image: mrt_renderer_pack_owned_tiles / _unpack_tiles, mrt_group reduce mode 2).
+// Layout: tiles_local x 64 RGBA32F — tile lt of shard (rank, world) is tile lt * world + rank of the image, its 8 x 8 pixels row-major; pixels of an edge tile
+// outside the image are 0 in the buffer and skipped on the way back.  1 / world of the image instead of the full frame the reduce(sum) moves per rank.
+template <bool PACK>
+__global__ void k_tiles(float4 *__restrict__ image, int w, int h, int tiles_x, int rank, int world, uint32_t tiles_local, float4 *__restrict__ compact) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lt = slot >> 6, k = slot & 63u;
+    if (lt >= tiles_local) return;
+    const uint32_t tile = lt * (uint32_t)world + (uint32_t)rank, ty = tile / (uint32_t)tiles_x, tx = tile - ty * (uint32_t)tiles_x;
+    const int x = (int)(tx * 8u + (k & 7u)), y = (int)(ty * 8u + (k >> 3));
+    const bool in = x < w && y < h;
+    if (PACK) compact[slot] = in ? image[(size_t)y * w + x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    else if (in) image[(size_t)y * w + x] = compact[slot];
+}
+
 // Shaders.metal:39-52 — Reinhard + vertical flip (the blit's uv, :35), RGBA8
 __global__ void k_tonemap(const float4 *__restrict__ accum, int w, int h, uchar4 *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1273,6 +1287,26 @@ int Renderer::write_accum_from_device(const void *dptr, size_t nbytes) {
     MRT_HIP(hipMemcpyAsync(accum[cur].p, dptr, nbytes, hipMemcpyDeviceToDevice, stream));
     return MRT_OK;
 }
+uint32_t shard_tiles(int width, int height, int rank, int world) {
+    const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
+    return (uint32_t)std::max(0, (tiles - rank + world - 1) / world);
+}
+int unpack_tiles_into(float4 *image, int width, int height, const void *compact, size_t nbytes, int rank, int world, hipStream_t st) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("unpack_tiles: invalid shard"); return MRT_ERR_INVALID_ARGUMENT; }
+    const uint32_t tl = shard_tiles(width, height, rank, world);
+    if (nbytes != (size_t)tl * 64 * sizeof(float4)) { set_error("unpack_tiles: nbytes must be tiles x 64 x 16 for that shard (mrt_renderer_shard_tiles)"); return MRT_ERR_INVALID_ARGUMENT; }
+    if (tl) hipLaunchKernelGGL(k_tiles<false>, dim3(cdiv((size_t)tl * 64, 256)), dim3(256), 0, st, image, width, height, (width + 7) / 8, rank, world, tl, (float4 *)const_cast<void *>(compact));
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+int Renderer::pack_owned_tiles(void *dptr, size_t nbytes) {
+    const uint32_t tl = shard_tiles(width, height, shard_rank, shard_world);
+    if (nbytes != (size_t)tl * 64 * sizeof(float4)) { set_error("pack_owned_tiles: nbytes must be tiles x 64 x 16 for this renderer's shard (mrt_renderer_shard_tiles)"); return MRT_ERR_INVALID_ARGUMENT; }
+    if (tl) hipLaunchKernelGGL(k_tiles<true>, dim3(cdiv((size_t)tl * 64, 256)), dim3(256), 0, stream, accum[cur].p, width, height, (width + 7) / 8, shard_rank, shard_world, tl, (float4 *)dptr);
+    MRT_HIP(hipGetLastError());
+    return MRT_OK;
+}
+int Renderer::unpack_tiles(const void *dptr, size_t nbytes, int rank, int world) { return unpack_tiles_into(accum[cur].p, width, height, dptr, nbytes, rank, world, stream); }
 int Renderer::read_tonemapped(uint8_t *rgba, size_t nbytes) {
     if (nbytes != (size_t)width * height * 4) { set_error("read_tonemapped: nbytes must be width*height*4"); return MRT_ERR_INVALID_ARGUMENT; }
     DevBuf<uchar4> tmp; MRT_HIP(tmp.alloc((size_t)width * height));

@@ -71,6 +71,60 @@ def reduce_accumulation(accum: torch.Tensor, mode="tile", dst=0, group=None):
     return accum
 
 
+def shard_tiles(width, height, rank, world):
+    """8 x 8 tiles of the image that shard (rank, world) owns (tile_id % world == rank)."""
+    tiles = ((width + 7) // 8) * ((height + 7) // 8)
+    return max(0, (tiles - rank + world - 1) // world)
+
+
+def _tile_index(width, height, rank, world):
+    """(ys, xs, inside) of the compact buffer's tiles x 64 pixels: tile lt of the shard is tile lt * world + rank of the image, its 8 x 8 pixels row-major."""
+    tl = shard_tiles(width, height, rank, world)
+    tiles_x = (width + 7) // 8
+    tile = np.arange(tl, dtype=np.int64)[:, None] * world + rank
+    k = np.arange(64, dtype=np.int64)[None, :]
+    ys, xs = (tile // tiles_x) * 8 + k // 8, (tile % tiles_x) * 8 + k % 8
+    return ys, xs, (xs < width) & (ys < height)
+
+
+def pack_owned_tiles(accum, rank, world):
+    """Host twin of mrt_renderer_pack_owned_tiles (csrc/renderer.hip k_tiles): (h, w, 4) -> (tiles x 64, 4), pixels outside the image 0."""
+    a = np.asarray(accum); h, w = a.shape[:2]
+    ys, xs, inside = _tile_index(w, h, rank, world)
+    out = np.zeros(ys.shape + (4,), a.dtype)
+    out[inside] = a[ys[inside], xs[inside]]
+    return out.reshape(-1, 4)
+
+
+def unpack_tiles(image, compact, rank, world):
+    """Host twin of mrt_renderer_unpack_tiles: writes shard (rank, world)'s compact buffer into the image (in place)."""
+    h, w = image.shape[:2]
+    ys, xs, inside = _tile_index(w, h, rank, world)
+    c = np.asarray(compact).reshape(ys.shape + (4,))
+    image[ys[inside], xs[inside]] = c[inside]
+    return image
+
+
+def gather_compact(accum: torch.Tensor, dst=0, group=None, pack=None, unpack=None):
+    """The compact assemble of a tile-sharded image (beside reduce_accumulation): every rank ships only the tiles it owns — 1 / world of the image — as one
+    dist.gather of equally sized (padded) compact buffers, and `dst` writes them in place.  Same image as the reduce, bit for bit (nothing is added).
+    pack(rank) -> this rank's compact tensor / unpack(compact, rank): device kernels of a ShardedRenderer; default: the numpy twins on host tensors."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    h, w = accum.shape[:2]
+    n_max = shard_tiles(w, h, 0, world) * 64                 # rank 0 owns the most tiles
+    mine = pack(rank) if pack else torch.from_numpy(pack_owned_tiles(accum.numpy(), rank, world))
+    send = torch.zeros((n_max, 4), dtype=accum.dtype, device=mine.device); send[: mine.shape[0]] = mine
+    recv = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank == dst:
+        for r in range(world):
+            if r == dst: continue
+            n = shard_tiles(w, h, r, world) * 64
+            if unpack: unpack(recv[r][:n], r)
+            else: unpack_tiles(accum.numpy(), recv[r][:n].numpy(), r, world)
+    return accum
+
+
 class ShardedRenderer:
     """A Renderer bound to this rank's GPU and shard; `gather()` runs the ONE collective per output image.  bench.py's N > 1
     path and the multi-process tests drive the multi-GPU case through this class (world == 1: a plain renderer, gather is a copy).
@@ -102,11 +156,14 @@ class ShardedRenderer:
     def draw(self, frames=1):
         self.renderer.draw(frames)
 
-    def gather(self, dst=0):
-        """The assembled image on `dst` (the per-rank accumulation buffers reduced); other ranks get their partial buffer."""
+    def gather(self, dst=0, compact=False):
+        """The assembled image on `dst`; other ranks get their partial buffer.  Default: the ONE reduce(sum) of the whole RGBA32F buffers (north_star).
+        compact=True (tile mode): every rank ships only the tiles it owns, packed and unpacked by the renderer's own kernels (gather_compact)."""
         r = self.renderer
         if self.world == 1:
             return torch.from_numpy(r.accumulation())
+        if compact and self.mode == "tile":
+            return self._gather_compact(dst)
         r.copy_accum_to(self.buffer.data_ptr(), self.buffer.numel() * 4)
         r.wait()
         if self.backend == "gloo":
@@ -115,6 +172,22 @@ class ShardedRenderer:
             self.buffer.copy_(host)
         else:
             reduce_accumulation(self.buffer, self.mode, dst)
+        return self.buffer
+
+    def _gather_compact(self, dst):
+        r = self.renderer; w, h = r.size
+        dev = self.buffer.device
+        def pack(rank):
+            t = torch.empty((r.shard_tiles(rank, self.world) * 64, 4), dtype=torch.float32, device=dev)
+            r.pack_owned_tiles(t.data_ptr(), t.numel() * 4); r.wait()
+            return t.cpu() if self.backend == "gloo" else t
+        def unpack(compact, rank):
+            c = compact.to(dev).contiguous()
+            r.unpack_tiles(c.data_ptr(), c.numel() * 4, rank, self.world); r.wait()
+        r.wait()
+        shape = torch.empty((h, w, 4), dtype=torch.float32, device="cpu" if self.backend == "gloo" else dev)          # (only its shape is read when pack / unpack are given)
+        gather_compact(shape, dst, pack=pack, unpack=unpack)
+        r.copy_accum_to(self.buffer.data_ptr(), self.buffer.numel() * 4); r.wait()          # the root's accumulation buffer now holds the whole image
         return self.buffer
 
     def close(self):

@@ -243,6 +243,18 @@ class Renderer:
     def write_accum_from(self, device_ptr, nbytes):
         check(lib.mrt_renderer_write_accum_from_device(self.handle, C.c_void_p(device_ptr), nbytes))
 
+    def shard_tiles(self, rank, world):
+        """8 x 8 tiles of this image that shard (rank, world) owns (a compact buffer of that shard is tiles x 64 RGBA32F pixels)."""
+        n = C.c_uint64()
+        check(lib.mrt_renderer_shard_tiles(self.handle, int(rank), int(world), C.byref(n)))
+        return n.value
+
+    def pack_owned_tiles(self, device_ptr, nbytes):
+        check(lib.mrt_renderer_pack_owned_tiles(self.handle, C.c_void_p(device_ptr), nbytes))
+
+    def unpack_tiles(self, device_ptr, nbytes, rank, world):
+        check(lib.mrt_renderer_unpack_tiles(self.handle, C.c_void_p(device_ptr), nbytes, int(rank), int(world)))
+
     @property
     def stats(self):
         s = RenderStats()

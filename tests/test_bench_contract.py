@@ -128,10 +128,21 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_one_rank_image(tmp_path):
     assert p1.returncode == 0, p1.stderr[-2000:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", *common, "--dump-accum", two],
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", *common, "--steady-steps", "12", "--dump-accum", two],
                         capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert p2.returncode == 0, p2.stderr[-3000:]
     d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    # the N > 1 line carries both regimes: the driver's steps (value) and a longer leg after them (steady) with its own per-rank times
+    s = d["steady"]
+    assert s["steps"] == 12 and s["value"] > 0 and s["ms_per_step"] > 0 and len(s["per_rank"]["ms_gpu_timed_draw"]) == 2 and "reduce" in d["per_rank"]["assemble"]
+    # the compact assemble (every rank ships only its own tiles) gives the same image
+    three = str(tmp_path / "three.npy")
+    p3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", *common, "--steady-steps", "0", "--assemble", "compact", "--dump-accum", three],
+                        capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert p3.returncode == 0, p3.stderr[-3000:]
+    d3 = json.loads([l for l in p3.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "compact" in d3["per_rank"]["assemble"] and "steady" not in d3 and np.array_equal(np.load(one), np.load(three))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0
     pr = d["per_rank"]           # every rank's device time and its time in the reduce: what the first real SCALE record will be diagnosed with
     assert len(pr["ms_gpu_timed_draw"]) == 2 and min(pr["ms_gpu_timed_draw"]) > 0 and len(pr["gather_wall_ms"]) == 2 and max(pr["render_wall_ms"]) * 1e-3 <= d["ms_per_step"] * d["steps"] * 1e-3 + 1e-3
@@ -151,9 +162,10 @@ def test_bench_group_path_assembles_the_one_rank_image(tmp_path):
     p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-accum", one], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert p1.returncode == 0, p1.stderr[-2000:]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group-devices", "0,0", *common, "--dump-accum", two], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group-devices", "0,0", *common, "--steady-steps", "12", "--assemble", "compact", "--dump-accum", two], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert p2.returncode == 0, p2.stderr[-3000:]
     d = json.loads([l for l in p2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["config"]["reduce_mode"] == 2 and "compact" in d["config"]["reduce"] and d["steady"]["steps"] == 12 and d["steady"]["value"] > 0
     d1 = json.loads([l for l in p1.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shard"] == "tile" and d["value"] > 0 and "device group" in d["config"]["launch"]
     assert len(d["per_rank"]["ms_gpu_timed_draw"]) == 2 and min(d["per_rank"]["ms_gpu_timed_draw"]) > 0 and d["per_rank"]["gather_wall_ms"] >= 0

@@ -37,9 +37,13 @@ def _worker(rank, world, port, mode, w, h, frames, out_path):
     own = D.tile_owner_map(w, h, world) == rank
     if mode == "tile":
         assert (acc.numpy()[~own] == 0).all() and int(own.sum()) == D.owned_pixel_count(w, h, rank, world)
+    if mode == "tile":            # the compact assemble beside the reduce: every rank ships only the tiles it owns; same image bit for bit
+        acc2 = acc.clone()
+        D.gather_compact(acc2, dst=0)
     D.reduce_accumulation(acc, mode, dst=0)
     if rank == 0:
         np.save(out_path, acc.numpy())
+        if mode == "tile": assert np.array_equal(acc.numpy().view(np.uint32), acc2.numpy().view(np.uint32)), "compact assemble != reduce"
     dist.barrier()
     dist.destroy_process_group()
 

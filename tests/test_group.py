@@ -36,6 +36,39 @@ def test_group_image_is_bit_identical_to_one_device(mrt, orc, gpu_ctx, n):
     assert_parity(img, oimg, exact_frac=1.0)
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_group_compact_assemble_is_the_reduce(mrt, gpu_ctx, n):
+    """Reduce mode 2: every rank packs the tiles it owns (1 / n of the image) and the root writes them in place — peer copies here (the group names one device n times), ncclSend /
+    ncclRecv on a real multi-GPU group.  Same image as peer copies + add and as one device, bit for bit; the device pack is the host twin's (distributed.pack_owned_tiles)."""
+    import torch
+    from metal_raytracing_amd import distributed as D
+    w, h, frames = 203, 117, 5          # ragged: partial edge tiles
+    sc = mrt.CornellScene((w, h))
+    ref, st = _plain(mrt, gpu_ctx, sc, w, h, frames)
+    with mrt.GroupRenderer((w, h), sc, [0] * n) as g:
+        g.draw(frames)
+        summed = g.gather()
+        g.set_reduce_mode(2)
+        mode, note = g.reduce_mode
+        assert mode == 2 and "compact" in note and "peer copies" in note
+        packed = g.gather(); again = g.gather()
+    assert np.array_equal(summed.view(np.uint32), ref.view(np.uint32)) and np.array_equal(packed.view(np.uint32), ref.view(np.uint32)) and np.array_equal(again, packed)
+    # one shard's renderer: pack on the device == the host twin of its accumulation buffer; unpack into a second renderer puts the tiles back
+    r = mrt.Renderer((w, h), sc, ctx=gpu_ctx); r.set_shard(1, n); r.draw(frames, wait=True)
+    acc = r.accumulation()
+    tl = r.shard_tiles(1, n); assert tl == D.shard_tiles(w, h, 1, n)
+    t = torch.empty((tl * 64, 4), dtype=torch.float32, device="cuda:0")
+    r.pack_owned_tiles(t.data_ptr(), t.numel() * 4); r.wait()
+    assert np.array_equal(t.cpu().numpy(), D.pack_owned_tiles(acc, 1, n))
+    r2 = mrt.Renderer((w, h), sc, ctx=gpu_ctx); r2.draw(1, wait=True); base = r2.accumulation().copy()
+    r2.unpack_tiles(t.data_ptr(), t.numel() * 4, 1, n); r2.wait()
+    own = D.tile_owner_map(w, h, n) == 1
+    got = r2.accumulation()
+    assert np.array_equal(got[own], acc[own]) and np.array_equal(got[~own], base[~own])
+    with pytest.raises(mrt.MRTError): r.pack_owned_tiles(t.data_ptr(), t.numel() * 4 - 16)
+    r.close(); r2.close()
+
+
 def test_group_accumulates_across_calls_and_options_reach_every_rank(mrt, gpu_ctx):
     w, h = 96, 64
     sc = mrt.SCENES["dragon_small"]((w, h)) if "dragon_small" in mrt.SCENES else mrt.CornellScene((w, h))
