@@ -13,10 +13,10 @@ def kname(n):
     if not m:
         return n.split("(")[0]
     targs = [t.strip() for t in (m.group(2) or "<>")[1:-1].split(",")]
-    if m.group(1) == "k_shade" and len(targs) >= 4 and targs[3] in ("1", "2", "3"):
-        return "k_shade_primary"          # k_shade<MATERIALS, CHAIN, PLANES, TRACE0 = 1 | 2 | 3, PAIRS>: the primary rays generated, traced (1: rope, 2: 8-wide layout, 3: both levels of a two-level scene) and shaded in one launch (fuse_primary)
+    if m.group(1) == "k_shade_pack":
+        return "k_shade"                  # the shades of the bounce queues (bounces >= 1), packed or not: one class; k_shade_primary<WALK> (bounce 0 with the primary walk inside) is its own
     if m.group(1).endswith("_x"):
-        return m.group(1)[:-2]            # the launches with LDS extras (renderer options hit_lds — default — and lds_top): the same kernel class as the form without them
+        return m.group(1)[:-2]            # the launches with the hit words in LDS (renderer option hit_lds, default): the same kernel class as the form without them
     return m.group(1)
 
 
