@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--builder", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], help="renderer option key=value (repeatable)")
     ap.add_argument("--sopt", action="append", default=[], help="scene (BVH build) option key=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 6, each carrying frame_batch frames: 8 at 1080p and above, up to 32 for smaller images; the reference keeps 3 frames)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="passes in flight on separate HIP streams (library default 3, each carrying frame_batch frames: 8 at 1080p and above, up to 32 for smaller images; the reference keeps 3 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra max_bounces=1 (primary + shadow only) measurement")
     ap.add_argument("--no-latency", action="store_true", help="skip the serialised per-frame latency leg and the on-chip calibration")

@@ -147,7 +147,7 @@ inline void uploadScene(MRTScene dst, const Scene &scene, bool instancing = fals
 
 class Renderer {                                                     // Renderer.swift:12-357
   public:
-    static constexpr int maxFramesInFlight = 3;                      // Renderer.swift:33 (here: setOption("frames_in_flight", n); library default 6 passes in flight of up to 8 frames each)
+    static constexpr int maxFramesInFlight = 3;                      // Renderer.swift:33 (here: setOption("frames_in_flight", n); library default: the same three, each a pass of up to 8 frames)
     // instancing = true: models loaded from the same resource become instances of one mesh (mrt_scene_add_instance) and the scene is committed
     // two-level — one BLAS per distinct mesh + a TLAS (the reference's instance acceleration structure, Renderer.swift:193-213)
     Renderer(int width, int height, const Scene &scene, int device = 0, uint32_t seed = 1, int max_bounces = 3, bool instancing = false) : w_(width), h_(height) {

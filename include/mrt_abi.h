@@ -265,7 +265,7 @@ int mrt_renderer_set_camera(MRTRenderer r, const MRTCamera *camera);
 int mrt_renderer_set_uniforms(MRTRenderer r, const MRTUniforms *uniforms);
 int mrt_renderer_get_uniforms(MRTRenderer r, MRTUniforms *uniforms);
 /* The renderer's knobs.  The reference's own: "max_bounces" (the literal 3 of Raytracing.metal:237; 1..19), "frames_in_flight"
- * (Renderer.maxFramesInFlight, Renderer.swift:33: here passes in flight on separate HIP streams, default 6), "sample_offset" (added to
+ * (Renderer.maxFramesInFlight, Renderer.swift:33: here passes in flight on separate HIP streams, default 3 as the reference), "sample_offset" (added to
  * frameIndex for the Halton index only: sample-index sharding).  This implementation's: "frame_batch" (frames carried through the pipeline
  * per pass, 1..32: larger launches against more queue memory — "lane_bytes" per pass in flight; 0, the default, sizes it by the image: 8 at 1920 x 1080 pixels
  * per device and above, proportionally more for a smaller image or a shard of one, so that a pass always carries about the same number of pixel-frames; reads back as the value in force), "megakernel" (1: one launch

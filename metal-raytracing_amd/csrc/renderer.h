@@ -59,7 +59,8 @@ struct Renderer {
     bool throughput_chain = true;        // bounce rays carry the resource slots of their path instead of a throughput record (renderer.hip FrameParams::chain)
     DevBuf<float4> accum[2];             // accumulationTargets (RGBA32F, :231-244)
     FrameLane lanes[MAX_FRAMES_IN_FLIGHT];
-    int frames_in_flight = 6;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33); 6 lanes x 8-frame passes measured best on MI355X (12 x 4 until then)
+    int frames_in_flight = 3;            // Renderer.maxFramesInFlight is 3 (Renderer.swift:33), and three 8-frame passes in flight reach the rate of six on the round-6 tree (14.1 = 14.1 Grays/s at 240 steps, 12.5 = 12.5 at 20;
+                                         // profiles/r06_lanes.txt) with half the queue memory: 8.2 instead of 16.3 GB at 1080p.  Tile groups of one-frame passes take the lanes they need beyond this
     int frame_batch = 0;                 // frames carried through the pipeline per pass at most (a draw's frames go in passes of equal size); 1 = one frame per pass; 0 (default) = by image size:
                                          // DEFAULT_FRAME_BATCH at 1920 x 1080 pixels per device and above, proportionally more for a smaller image or a shard of one (batch_wanted())
     int batch_wanted() const;            // the option, or what "by image size" comes to for this renderer's pixels

@@ -40,7 +40,7 @@ namespace {
 
 __global__ void k_halton_table(float *__restrict__ tab, uint32_t w0, uint32_t n) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) tab[(size_t)blockIdx.y * n + j] = halton_dev((int)(w0 + j), (int)blockIdx.y + 1);
+    if (j < n) tab[MRT_HALTON_INTERLEAVED ? (size_t)j * HALTON_TAB_DIMS + blockIdx.y : (size_t)blockIdx.y * n + j] = halton_dev((int)(w0 + j), (int)blockIdx.y + 1);
 }
 
 // seeds[s * n + i] = hash(seed, i) + s: sub-frame s of a batch reads its Halton offset with the sub-frame index already added

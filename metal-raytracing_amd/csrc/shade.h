@@ -60,10 +60,13 @@ struct FrameParams {            // Uniforms (ShaderTypes.h:89-97) + shard + boun
     // the recurrence.
     const float *halton_tab; uint32_t halton_w0, halton_n;
 };
+#ifndef MRT_HALTON_INTERLEAVED
+#define MRT_HALTON_INTERLEAVED 1      // the six dimensions of an index side by side (24 B): the eight sub-frames of a pixel read 192 contiguous bytes — three or four 64-byte requests — instead of one request in each of six planes (profiles/r06_shade_primary_bytes.txt: the table was 0.83 GB of k_shade_primary's fetches per launch)
+#endif
 constexpr uint32_t HALTON_TAB_DIMS = 6, HALTON_TAB_SPAN = (1u << 20) + (1u << 16);      // seed offsets are below 2^20 (Renderer.swift:259): the window serves 2^16 frames before it moves
 MRT_DEV float halton_b0(const FrameParams &fp, int idx, int d /* 1 .. 6 */) {
     const uint32_t j = (uint32_t)idx - fp.halton_w0;
-    if (fp.halton_tab != nullptr && j < fp.halton_n) return fp.halton_tab[(size_t)(d - 1) * fp.halton_n + j];
+    if (fp.halton_tab != nullptr && j < fp.halton_n) return fp.halton_tab[MRT_HALTON_INTERLEAVED ? (size_t)j * HALTON_TAB_DIMS + (uint32_t)(d - 1) : (size_t)(d - 1) * fp.halton_n + j];
     return halton_dev(idx, d);
 }
 
