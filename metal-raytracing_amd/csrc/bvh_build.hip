@@ -1256,7 +1256,11 @@ static void run_tasks(std::vector<std::function<void()>> &tasks, size_t bytes) {
     for (auto &t : th) t.join();
 }
 
-int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStream_t stream, DeviceScene &out, PinnedBuf *stage, bool geometry_unchanged, bool refit) {
+int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hipStream_t stream, DeviceScene &out, PinnedBuf *stage, bool geometry_unchanged, bool refit) {
+    BuildOptions opt = opt_in;
+    // a wide node addresses the triangles of its leaf children with a 32-bit mask (8 children x 4): with the 8-wide layout the leaf limit is at most 4 — a larger max_leaf
+    // applies to scenes built without it (scene option wide = 0).  Until round 6 such a scene silently lost the 8-wide layout and rendered at half the rate.
+    if (opt.wide && opt.max_leaf > 4) opt.max_leaf = 4;
     struct MeshView { const std::vector<float> &positions, &normals; const float *xf; const std::vector<std::vector<uint32_t>> &sub_indices; const std::vector<MRTMaterial> &sub_materials; };
     std::vector<MeshView> meshes;
     for (auto &r : refs) meshes.push_back(MeshView{r.g->positions, r.g->normals, r.xf, r.g->sub_indices, r.g->sub_materials});
@@ -1640,6 +1644,11 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
         MRT_HIP(hipGetLastError());
         float wms = 0; MRT_HIP(hipEventElapsedTime(&wms, ev0, ev1));
         out.stats.build_ms += wms;
+        // A tree deeper than the traversal's LDS stack can be made (nested, growing triangles: the agglomerative builder merges one pair per round and the binary tree is a chain —
+        // tests/test_deep_tree.py) would fall back to the rope kernels at half the rate.  The radix tree over the same Morton order (builder 0) is at most 63 key bits + the index
+        // splits of equal keys deep whatever the geometry, and its 8-wide collapse a fraction of that: such a scene is built again with it and keeps the 8-wide layout
+        // (from WIDE_DEPTH_REBUILD levels on: DragonScene has 13, a scene beyond 48 is a chain, and every level costs 320 B of LDS per wave).
+        if (depth > WIDE_DEPTH_REBUILD && opt.builder == 1 && !refit) { BuildOptions o2 = opt; o2.builder = 0; return build_flat(refs, o2, stream, out, stage, geometry_unchanged, false); }
         out.wide_depth = depth;
         out.wide_levels.assign(h_lv.begin(), h_lv.begin() + depth); out.refit_triangles = T;
         if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;

@@ -53,7 +53,7 @@ struct Renderer {
     DevBuf<float> halton_tab;            // bounce 0's Halton values by index, dimensions 1 .. 6 (renderer.hip FrameParams::halton_tab), for the window [halton_w0, halton_w0 + 2^20 + 2^16); allocated by the first bundled pass
     uint32_t halton_w0 = 0;
     int halton_table = 1;                // renderer option: bundled passes read bounce 0's Halton values from the table
-    int ensure_halton_table(hipStream_t st, uint32_t sample_index, uint32_t batch);
+    int ensure_halton_table(uint32_t sample_index, uint32_t frames);          // once per draw, on the main stream ahead of the fork
     DevBuf<uint32_t> hint;               // per pixel: the packet its primary ray hit last (k_trace_primary tests it first); 0xFFFFFFFF = none
     bool primary_hint = true;
     bool throughput_chain = true;        // bounce rays carry the resource slots of their path instead of a throughput record (renderer.hip FrameParams::chain)

@@ -661,16 +661,17 @@ int read_drain_probe(unsigned long long *out18, int reset) {
 
 // ====================================================================== Renderer (host)
 // The table of bounce 0's Halton values (FrameParams::halton_tab) for the indices [w0, w0 + HALTON_TAB_SPAN): a pass needs offset + sampleIndex + sub-frame for offsets below 2^20.
-// Filled on `st` (the pass's stream, ahead of its shade(0)) when the window has to move: every 2^16 frames, or when the frame index went back (resize, reset).
-int Renderer::ensure_halton_table(hipStream_t st, uint32_t sample_index, uint32_t batch) {
-    const bool fits = halton_tab.p != nullptr && sample_index >= halton_w0 && (uint64_t)sample_index + batch + (1u << 20) <= (uint64_t)halton_w0 + HALTON_TAB_SPAN;
+// Once per draw, on the MAIN stream ahead of the fork: every lane of this draw starts behind it (the fork event), and every pass of earlier draws has been joined into the main stream
+// — no host or device synchronisation (until round 6 a window move drained the whole device from inside the enqueue loop).  The window follows the draw's first frame when the draw's
+// first pass would leave it; what a very long draw reaches beyond the window falls back to the recurrence per index (halton_b0), bit-identical either way.
+int Renderer::ensure_halton_table(uint32_t sample_index, uint32_t frames) {
+    const uint64_t first_pass = std::min<uint64_t>(frames, MAX_FRAME_BATCH);
+    const bool fits = halton_tab.p != nullptr && sample_index >= halton_w0 && (uint64_t)sample_index + first_pass + (1u << 20) <= (uint64_t)halton_w0 + HALTON_TAB_SPAN;
     if (fits) return MRT_OK;
-    MRT_HIP(hipDeviceSynchronize());            // passes in flight on other streams may still read the old window: they finish first (rare: once per 65 536 frames)
     if (!halton_tab.p) MRT_HIP(halton_tab.alloc((size_t)HALTON_TAB_DIMS * HALTON_TAB_SPAN));
     halton_w0 = sample_index;
-    hipLaunchKernelGGL(k_halton_table, dim3(cdiv(HALTON_TAB_SPAN, 256), HALTON_TAB_DIMS), dim3(256), 0, st, halton_tab.p, halton_w0, HALTON_TAB_SPAN);
+    hipLaunchKernelGGL(k_halton_table, dim3(cdiv(HALTON_TAB_SPAN, 256), HALTON_TAB_DIMS), dim3(256), 0, stream, halton_tab.p, halton_w0, HALTON_TAB_SPAN);
     MRT_HIP(hipGetLastError());
-    MRT_HIP(hipStreamSynchronize(st));          // (rare: once per 65 536 frames) every later pass, on any stream, sees the new window
     return MRT_OK;
 }
 
@@ -900,7 +901,7 @@ int Renderer::render(int n_frames) {                                   // Render
         if (G > 1) F = in_flight * G;          // lanes this draw runs on: G per pass in flight
     }
     for (; lanes_ready < F; lanes_ready++) {
-        const size_t need = lane_bytes();
+        const size_t need = lane_bytes() + (lanes_ready == 0 && !halton_tab.p ? (size_t)HALTON_TAB_DIMS * HALTON_TAB_SPAN * sizeof(float) : 0);      // (+ the renderer's one Halton table, allocated at its first bundled draw)
         size_t free_b = 0, total_b = 0;
         const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b > need + (size_t(1) << 30);      // keep 1 GiB of slack for the caller
         int rc = fits ? alloc_lane(lanes[lanes_ready]) : MRT_ERR_OUT_OF_MEMORY;
@@ -913,6 +914,7 @@ int Renderer::render(int n_frames) {                                   // Render
     if (G > 1) { if (int rc = ensure_tile_groups(G)) return rc; }
     const int Fp = G > 1 ? F / G : F;          // passes in flight
     ext_used = 0;
+    if (halton_table && frame_bundle && !megakernel && n_frames > 1) { if (int rc = ensure_halton_table(frame_index + sample_offset, (uint32_t)n_frames)) return rc; }      // (ahead of the fork: see there)
     MRT_HIP(hipEventRecord(ev_begin, stream));
     // fork: every lane starts after whatever the caller queued on the main stream (resize, camera, ...)
     MRT_HIP(hipEventRecord(ev_fork, stream));
@@ -1071,8 +1073,7 @@ int Renderer::render(int n_frames) {                                   // Render
                     fp.bundle_per_wave = 64u / fp.bundle_w; fp.bundle_magic = (65536u + fp.bundle_w - 1u) / fp.bundle_w;
                 }
                 fp.halton_tab = nullptr; fp.halton_w0 = 0; fp.halton_n = 0;
-                if (b == 0 && fp.frame_bundle && fp.bundle_w >= 4u && halton_table) {          // a wave reads bundle_w consecutive values per load: the table pays from four on
-                    if (int rc = ensure_halton_table(st, fp.sampleIndex, (uint32_t)B)) return rc;
+                if (b == 0 && fp.frame_bundle && fp.bundle_w >= 4u && halton_table && halton_tab.p) {          // a wave reads bundle_w consecutive values per load: the table pays from four on (indices outside its window: the recurrence)
                     fp.halton_tab = halton_tab.p; fp.halton_w0 = halton_w0; fp.halton_n = HALTON_TAB_SPAN;
                 }
                 const dim3 gs = b == 0 ? (fp.frame_bundle ? dim3(cdiv(cdiv((size_t)capacity * fp.bundle_groups, fp.bundle_per_wave) * 64, SHADE_THREADS), 1) : dim3(grid_shade, B)) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
@@ -1171,7 +1172,8 @@ int Renderer::render(int n_frames) {                                   // Render
                     // a shard's launches (a rank of eight over the driver's 20 frames: three passes of its 1/8 of the tiles in flight) do better with ONE round of waves that take the queue's
                     // 64-ray batches round-robin — every rank of eight timed: 2.00 against 2.21 ms on average, the slowest 2.13-2.18 against 2.46-2.50 (profiles/r05_shard_stride.txt); a whole
                     // image's one-frame launches do not (one frame alone 1.38 = 1.38 ms, three in flight 0.775 against 0.765)
-                    const bool shard_auto = stream_stride == 2 && stream_even == 200 && this->shard_world > 1 && G == 1;
+                    const bool takes_x = !two_level && planes_pass && hit_lds;          // k_trace_mixed_wide_stream_x: the one kernel that deals batches round-robin (BatchStride)
+                    const bool shard_auto = stream_stride == 2 && stream_even == 200 && this->shard_world > 1 && G == 1 && takes_x;          // (one round of waves was measured with the strided deal only)
                     const bool strided = stream_stride == 1 || shard_auto;
                     const int even_pct = shard_auto ? 100 : stream_even;
                     const uint32_t even = even_pct > 0 ? (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots_m, 64), (size_t)wave_slots * (size_t)even_pct / 100)) : 0u;     // stream_even: percent of the wave slots
@@ -1181,7 +1183,7 @@ int Renderer::render(int n_frames) {                                   // Render
 #else
                     const uint32_t rpw_m_arg = rpw_m;
 #endif
-                    if (!two_level && planes_pass && hit_lds) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + HIT_LDS_WORDS * 4, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m_arg, lit_b, even | (strided ? 0x80000000u : 0u));
+                    if (takes_x) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream_x, grid_s, dim3(64), stack_bytes + HIT_LDS_WORDS * 4, st, sv, (const float4 *)L.rayA[q].p, (const float4 *)L.rayB[q].p, L.hits.p, (const float4 *)L.srayA.p, (const float4 *)L.srayB.p, (const unsigned long long *)(bc + b), rpw_m_arg, lit_b, even | (strided ? 0x80000000u : 0u));
                     else if (two_level) launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<true>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                     else launch_timed(timed(MRT_KERNEL_TRACE), k_trace_mixed_wide_stream<false>, grid_s, dim3(64), stack_bytes, st, sv, L.rayA[q].p, L.rayB[q].p, L.hits.p, L.srayA.p, L.srayB.p, L.scon.p, (const unsigned long long *)(bc + b), L.sample.p, rpw_m, lit_b, even);
                 }

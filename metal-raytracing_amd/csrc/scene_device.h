@@ -51,8 +51,10 @@ constexpr uint32_t WNODE_STRIDE = MRT_WNODE_STRIDE;   // float4 units between wi
 #define MRT_WPACKET_STRIDE 3
 #endif
 constexpr uint32_t WPK = MRT_WPACKET_STRIDE;          // float4 units between the triangle packets of the 8-wide layout (3 = packed 48 B; 4 = one 64-byte sector each, never straddling two)
-constexpr int WIDE_STACK_MAX = 64;   // deepest 8-wide tree the traversal kernels walk: their LDS stack is sized per launch from the scene's depth (320 B per wave and level: 4.2 KB at DragonScene's 13
-                                     // levels, 7.7 KB at 24 — five instead of six waves per SIMD —, 20 KB at 64); a deeper tree (a chain of nested triangles) keeps the rope layout, and MRTSceneStats::wide_layout says so
+constexpr int WIDE_STACK_MAX = 96;   // deepest 8-wide tree the traversal kernels walk: their LDS stack is sized per launch from the scene's depth (320 B per wave and level: 4.2 KB at DragonScene's 13
+                                     // levels, 7.7 KB at 24 — five instead of six waves per SIMD —, 30 KB at 96: what a radix tree over 63-bit keys + 26 levels of index splits can need at most); the agglomerative
+                                     // builder's deeper trees (a chain of nested triangles) are built again as radix trees (build_flat); only a tree deeper than this keeps the rope layout, and MRTSceneStats::wide_layout says so
+constexpr int WIDE_DEPTH_REBUILD = 48;     // an 8-wide tree from the agglomerative builder deeper than this is built again from the radix tree (build_flat)
 constexpr int WIDE_STACK_TWO_LEVEL = 30;   // two-level scenes: TLAS levels + 1 (the TLAS group parked at instance entry) + the deepest BLAS; 5-bit depth fields
 constexpr uint32_t WIDE_WORLD_RAY_BYTES = 6 * 64 * 4;   // two-level stream traversal: the world-space ray of every lane (o.xyz, d.xyz) parked in LDS in front of the stack
 constexpr uint32_t WIDE_STACK_LEVEL_BYTES = 320;   // per wave and level: 64 x 4 B {child_base << 8 | hit bits} + 64 x 1 B {imask}

@@ -1,6 +1,7 @@
 """Deliberately deep trees: a chain of nested, growing triangles makes the agglomerative builder merge one pair per round — a binary tree as deep as the
-scene has triangles, an 8-wide tree of about a seventh of that.  The render kernels size their LDS stack from the scene's depth (up to WIDE_STACK_MAX = 64
-levels); a scene deeper than that keeps the rope layout, and MRTSceneStats says which of the two a scene got.  Either way the image is the oracle's."""
+scene has triangles, an 8-wide tree of about a seventh of that.  The render kernels size their LDS stack from the scene's depth; an agglomerative tree deeper than
+48 wide levels is built again as a radix tree over the same Morton order (bounded depth whatever the geometry), so that EVERY such scene keeps the 8-wide layout
+(round 6; until then a scene deeper than 64 levels fell back to the rope kernels at half the rate).  MRTSceneStats says what a scene got; the image is the oracle's."""
 import numpy as np
 import pytest
 
@@ -27,17 +28,18 @@ def _scene(mrt, n, growth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,growth,wide", [(150, 1.055, True), (300, 1.027, True), (520, 1.0155, False)])
-def test_deep_chain_renders_on_the_layout_the_stats_name(mrt, orc, gpu_ctx, n, growth, wide):
+@pytest.mark.parametrize("n,growth", [(150, 1.055), (300, 1.027), (520, 1.0155), (2000, 1.004)])
+def test_deep_chain_renders_on_the_wide_layout(mrt, orc, gpu_ctx, n, growth):
+    wide = True
     from test_gpu_parity import assert_parity, oracle_render
     w, h = 96, 64
     sc = _scene(mrt, n, growth)
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
     st = r.device_scene.stats
     print(n, "wide_layout", st.wide_layout, "wide_depth", st.wide_depth, "nodes", st.bvh_nodes)
-    assert st.wide_depth > 16, "the chain is meant to be deeper than the 16 levels the stack used to have"
-    assert st.wide_layout == (1 if wide else 0)
-    assert (st.wide_depth <= 64) == wide
+    assert st.wide_layout == 1 and st.wide_depth <= 96, "every chain keeps the 8-wide layout"
+    if n <= 300: assert st.wide_depth > 16, "the chain is meant to be deeper than the 16 levels the stack used to have (kept as the agglomerative builder made it: <= 48 levels)"
+    rope = mrt.DeviceScene(gpu_ctx, sc, {"wide": 0})          # what such a scene used to fall back to: the same queries below must agree with it too
     r.draw(3, wait=True)
     ref, cnt = oracle_render(orc, mrt, sc, w, h, 3)
     assert_parity(r.accumulation(), ref)
@@ -46,7 +48,7 @@ def test_deep_chain_renders_on_the_layout_the_stats_name(mrt, orc, gpu_ctx, n, g
     osc = orc.OracleScene(mrt.flatten_scene(sc), sc.lights)
     rays = _rays(np.random.default_rng(n), 3000)
     o = osc.intersect_closest(rays, brute=True)
-    walks = [r.device_scene.intersect_closest(rays)] + ([r.device_scene.intersect_stream(rays)] if wide else [])
+    walks = [r.device_scene.intersect_closest(rays), r.device_scene.intersect_stream(rays), rope.intersect_closest(rays)]
     for g in walks:
         for f in ("type", "distance", "primitive_id", "u", "v"):
             assert np.array_equal(g[f], o[f]), (f, n)
@@ -54,4 +56,5 @@ def test_deep_chain_renders_on_the_layout_the_stats_name(mrt, orc, gpu_ctx, n, g
         m = mrt.Renderer((w, h), sc, ctx=gpu_ctx); m.set_option("megakernel", 1); m.draw(3, wait=True)
         assert np.array_equal(m.accumulation(), r.accumulation())
         m.close()
+    rope.close()
     r.close()

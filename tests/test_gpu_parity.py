@@ -631,13 +631,19 @@ def test_animated_transform_recommit(mrt, orc, gpu_ctx):
     r.close()
 
 
-def test_large_leaf_option_falls_back_to_rope(mrt, orc, gpu_ctx):
-    """max_leaf > 4 cannot be addressed by the wide layout's 32-bit triangle mask: the scene then has no wide
-    layout and every ray uses the rope traversal; the image is unchanged."""
+def test_large_leaf_option_keeps_the_wide_layout(mrt, orc, gpu_ctx):
+    """max_leaf > 4 cannot be addressed by the wide layout's 32-bit triangle mask (8 leaf children x 4): with the 8-wide layout the leaf limit is 4 whatever the option says
+    (round 6; such a scene used to lose the layout and render on the rope kernels); a scene built without the layout (wide = 0) takes the larger leaves.  Same image."""
     w, h = 160, 90
     sc = mrt.DragonScene((w, h))
     r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"max_leaf": 7})
+    assert r.device_scene.stats.wide_layout == 1 and r.device_scene.stats.max_leaf_tris == 4
     r.draw(2, wait=True)
+    r7 = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"max_leaf": 7, "wide": 0})
+    assert r7.device_scene.stats.wide_layout == 0 and r7.device_scene.stats.max_leaf_tris == 7
+    r7.draw(2, wait=True)
+    assert np.array_equal(r.accumulation().view(np.uint32), r7.accumulation().view(np.uint32))
+    r7.close()
     ref, _ = oracle_render(orc, mrt, sc, w, h, 2)
     assert_parity(r.accumulation(), ref)
     r.close()
