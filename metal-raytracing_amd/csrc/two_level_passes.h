@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(64, MRT_TWO_LEVEL_WAVES) k_tl_top(SceneView s,
 // order — the rows and boxes are wave-uniform (scalar loads), nothing diverges, nothing is gathered, no stack, no refill.  First the instances of at most eight triangles, tested in
 // place in object space (they give the ray its bound); then the large ones: the ray against the instance's BLAS box in object space, and a pair for the BLAS pass where it enters
 // before that bound.  A refused pair (queue full) is walked here, one ray per lane (traverse_wide from the BLAS root).  Pairs leave instance-major, so the BLAS pass's waves see one
-// instance at a time.  The stream walk of the 8-wide TLAS (k_tl_top) spent 1.16 ms per launch on the 12 M rays of an 8-frame pass of dragon x 4, refilling lanes every other iteration; this takes them in 0.53 ms (profiles/r04_two_level_binned_ab.txt).
+// instance at a time.  (Compacting the (ray, instance) candidates across the wave — world boxes first, then a list in LDS taken 64 entries at a time — measured -12 % in round 6:
+// per-lane gathers of rows and packets cost more than the idle lanes they save; profiles/r06_two_level_ab.txt D.)  The stream walk of the 8-wide TLAS (k_tl_top) spent 1.16 ms per launch on the 12 M rays of an 8-frame pass of dragon x 4, refilling lanes every other iteration; this takes them in 0.53 ms (profiles/r04_two_level_binned_ab.txt).
 constexpr uint32_t TL_FLAT_MAX_INSTANCES = 64;
 // ONE ray of that pass (every lane of the wave calls it; `done` = the lane has no ray, or its shadow ray is already occluded).  push(id): the ray enters large instance id —
 // true = a pair for the BLAS pass is (or will be) queued; false = walk(I, oo, dd, bound, h) walks the instance in place.  Leaves the closest hit among the small instances (and refused pairs) in
