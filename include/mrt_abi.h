@@ -123,7 +123,10 @@ typedef struct {
     float    wide_cost_built;  /* the same as the last BUILD left it: wide_cost / wide_cost_built is how much refits have loosened the tree —
                                   the signal to build again (scene option "refit_max_cost_ratio" does it by itself)                         */
     uint32_t refits;           /* commits served by a refit since the last build                                                          */
-    uint32_t _pad;
+    float    leaf_growth;      /* surface area of the MOVED meshes' leaf boxes against what the build gave them (1 after a build; chained over the
+                                  refits since; two-level scenes: the worst BLAS).  The sharper of the two signals: a small, finely tessellated
+                                  mesh in a large room hardly moves the whole tree's cost (DragonScene at a 2 % deformation: wide_cost x 1.014,
+                                  leaf_growth ~2, rate x 0.85).  "refit_max_cost_ratio" acts on whichever is larger                            */
 } MRTSceneStats;
 
 typedef struct {

@@ -97,7 +97,7 @@ class SceneStats(C.Structure):
     _fields_ = [("triangles", C.c_uint64), ("vertices", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_leaves", C.c_uint64),
                 ("scene_bytes", C.c_uint64), ("build_ms", C.c_float), ("sah_cost", C.c_float), ("instances", C.c_int32),
                 ("max_submeshes", C.c_int32), ("max_leaf_tris", C.c_int32), ("max_depth", C.c_int32), ("wide_layout", C.c_int32), ("wide_depth", C.c_int32),
-                ("wide_cost", C.c_float), ("wide_cost_built", C.c_float), ("refits", C.c_uint32), ("_pad", C.c_uint32)]
+                ("wide_cost", C.c_float), ("wide_cost_built", C.c_float), ("refits", C.c_uint32), ("leaf_growth", C.c_float)]
 
 
 class RenderStats(C.Structure):

@@ -907,9 +907,13 @@ __global__ void k_refit_wide_packets(const float4 *__restrict__ tri_world, float
 // that reference, clipped to its slab if the triangle was pre-split (walls and floor: 32 references each; with the whole triangle's box on every one of them the refitted
 // DragonScene rendered 14 % slower than a fresh build at a deformation of half a percent of the dragon's size).
 __global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__restrict__ wpackets, const float4 *__restrict__ tri_lo, const float4 *__restrict__ tri_hi,
-                                   const uint4 *__restrict__ tri_shade, const uint8_t *__restrict__ inst_dirty, float4 *__restrict__ nbox, uint32_t first, uint32_t count) {
+                                   const uint4 *__restrict__ tri_shade, const uint8_t *__restrict__ inst_dirty, float4 *__restrict__ nbox, uint32_t first, uint32_t count, double *__restrict__ growth /* [0] += area of the moved leaf children's boxes as they were, [1] += as they are now */) {
+    __shared__ double s_g[2];          // (one wave per workgroup) the workgroup's two sums: one pair of global atomics per 64 nodes
+    if (threadIdx.x == 0) { s_g[0] = 0.0; s_g[1] = 0.0; }
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    double g_old = 0.0, g_new = 0.0;
     const size_t w = WNODE_STRIDE * (size_t)(first + i);
     const float4 n0 = wnodes[w], n1 = wnodes[w + 1];
     const uint32_t imask = __float_as_uint(n0.w) >> 24, cbase = __float_as_uint(n1.x), tbase = __float_as_uint(n1.y), meta[2] = {__float_as_uint(n1.z), __float_as_uint(n1.w)};
@@ -935,23 +939,36 @@ __global__ void k_refit_wide_level(float4 *__restrict__ wnodes, const float4 *__
                 hi[0] = fmaxf(hi[0], b.x); hi[1] = fmaxf(hi[1], b.y); hi[2] = fmaxf(hi[2], b.z);
                 occ[sl] = true;
             }
-            if (cnt != 0u && !moved) {          // the box this child has: planes q * 2^e + p on the node's grid as it stands (rounded outwards when they were written)
+            if (cnt != 0u) {          // the box this child has: planes q * 2^e + p on the node's grid as it stands (rounded outwards when they were written)
                 const uint32_t ew = __float_as_uint(n0.w);
                 const float org[3] = {n0.x, n0.y, n0.z};
                 const float4 p2 = wnodes[w + 2], p3 = wnodes[w + 3], p4 = wnodes[w + 4];
                 const uint32_t pl[6][2] = {{__float_as_uint(p2.x), __float_as_uint(p2.y)}, {__float_as_uint(p2.z), __float_as_uint(p2.w)}, {__float_as_uint(p3.x), __float_as_uint(p3.y)},
                                            {__float_as_uint(p3.z), __float_as_uint(p3.w)}, {__float_as_uint(p4.x), __float_as_uint(p4.y)}, {__float_as_uint(p4.z), __float_as_uint(p4.w)}};
+                float had_lo[3], had_hi[3], now_lo[3], now_hi[3];          // the child's box as it was, and the new one rounded outwards onto the SAME (old) grid: like with like
                 for (int a = 0; a < 3; a++) {
                     const float st = __builtin_ldexpf(1.0f, (int)(int8_t)((ew >> (8 * a)) & 0xFFu));
                     const float ql = (float)((pl[a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu), qh = (float)((pl[3 + a][sl >> 2] >> (8 * (sl & 3))) & 0xFFu);
                     // (exact: a plane is p + q * 2^e with q < 256)  Never beyond its triangles' own boxes: a moving sibling changes the node's grid with every refit, and a box
                     // re-rounded outwards onto each new grid would creep; an unsplit triangle's leaf thus keeps exactly its box, a pre-split reference at worst ends at its triangle's
-                    lo[a] = fmaxf(lo[a], __builtin_fmaf(ql, st, org[a])); hi[a] = fminf(hi[a], __builtin_fmaf(qh, st, org[a]));
+                    had_lo[a] = __builtin_fmaf(ql, st, org[a]); had_hi[a] = __builtin_fmaf(qh, st, org[a]);
+                    now_lo[a] = __builtin_fmaf(floorf((lo[a] - org[a]) / st), st, org[a]); now_hi[a] = __builtin_fmaf(ceilf((hi[a] - org[a]) / st), st, org[a]);
+                    if (!moved) { lo[a] = fmaxf(lo[a], had_lo[a]); hi[a] = fminf(hi[a], had_hi[a]); }
+                }
+                if (moved) {          // what the refit does to the moved meshes' leaves: their boxes' area before and after (MRTSceneStats.leaf_growth)
+                    const float ox = fmaxf(had_hi[0] - had_lo[0], 0.0f), oy = fmaxf(had_hi[1] - had_lo[1], 0.0f), oz = fmaxf(had_hi[2] - had_lo[2], 0.0f);
+                    const float nx_ = fmaxf(now_hi[0] - now_lo[0], 0.0f), ny_ = fmaxf(now_hi[1] - now_lo[1], 0.0f), nz_ = fmaxf(now_hi[2] - now_lo[2], 0.0f);
+                    g_old += (double)(ox * oy + oy * oz + oz * ox); g_new += (double)(nx_ * ny_ + ny_ * nz_ + nz_ * nx_);
                 }
             }
         }
         for (int a = 0; a < 3; a++) { clo[sl][a] = lo[a]; chi[sl][a] = hi[a]; if (occ[sl]) { nl[a] = fminf(nl[a], lo[a]); nh[a] = fmaxf(nh[a], hi[a]); } }
         any = any || occ[sl];
+    }
+    if (growth) {          // (the lanes of the wave are together here)
+        if (g_new > 0.0) { atomicAdd(&s_g[0], g_old); atomicAdd(&s_g[1], g_new); }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_g[1] > 0.0) { atomicAdd(&growth[0], s_g[0]); atomicAdd(&growth[1], s_g[1]); }
     }
     if (!any) { nbox[2 * (size_t)(first + i)] = make_float4(n0.x, n0.y, n0.z, 0.0f); nbox[2 * (size_t)(first + i) + 1] = make_float4(n0.x, n0.y, n0.z, 0.0f); return; }      // (a node without children: nothing to move)
     // the node's grid: p = lo, step 2^e >= extent / 255 per axis; a child's planes rounded outwards and checked against their decoded positions (as k_wide_level)
@@ -1104,7 +1121,7 @@ int wide_tree_cost(const float4 *wnodes, uint32_t first, uint32_t count, uint32_
 // Refit of ONE BLAS of a two-level scene in the scene's shared arrays (two_level.hip refit_two_level): the mesh's new object-space triangles (k_flatten under the identity),
 // the BLAS's packets of both layouts rewritten by the id each carries, its 8-wide nodes [wnode_base, + wnodes) bottom-up level by level (k_refit_wide_level: child and packet
 // indices in there are absolute, the triangle arrays are the BLAS's own), its rope nodes by k_rope_refit, its normals.  Leaves the BLAS's root box (object space) in root_lo / root_hi.
-int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out) {
+int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out, float *growth_out) {
     const size_t nv = g.positions.size() / 3, T = br.ntri;
     if (T == 0 || br.wnodes == 0 || g.normals.size() != g.positions.size()) { set_error("refit_blas: nothing to refit"); return MRT_ERR_STATE; }
     static_assert(WPK == 3, "k_refit_wide_packets serves both packet arrays at a stride of three float4");
@@ -1125,6 +1142,7 @@ int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, Devic
     MRT_HIP(d_pos.alloc_in(arena, 3 * nv)); MRT_HIP(d_idx.alloc_in(arena, idx.size())); MRT_HIP(d_recs.alloc_in(arena, 6 * recs.size())); MRT_HIP(cbounds.alloc_in(arena, 6)); MRT_HIP(cols.alloc_in(arena, 4));
     MRT_HIP(tri_world.alloc_in(arena, 3 * T)); MRT_HIP(tri_lo.alloc_in(arena, T)); MRT_HIP(tri_hi.alloc_in(arena, T)); MRT_HIP(ts_tmp.alloc_in(arena, T));
     MRT_HIP(nbox.alloc_in(arena, 2 * (out.wnodes.n / WNODE_STRIDE))); MRT_HIP(dirty.alloc_in(arena, 4));
+    DevBuf<double> growth; MRT_HIP(growth.alloc_in(arena, 2)); MRT_HIP(hipMemsetAsync(growth.p, 0, 16, stream));
     MRT_HIP(parent.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1))); MRT_HIP(arrived.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1))); MRT_HIP(ab.alloc_in(arena, std::max<size_t>(br.rope_nodes, 1)));
     struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs;
     MRT_HIP(hipEventCreate(&evs.a)); MRT_HIP(hipEventCreate(&evs.b));
@@ -1143,7 +1161,7 @@ int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, Devic
     std::vector<uint32_t> first(br.wide_levels.size(), br.wnode_base);
     for (size_t L = 1; L < br.wide_levels.size(); L++) first[L] = first[L - 1] + br.wide_levels[L - 1];
     for (size_t L = br.wide_levels.size(); L-- > 0;)
-        hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(br.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, ts_tmp.p, dirty.p, nbox.p, first[L], br.wide_levels[L]);
+        hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(br.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, ts_tmp.p, dirty.p, nbox.p, first[L], br.wide_levels[L], growth.p);
     // rope layout
     float4 *const rn = out.bnodes.p + 4 * (size_t)br.node_base, *const rp = out.bnodes.p + out.bpackets_offset + 3 * (size_t)br.packet_base;
     hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(T32, 256)), dim3(256), 0, stream, tri_world.p, rp, T32);
@@ -1155,7 +1173,10 @@ int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, Devic
     MRT_HIP(hipMemcpyAsync(out.normals.p + br.vbase, h_nrm.data(), nv * 16, hipMemcpyHostToDevice, stream));
     float4 h_box[2];
     MRT_HIP(hipMemcpyAsync(h_box, nbox.p + 2 * (size_t)br.wnode_base, sizeof h_box, hipMemcpyDeviceToHost, stream));
+    double h_growth[2] = {0.0, 0.0};
+    MRT_HIP(hipMemcpyAsync(h_growth, growth.p, sizeof h_growth, hipMemcpyDeviceToHost, stream));
     MRT_HIP(hipStreamSynchronize(stream));
+    if (growth_out) *growth_out = h_growth[0] > 0.0 ? (float)(h_growth[1] / h_growth[0]) : 1.0f;
     MRT_HIP(hipGetLastError());
     float ms = 0; MRT_HIP(hipEventElapsedTime(&ms, evs.a, evs.b));
     if (ms_out) *ms_out = ms;
@@ -1417,6 +1438,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     if (do_refit) {
         DevBuf<float4> nbox; MRT_HIP(nbox.alloc_in(arena, 2 * (size_t)out.num_wnodes));
+        DevBuf<double> growth; MRT_HIP(growth.alloc_in(arena, 2)); MRT_HIP(hipMemsetAsync(growth.p, 0, 16, stream));
         DevBuf<uint8_t> inst_dirty; MRT_HIP(inst_dirty.alloc_in(arena, std::max<size_t>(I, 1)));
         std::vector<uint8_t> h_dirty(std::max<size_t>(I, 1), 0);
         for (size_t mi = 0; mi < I; mi++) h_dirty[mi] = refs[mi].g->dirty ? 1 : 0;
@@ -1425,10 +1447,12 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         std::vector<uint32_t> first(out.wide_levels.size(), 0u);
         for (size_t L = 1; L < out.wide_levels.size(); L++) first[L] = first[L - 1] + out.wide_levels[L - 1];
         for (size_t L = out.wide_levels.size(); L-- > 0;)
-            hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(out.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, out.tri_shade.p, inst_dirty.p, nbox.p, first[L], out.wide_levels[L]);
+            hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(out.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, out.tri_shade.p, inst_dirty.p, nbox.p, first[L], out.wide_levels[L], growth.p);
         MRT_HIP(hipEventRecord(ev1, stream));
         float4 h_box[2];
         MRT_HIP(hipMemcpyAsync(h_box, nbox.p, sizeof h_box, hipMemcpyDeviceToHost, stream));
+        double h_growth[2] = {0.0, 0.0};
+        MRT_HIP(hipMemcpyAsync(h_growth, growth.p, sizeof h_growth, hipMemcpyDeviceToHost, stream));
         if (int rc = upload_normals()) return rc;
         MRT_HIP(hipStreamSynchronize(stream));
         MRT_HIP(hipGetLastError());
@@ -1439,11 +1463,14 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         if (int rc = wide_tree_cost(out.wnodes.p, 0, out.num_wnodes, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc;
         if (out.stats.wide_cost_built > 0.0f) out.stats.sah_cost = out.sah_cost_built * (out.stats.wide_cost / out.stats.wide_cost_built);
         out.stats.refits = out.refits + 1;
+        // the moved meshes' leaf boxes against what they were before this refit, chained over the refits since the build: the view-independent cost above hardly moves when a small,
+        // finely tessellated mesh in a large room loosens (DragonScene, 2 % deformation: wide_cost x 1.014, rate x 0.85) — this does
+        out.stats.leaf_growth = stats_before.leaf_growth * (h_growth[0] > 0.0 ? (float)(h_growth[1] / h_growth[0]) : 1.0f);
         out.root_lo[0] = h_box[0].x; out.root_lo[1] = h_box[0].y; out.root_lo[2] = h_box[0].z; out.root_hi[0] = h_box[1].x; out.root_hi[1] = h_box[1].y; out.root_hi[2] = h_box[1].z;
         out.commit_ms[2] = since(tw2);
         out.refits++;
         // scene option refit_max_cost_ratio: a tree that refits have loosened beyond that factor of its build-time cost is built again, here (the commit then costs a build)
-        if (opt.refit_max_cost_ratio > 0.0f && out.stats.wide_cost_built > 0.0f && out.stats.wide_cost > opt.refit_max_cost_ratio * out.stats.wide_cost_built)
+        if (opt.refit_max_cost_ratio > 0.0f && ((out.stats.wide_cost_built > 0.0f && out.stats.wide_cost > opt.refit_max_cost_ratio * out.stats.wide_cost_built) || out.stats.leaf_growth > opt.refit_max_cost_ratio))
             return build_flat(refs, opt, stream, out, stage, false, false);
         return MRT_OK;
     }
@@ -1653,7 +1680,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         out.wide_levels.assign(h_lv.begin(), h_lv.begin() + depth); out.refit_triangles = T;
         if (depth <= WIDE_STACK_MAX && total < (1u << 24)) out.num_wnodes = total;
         if (int rc = wide_tree_cost(out.wnodes.p, 0, total, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc;
-        out.stats.wide_cost_built = out.stats.wide_cost; out.sah_cost_built = out.stats.sah_cost;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
+        out.stats.wide_cost_built = out.stats.wide_cost; out.sah_cost_built = out.stats.sah_cost; out.stats.leaf_growth = 1.0f;       // deeper than any LDS stack the kernels are launched with (or child_base beyond its 24 stack bits): the rope backend, reported by MRTSceneStats::wide_layout = 0
         out.stats.scene_bytes += (uint64_t)total * 16 * WNODE_STRIDE + (uint64_t)n * 48;
         out.stats.bvh_nodes = out.num_wnodes ? total : h_size;
         out.stats.max_depth = out.num_wnodes ? depth : out.stats.max_depth;

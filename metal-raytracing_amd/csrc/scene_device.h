@@ -215,7 +215,7 @@ struct BlasRange {
     uint32_t ts_base = 0, vbase = 0;
     std::vector<uint32_t> wide_levels;                       // nodes per level of its 8-wide tree (BFS numbering)
     float wide_cost_built = 0.0f, sah_cost_built = 0.0f;     // as its build left them (MRTSceneStats)
-    float wide_cost = 0.0f;
+    float wide_cost = 0.0f, leaf_growth = 1.0f;              // leaf_growth: its leaf boxes' area against the build's, chained over its refits
 };
 
 struct DeviceScene {
@@ -263,7 +263,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt, hipStr
 // two_level.hip
 int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);
 int refit_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out);      // after mrt_scene_update_mesh alone: the BLASes of the updated meshes refitted in place (both layouts) + the TLAS; MRT_ERR_UNSUPPORTED (no message): the scene cannot be refitted, build it
-int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out);      // bvh_build.hip
+int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, DeviceScene &out, float root_lo[3], float root_hi[3], float *ms_out, float *growth_out);      // bvh_build.hip
 int update_tlas(const std::vector<HostMesh> &meshes, hipStream_t stream, DeviceScene &out);      // after transform changes: instance rows + TLAS, BLASes untouched
 int validate_layout(const DeviceScene &sc, hipStream_t stream, bool tlas_only, const float4 *wnodes_override = nullptr);      // wnodes_override: a device copy of the 8-wide nodes to check in place of the scene's (mrt_debug_validate_patched)
          // every index of the 8-wide layout / instance rows inside its array; MRT_ERR_STATE + message otherwise

@@ -545,7 +545,7 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
     out.stats = MRTSceneStats{};
     out.stats.triangles = T_total; out.stats.vertices = V_total; out.stats.instances = (int32_t)I; out.stats.max_submeshes = max_sub; out.stats.max_leaf_tris = opt.max_leaf;
     out.stats.bvh_leaves = leaves; out.stats.build_ms = build_ms; out.stats.sah_cost = B ? (float)(sah / (double)B) : 0.0f;
-    out.stats.wide_cost = out.stats.wide_cost_built = (B && all_wide) ? (float)(wcost / (double)B) : 0.0f; out.sah_cost_built = out.stats.sah_cost; out.refits = 0; out.blas_all_wide = all_wide;
+    out.stats.wide_cost = out.stats.wide_cost_built = (B && all_wide) ? (float)(wcost / (double)B) : 0.0f; out.sah_cost_built = out.stats.sah_cost; out.refits = 0; out.blas_all_wide = all_wide; out.stats.leaf_growth = 1.0f;
     out.stats.scene_bytes = (uint64_t)nodes_total * 64 + (uint64_t)packets_total * 48 + (all_wide ? (uint64_t)wnodes_total * 80 + (uint64_t)packets_total * 48 : 0) + (uint64_t)ts_total * 16 + (uint64_t)V_total * 16 + (uint64_t)I * (80 + 64 + (uint64_t)max_sub * 20);
     out.validated_blas = false;            // the BLAS part of wnodes is new: update_tlas checks all of it this time
     return update_tlas(meshes, stream, out);
@@ -558,24 +558,25 @@ int build_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt
 int refit_two_level(const std::vector<HostMesh> &meshes, const BuildOptions &opt, hipStream_t stream, DeviceScene &out) {
     if (!out.blas_all_wide || out.num_inst != meshes.size() || out.blas_ranges.empty() || out.h_inst.size() != meshes.size()) return MRT_ERR_UNSUPPORTED;
     for (const BlasRange &r : out.blas_ranges) if (r.src_mesh >= meshes.size() || (meshes[r.src_mesh].dirty && (r.wnodes == 0 || r.wide_levels.empty() || meshes[r.src_mesh].positions.size() / 3 == 0))) return MRT_ERR_UNSUPPORTED;
-    float ms_total = 0; double sah = 0, wcost = 0;
+    float ms_total = 0, growth_max = 1.0f; double sah = 0, wcost = 0;
     for (size_t b = 0; b < out.blas_ranges.size(); b++) {
         BlasRange &r = out.blas_ranges[b];
         if (meshes[r.src_mesh].dirty && r.ntri != 0) {
-            float ms = 0;
-            if (int rc = refit_blas(meshes[r.src_mesh], r, stream, out, &out.blas_lo[3 * b], &out.blas_hi[3 * b], &ms)) return rc;
+            float ms = 0, gr = 1.0f;
+            if (int rc = refit_blas(meshes[r.src_mesh], r, stream, out, &out.blas_lo[3 * b], &out.blas_hi[3 * b], &ms, &gr)) return rc;
+            r.leaf_growth *= gr;
             if (int rc = wide_tree_cost(out.wnodes.p, r.wnode_base, r.wnodes, r.wnode_base, opt.wide_cost_node, opt.wide_cost_tri, stream, &r.wide_cost)) return rc;
             ms_total += ms;
         }
-        wcost += r.wide_cost; sah += r.wide_cost_built > 0.0f ? r.sah_cost_built * (r.wide_cost / r.wide_cost_built) : r.sah_cost_built;
+        growth_max = std::max(growth_max, r.leaf_growth); wcost += r.wide_cost; sah += r.wide_cost_built > 0.0f ? r.sah_cost_built * (r.wide_cost / r.wide_cost_built) : r.sah_cost_built;
     }
     const MRTSceneStats before = out.stats;
     // scene option refit_max_cost_ratio: the refits have loosened the BLASes beyond that factor of their build-time cost — the caller builds the scene again
-    if (opt.refit_max_cost_ratio > 0.0f && before.wide_cost_built > 0.0f && (float)(wcost / (double)out.blas_ranges.size()) > opt.refit_max_cost_ratio * before.wide_cost_built) return MRT_ERR_UNSUPPORTED;
+    if (opt.refit_max_cost_ratio > 0.0f && before.wide_cost_built > 0.0f && ((float)(wcost / (double)out.blas_ranges.size()) > opt.refit_max_cost_ratio * before.wide_cost_built || growth_max > opt.refit_max_cost_ratio)) return MRT_ERR_UNSUPPORTED;
     if (int rc = update_tlas(meshes, stream, out)) return rc;          // the instances' world boxes follow their BLAS's new root box
     const size_t B = out.blas_ranges.size();
     out.stats.build_ms = ms_total; out.stats.wide_cost = (float)(wcost / (double)B); out.stats.wide_cost_built = before.wide_cost_built; out.stats.sah_cost = (float)(sah / (double)B);
-    out.refits++; out.stats.refits = out.refits;
+    out.refits++; out.stats.refits = out.refits; out.stats.leaf_growth = growth_max;
     return MRT_OK;
 }
 
