@@ -214,8 +214,8 @@ int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const floa
  * a two-level scene (instancing = 1) the BLAS of every changed mesh in place, in both layouts, and then its TLAS: every triangle packet rewritten, the boxes recomputed
  * bottom-up, the tree's shape as built — in a fraction of a build's time; the image is the one a fresh build of the deformed scene gives (the closest hit does not depend on
  * the tree).  The boxes of a tree that keeps its shape loosen with the deformation: MRTSceneStats.wide_cost against wide_cost_built says by how much (sah_cost follows), and
- * scene option "refit_max_cost_ratio" = r makes a commit build again by itself once wide_cost > r x wide_cost_built.  Flattened scenes on the rope layout and scene option
- * refit = 0 build again.  The reference builds its acceleration structures once (Renderer.swift:184-214) and never deforms a mesh; this is the counterpart of Metal's refit
+ * scene option "refit_max_cost_ratio" = r makes a commit build again by itself once wide_cost > r x wide_cost_built.  A rope layout (scene option rope = 1 beside the 8-wide one, or wide = 0 alone) is
+ * refitted the same way; scene option refit = 0 builds again.  The reference builds its acceleration structures once (Renderer.swift:184-214) and never deforms a mesh; this is the counterpart of Metal's refit
  * of a primitive acceleration structure.                                                                                                                              */
 int mrt_scene_update_mesh(MRTScene scene, int32_t mesh_id, const float *positions, size_t pos_stride_bytes,
                           const float *normals, size_t nrm_stride_bytes, size_t vertex_count);

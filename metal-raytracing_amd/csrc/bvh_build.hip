@@ -1006,7 +1006,8 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
 // packet carries) and climbs — the second thread to arrive at a node (a counter per node) unions the children's boxes and goes on.  The hand-off is k_refit's: 16-byte
 // write-through stores, drained before the agent-scope arrival, sc1 loads after it.  Escape links and near-child masks are the build's: order, not correctness.
 __global__ void k_rope_refit(float4 *nodes, uint32_t n, const float4 *__restrict__ packets, const float4 *__restrict__ tri_lo, const float4 *__restrict__ tri_hi,
-                             const uint32_t *__restrict__ parent, const uint2 *__restrict__ ab /* per node: its {a, b} words, copied before the pass */, uint32_t *__restrict__ arrived) {
+                             const uint32_t *__restrict__ parent, const uint2 *__restrict__ ab /* per node: its {a, b} words, copied before the pass */, uint32_t *__restrict__ arrived,
+                             const uint4 *__restrict__ tri_shade, const uint8_t *__restrict__ inst_dirty /* both or neither: a leaf none of whose triangles' instances moved keeps the box it has (the clipped boxes of pre-split references survive) */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint2 w = ab[i];
@@ -1014,11 +1015,14 @@ __global__ void k_rope_refit(float4 *nodes, uint32_t n, const float4 *__restrict
     const __amdgpu_buffer_rsrc_t rn = refit_rsrc(nodes);
     const float BIG = 3.0e38f;
     float4 lo = make_float4(BIG, BIG, BIG, 0.0f), hi = make_float4(-BIG, -BIG, -BIG, 0.0f);
+    bool moved = inst_dirty == nullptr;
     for (uint32_t r = 0; r < w.y; r++) {
         const uint32_t gid = __float_as_uint(packets[3 * (size_t)((w.x & 0x7FFFFFFFu) + r)].w);
+        if (inst_dirty) moved = moved || inst_dirty[tri_shade[gid].w >> 16] != 0;
         const float4 l = tri_lo[gid], h = tri_hi[gid];
         lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z); hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
     }
+    if (!moved) { lo = nodes[4 * (size_t)i]; hi = nodes[4 * (size_t)i + 1]; }          // (written by the build or an earlier refit, long before this launch)
     for (;;) {
         lo.w = __uint_as_float(w.x); hi.w = __uint_as_float(w.y);
         refit_st_wt(rn, 4u * i, lo); refit_st_wt(rn, 4u * i + 1u, hi);
@@ -1167,7 +1171,7 @@ int refit_blas(const HostMesh &g, const BlasRange &br, hipStream_t stream, Devic
     hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(T32, 256)), dim3(256), 0, stream, tri_world.p, rp, T32);
     if (br.rope_nodes) {
         hipLaunchKernelGGL(k_rope_prepare, dim3(cdiv(br.rope_nodes, 256)), dim3(256), 0, stream, (const float4 *)rn, br.rope_nodes, parent.p, ab.p);
-        hipLaunchKernelGGL(k_rope_refit, dim3(cdiv(br.rope_nodes, 256)), dim3(256), 0, stream, rn, br.rope_nodes, (const float4 *)rp, tri_lo.p, tri_hi.p, (const uint32_t *)parent.p, (const uint2 *)ab.p, arrived.p);
+        hipLaunchKernelGGL(k_rope_refit, dim3(cdiv(br.rope_nodes, 256)), dim3(256), 0, stream, rn, br.rope_nodes, (const float4 *)rp, tri_lo.p, tri_hi.p, (const uint32_t *)parent.p, (const uint2 *)ab.p, arrived.p, (const uint4 *)nullptr, (const uint8_t *)nullptr);
     }
     MRT_HIP(hipEventRecord(evs.b, stream));
     MRT_HIP(hipMemcpyAsync(out.normals.p + br.vbase, h_nrm.data(), nv * 16, hipMemcpyHostToDevice, stream));
@@ -1359,8 +1363,10 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         catch (...) { for (auto &f : tasks_n) f(); }
     }
     run_tasks(tasks, task_bytes);
-    // a refit keeps the tree (and what the statistics say about it): same triangle count as the build that made the 8-wide layout, that layout usable and the only one resident
-    const bool do_refit = refit && opt.wide && out.num_wnodes != 0 && out.wnodes.p && out.wpackets.p && !out.nodes.p && out.refit_triangles == T && T != 0 && !out.wide_levels.empty();
+    // a refit keeps the tree (and what the statistics say about it): same triangle count as the build that made the layouts — the 8-wide one, the rope one (scene option rope = 1, or a
+    // scene built without the 8-wide layout), or both: whatever is resident is refitted
+    const bool wide_there = opt.wide && out.num_wnodes != 0 && out.wnodes.p && out.wpackets.p && !out.wide_levels.empty(), rope_there = out.nodes.p != nullptr && out.rope_nodes != 0;
+    const bool do_refit = refit && out.refit_triangles == T && T != 0 && (wide_there || rope_there) && (wide_there || !opt.wide);
     const MRTSceneStats stats_before = out.stats;
     if (!do_refit) { out.wide_levels.clear(); out.refit_triangles = 0; out.refits = 0; }
     out.stats = MRTSceneStats{};
@@ -1437,20 +1443,33 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(T32, 1024)), dim3(1024), 0, stream, d_recs_p, (int)nrec, d_pos_p, d_idx_p, out.inst_cols.p, T32,
                        tri_world.p, out.tri_shade.p, tri_lo.p, tri_hi.p, cbounds.p);
     if (do_refit) {
-        DevBuf<float4> nbox; MRT_HIP(nbox.alloc_in(arena, 2 * (size_t)out.num_wnodes));
+        DevBuf<float4> nbox; MRT_HIP(nbox.alloc_in(arena, 2 * (size_t)std::max<uint32_t>(out.num_wnodes, 1u)));
         DevBuf<double> growth; MRT_HIP(growth.alloc_in(arena, 2)); MRT_HIP(hipMemsetAsync(growth.p, 0, 16, stream));
         DevBuf<uint8_t> inst_dirty; MRT_HIP(inst_dirty.alloc_in(arena, std::max<size_t>(I, 1)));
         std::vector<uint8_t> h_dirty(std::max<size_t>(I, 1), 0);
         for (size_t mi = 0; mi < I; mi++) h_dirty[mi] = refs[mi].g->dirty ? 1 : 0;
         MRT_HIP(hipMemcpyAsync(inst_dirty.p, h_dirty.data(), h_dirty.size(), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(out.num_packets, B)), dim3(B), 0, stream, tri_world.p, out.wpackets.p, out.num_packets);
-        std::vector<uint32_t> first(out.wide_levels.size(), 0u);
-        for (size_t L = 1; L < out.wide_levels.size(); L++) first[L] = first[L - 1] + out.wide_levels[L - 1];
-        for (size_t L = out.wide_levels.size(); L-- > 0;)
-            hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(out.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, out.tri_shade.p, inst_dirty.p, nbox.p, first[L], out.wide_levels[L], growth.p);
+        if (wide_there) {
+            hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(out.num_packets, B)), dim3(B), 0, stream, tri_world.p, out.wpackets.p, out.num_packets);
+            std::vector<uint32_t> first(out.wide_levels.size(), 0u);
+            for (size_t L = 1; L < out.wide_levels.size(); L++) first[L] = first[L - 1] + out.wide_levels[L - 1];
+            for (size_t L = out.wide_levels.size(); L-- > 0;)
+                hipLaunchKernelGGL(k_refit_wide_level, dim3(cdiv(out.wide_levels[L], 64)), dim3(64), 0, stream, out.wnodes.p, out.wpackets.p, tri_lo.p, tri_hi.p, out.tri_shade.p, inst_dirty.p, nbox.p, first[L], out.wide_levels[L], growth.p);
+        }
+        if (rope_there) {          // [r6] the rope layout beside it (rope = 1) or alone (wide = 0): packets by the id they carry, boxes by k_rope_refit
+            DevBuf<uint32_t> parent, arrived; DevBuf<uint2> ab;
+            MRT_HIP(parent.alloc_in(arena, out.rope_nodes)); MRT_HIP(arrived.alloc_in(arena, out.rope_nodes)); MRT_HIP(ab.alloc_in(arena, out.rope_nodes));
+            MRT_HIP(hipMemsetAsync(arrived.p, 0, arrived.bytes(), stream));
+            float4 *const rp = out.nodes.p + out.packets_offset;
+            hipLaunchKernelGGL(k_refit_wide_packets, dim3(cdiv(out.num_packets, B)), dim3(B), 0, stream, tri_world.p, rp, out.num_packets);
+            hipLaunchKernelGGL(k_rope_prepare, dim3(cdiv(out.rope_nodes, B)), dim3(B), 0, stream, (const float4 *)out.nodes.p, out.rope_nodes, parent.p, ab.p);
+            hipLaunchKernelGGL(k_rope_refit, dim3(cdiv(out.rope_nodes, B)), dim3(B), 0, stream, out.nodes.p, out.rope_nodes, (const float4 *)rp, tri_lo.p, tri_hi.p, (const uint32_t *)parent.p, (const uint2 *)ab.p, arrived.p,
+                               (const uint4 *)out.tri_shade.p, (const uint8_t *)inst_dirty.p);
+        }
         MRT_HIP(hipEventRecord(ev1, stream));
         float4 h_box[2];
-        MRT_HIP(hipMemcpyAsync(h_box, nbox.p, sizeof h_box, hipMemcpyDeviceToHost, stream));
+        if (wide_there) MRT_HIP(hipMemcpyAsync(h_box, nbox.p, sizeof h_box, hipMemcpyDeviceToHost, stream));
+        else MRT_HIP(hipMemcpyAsync(h_box, out.nodes.p, sizeof h_box, hipMemcpyDeviceToHost, stream));          // (the rope root's box: node 0)
         double h_growth[2] = {0.0, 0.0};
         MRT_HIP(hipMemcpyAsync(h_growth, growth.p, sizeof h_growth, hipMemcpyDeviceToHost, stream));
         if (int rc = upload_normals()) return rc;
@@ -1460,7 +1479,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         out.stats = stats_before;          // the tree's shape, and what was measured on it
         out.stats.build_ms = ms;
         // what the refit did to the tree: the 8-wide tree's cost as it lies now against the build's (MRTSceneStats.wide_cost / wide_cost_built); sah_cost — the build's binary-tree figure — scaled alike
-        if (int rc = wide_tree_cost(out.wnodes.p, 0, out.num_wnodes, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc;
+        if (wide_there) { if (int rc = wide_tree_cost(out.wnodes.p, 0, out.num_wnodes, 0, opt.wide_cost_node, opt.wide_cost_tri, stream, &out.stats.wide_cost)) return rc; }
         if (out.stats.wide_cost_built > 0.0f) out.stats.sah_cost = out.sah_cost_built * (out.stats.wide_cost / out.stats.wide_cost_built);
         out.stats.refits = out.refits + 1;
         // the moved meshes' leaf boxes against what they were before this refit, chained over the refits since the build: the view-independent cost above hardly moves when a small,
@@ -1704,7 +1723,7 @@ int build_flat(const std::vector<MeshRef> &refs, const BuildOptions &opt_in, hip
         MRT_HIP(hipGetLastError());
         float rms = 0; MRT_HIP(hipEventElapsedTime(&rms, ev0, ev1));
         out.stats.build_ms += rms;
-        out.rope_nodes = h_size;
+        out.rope_nodes = h_size; out.refit_triangles = T;
         out.stats.scene_bytes += (uint64_t)h_size * 64 + (uint64_t)n * 48;
     }
     out.commit_ms[4] = since(tw4);

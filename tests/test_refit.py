@@ -67,6 +67,34 @@ def test_refit_gives_the_image_of_a_fresh_build_and_of_the_oracle(mrt, orc, gpu_
     ref.close(); r.close()
 
 
+@pytest.mark.parametrize("sopt,ropt", [({"rope": 1}, {"wide_bounce": 0, "primary_wide": 0}), ({"wide": 0}, {})])
+def test_refit_of_the_rope_layout(mrt, orc, gpu_ctx, sopt, ropt):
+    """The rope layout is refitted too (round 6): beside the 8-wide one (scene option rope = 1; the renderer's A/B switches then walk the rope copy) and alone (wide = 0: every ray
+    on the rope kernels).  A leaf none of whose triangles moved keeps its box (the clipped boxes of the pre-split walls survive).  Same image as a fresh build and as the oracle."""
+    w, h = 160, 90
+    sc0, base = _deformed(mrt, (w, h), 0.0, 0.0)
+    big = [k for k, m in enumerate(base) if len(m[0]) > 100000]
+    r = mrt.Renderer((w, h), sc0, ctx=gpu_ctx, scene_options=sopt)
+    for k, v in ropt.items(): r.set_option(k, v)
+    ds = r.device_scene
+    assert ds.stats.wide_layout == (0 if sopt.get("wide") == 0 else 1)
+    r.draw(2, wait=True)
+    _, meshes = _deformed(mrt, (w, h), 0.03, 0.9)
+    ds.update_mesh(big[0], meshes[big[0]][0], meshes[big[0]][1]); ds.commit()
+    assert ds.refits == 1 and ds.stats.refits == 1
+    r.frameIndex = 0; r.reset_stats(); r.draw(4, wait=True)
+    osc = orc.OracleScene([m[:4] for m in meshes], sc0.lights)
+    o = orc.OracleRenderer(osc, w, h, seed=1, max_bounces=3, camera=sc0.camera); o.render(4)
+    assert np.array_equal(r.accumulation().view(np.uint32), o.accumulation().view(np.uint32))
+    assert (r.stats.closest_rays, r.stats.shadow_rays) == o.counters()
+    rng = np.random.default_rng(3)
+    rays = np.zeros((3000, 8), np.float32); rays[:, 0:3] = rng.uniform([-1.5, 0.1, 0.5], [1.5, 1.5, 4.0], (3000, 3)); d = rng.normal(size=(3000, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = np.inf
+    g, b = ds.intersect_closest(rays), osc.intersect_closest(rays)
+    for f in ("type", "primitive_id", "geometry_id", "instance_id"): assert np.array_equal(g[f], b[f]), f
+    assert np.array_equal(g["distance"].view(np.uint32), b["distance"].view(np.uint32))
+    r.close()
+
+
 def _deformed_instanced(mrt, size, amp, phase):
     """Dragon x 4 as ONE mesh + four instances (the shared-BLAS scene), the mesh's vertices pushed along their normals by a wave."""
     sc = mrt.InstancedDragonScene(size)
