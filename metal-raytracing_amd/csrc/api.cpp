@@ -536,7 +536,6 @@ int mrt_debug_renderer_set_option(MRTRenderer r, const char *key, double value) 
     else if (k == "fuse_primary") { REQUIRE(value == 0 || value == 1 || value == 2, "fuse_primary must be 0, 1 (not for one frame alone) or 2 (always)"); r->r.fuse_primary = (int)value; }
     else if (k == "wide_bounce") r->r.wide_bounce = value != 0;
     else if (k == "tl_pair_cap") { REQUIRE(value >= 0 && value <= 4294967295.0, "tl_pair_cap out of range"); r->r.tl_pair_cap = (int)std::min(value, 2147483647.0); }
-    else if (k == "tl_fuse") { REQUIRE(value == 0 || value == 1, "tl_fuse must be 0 or 1"); r->r.tl_fuse = (int)value; }
     else if (k == "tl_pairs") { REQUIRE(value == 0 || value == 1 || value == 2, "tl_pairs must be 0 (two-level scenes walked in one loop), 1 (TLAS pass + BLAS pass over (ray, instance) pairs) or 2 (the same, the TLAS pass always as a walk of the 8-wide TLAS)"); r->r.tl_pairs = (int)value; }
     else if (k == "primary_wide") { REQUIRE(value == 0 || value == 1 || value == 2, "primary_wide must be 0 (rope walk inside shade(0)), 1 (own launch of the 8-wide stream kernel) or 2 (8-wide walk inside shade(0))"); r->r.primary_wide = (int)value; }
     else return mrt_renderer_set_option(r, key, value);
@@ -565,7 +564,6 @@ int mrt_debug_renderer_get_option(MRTRenderer r, const char *key, double *value)
     else if (k == "tail_accumulate") *value = r->r.tail_accumulate ? 1 : 0;
     else if (k == "fuse_primary") *value = r->r.fuse_primary;
     else if (k == "wide_bounce") *value = r->r.wide_bounce ? 1 : 0;
-    else if (k == "tl_fuse") *value = r->r.tl_fuse;
     else if (k == "tl_pairs") *value = r->r.tl_pairs;
     else if (k == "tl_pair_cap") *value = r->r.tl_pair_cap;
     else if (k == "primary_wide") *value = r->r.primary_wide;

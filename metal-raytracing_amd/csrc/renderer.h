@@ -94,7 +94,6 @@ struct Renderer {
     int stream_stride = 2;               // the static split deals 64-ray batches round-robin to the waves (BatchStride) instead of one contiguous range each: 0 never, 1 always, 2 = a shard's launches (with one round of waves)
     int stream_even = 200;               // a traversal launch too small for chunk pulling has stream_even % of the wave slots as waves and splits the rays its queue really holds evenly among them (k_trace_mixed_wide_stream); 0 = rays_per_wave each, grid sized for the queue's capacity
     int tl_pair_cap = 0;                 // test aid: > 0 bounds the pair queue (pushes beyond it walk their instance in place); 0 = one pair per virtual ray
-    int tl_fuse = 0;                     // two-level scenes of at most 64 instances, binned walk: 1 = the tree-less TLAS pass runs inside the shade kernels on the rays they emit (shade.h TLFUSE); 0 (default) = as a launch of its own (k_tl_top_flat).
                                          // Measured on dragon x 4 (profiles/r06_two_level_ab.txt): 7.4 against 9.2 Grays/s — the pass is ~225 M wave-instructions per 8-frame launch, 0.55 ms of VALU issue wherever it runs; the shade kernels' idle VALU time (0.2 ms per launch) cannot hide it
     int tl_pairs = 1;                    // two-level scenes: bounce / shadow rays as TLAS pass + BLAS pass over (ray, instance) pairs (k_tl_top / k_tl_blas) instead of one loop over both levels; 0 = the one-loop walk
     bool wide_bounce = true;             // A/B switch: 0 = bounce / shadow rays on the rope kernels although the scene has the 8-wide layout

@@ -31,6 +31,7 @@
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
 #include "shade.h"
+#include "two_level_passes.h"
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -1026,10 +1027,8 @@ int Renderer::render(int n_frames) {                                   // Render
             const bool pairs_pass = two_level && planes_pass && tl_pairs != 0 && sv.tri_packet != nullptr;
             const size_t pair_cap = 2 * (size_t)this->capacity * (size_t)std::max(1, alloc_batch);          // one pair per virtual ray of the combined queue; a push beyond it walks its instance in place
             if (pairs_pass && !L.pairs.p) MRT_HIP(L.pairs.alloc(std::max<size_t>(PairQueue::WORDS * pair_cap, 1)));
-            // few instances: the TLAS pass has no tree (every lane visits every instance: nothing diverges) and runs inside the shade kernels, on the rays they emit (tl_fuse; shade.h TLFUSE);
-            // the 64-bit keys of bounce b's rays then live in half (b & 1) of the hit buffer — shade(b) reads the keys of bounce b - 1 while it writes those of bounce b
-            const bool tl_flat = pairs_pass && sv.num_inst <= TL_FLAT_MAX_INSTANCES && tl_pairs != 2, tl_fused = tl_flat && tl_fuse != 0;
-            auto keys_of = [&](int b_) { return reinterpret_cast<unsigned long long *>(L.hits.p) + (tl_fused ? (size_t)(b_ & 1) * L.hits.n : 0); };
+            // few instances: the TLAS pass has no tree (every lane visits every instance: nothing diverges; two_level_passes.h k_tl_top_flat)
+            const bool tl_flat = pairs_pass && sv.num_inst <= TL_FLAT_MAX_INSTANCES && tl_pairs != 2;
             const uint32_t pair_cap_used = (uint32_t)std::min<size_t>(tl_pair_cap > 0 ? std::min<size_t>((size_t)tl_pair_cap, pair_cap) : pair_cap, 0xFFFFFFFFu);
             // the primary trace inside shade(0): flattened scenes, planes passes
             // (not for one frame alone on the chip, fuse_primary = 1: there the primary kernel's 48 registers and 64-thread workgroups fill the chip better than shade's 76 and 256 — 1.71 against 1.81 ms;
@@ -1078,16 +1077,15 @@ int Renderer::render(int n_frames) {                                   // Render
                 }
                 const dim3 gs = b == 0 ? (fp.frame_bundle ? dim3(cdiv(cdiv((size_t)capacity * fp.bundle_groups, fp.bundle_per_wave) * 64, SHADE_THREADS), 1) : dim3(grid_shade, B)) : dim3(cdiv((size_t)capacity * B, pack ? fp.pack_range : (uint32_t)SHADE_THREADS));
                 using ShadeKernel = void (*)(SceneView, FrameParams, const uint32_t *, const float4 *, const float4 *, const float4 *, const float4 *, const unsigned long long *, uint32_t, float4 *, float4 *, float4 *, float4 *, float4 *, float4 *,
-                                             unsigned long long *, float4 *, float4 *, uint32_t *, unsigned long long *, uint8_t *, uint4 *, uint32_t *, uint32_t);
+                                             unsigned long long *, float4 *, float4 *, uint32_t *);
                 const bool trace0_tl = trace0_wide && b == 0 && two_level;
-                const bool fuse_b = tl_fused && (b > 0 || trace0_tl);          // (bounce 0 from the hit records of a primary launch reads the buffer the keys go to: its TLAS pass stays a launch)
                 const ShadeKernel shade_kernel = pack ? (materials ? (ShadeKernel)k_shade_pack<true, false, false, false>
-                                                          : pairs_pass ? (fuse_b ? (ShadeKernel)k_shade_pack<false, true, true, true, true> : (ShadeKernel)k_shade_pack<false, true, true, true>)
+                                                          : pairs_pass ? (ShadeKernel)k_shade_pack<false, true, true, true>
                                                           : planes_pass ? (ShadeKernel)k_shade_pack<false, true, true, false>
                                                           : fp.chain ? (ShadeKernel)k_shade_pack<false, true, false, false> : (ShadeKernel)k_shade_pack<false, false, false, false>)
                                                   : materials ? (ShadeKernel)k_shade<true, false, false, false>
-                                                  : (pairs_pass && b > 0) ? (fuse_b ? (ShadeKernel)k_shade<false, true, true, true, true> : (ShadeKernel)k_shade<false, true, true, true>)
-                                                  : trace0_tl ? (fuse_b ? (ShadeKernel)k_shade_primary<3, true> : (ShadeKernel)k_shade_primary<3>)
+                                                  : (pairs_pass && b > 0) ? (ShadeKernel)k_shade<false, true, true, true>
+                                                  : trace0_tl ? (ShadeKernel)k_shade_primary<3>
                                                   : (trace0_wide && b == 0) ? (ShadeKernel)k_shade_primary<2>
                                                   : (trace0_pass && b == 0) ? (ShadeKernel)k_shade_primary<1>
                                                   : planes_pass ? (ShadeKernel)k_shade<false, true, true, false>
@@ -1095,14 +1093,14 @@ int Renderer::render(int n_frames) {                                   // Render
                 float4 *const con_b = !planes_pass ? L.scon.p : b == 0 ? L.sample.p : L.f_con[b - 1].p;         // PLANES: this bounce's contribution plane in place of the queue
                 uint8_t *const lit_b = planes_pass ? L.f_lit.p + b : nullptr;
                 ShadeIO io{};
-                io.seeds = seeds_p; io.rayA = L.rayA[1 - q].p; io.rayB = L.rayB[1 - q].p; io.thr = L.thr[1 - q].p; io.hits = (pairs_pass && b > 0) ? reinterpret_cast<const float4 *>(keys_of(b - 1)) : L.hits.p; io.count_in = cin; io.capacity = capacity;
+                io.seeds = seeds_p; io.rayA = L.rayA[1 - q].p; io.rayB = L.rayB[1 - q].p; io.thr = L.thr[1 - q].p; io.hits = L.hits.p;          // (two-level, binned, b > 0: the 64-bit keys of the TLAS / BLAS passes, in the hit buffer)
+                io.count_in = cin; io.capacity = capacity;
                 io.nrayA = L.rayA[q].p; io.nrayB = L.rayB[q].p; io.nthr = L.thr[q].p; io.srayA = L.srayA.p; io.srayB = L.srayB.p; io.scon = con_b; io.count_out = bc + b;
                 io.sample_primary = b == 0 ? L.sample.p : nullptr; io.sample = L.sample.p; io.hint = (b == 0 && trace0_pass && trace0_hint) ? hint.p : nullptr;
                 uint32_t *const pc = reinterpret_cast<uint32_t *>(bc + 65 + b);          // two-level, binned: {pairs queued, work counter of the BLAS pass}
-                if (fuse_b) { io.keys_out = keys_of(b); io.lit = lit_b; io.pairs = L.pairs.p; io.pair_count = pc; io.pair_cap = pair_cap_used; }
                 const size_t shade_lds = (trace0_wide && b == 0) ? (size_t)SHADE_WAVES * (scene->wide_depth * WIDE_STACK_LEVEL_BYTES + (MRT_LANE_HIT_LDS ? 1024 : 0)) : 0;
                 launch_timed(timed(MRT_KERNEL_SHADE), shade_kernel, gs, dim3(SHADE_THREADS), shade_lds, st, sv, fp, io.seeds, io.rayA, io.rayB, io.thr, io.hits, io.count_in, io.capacity, io.nrayA, io.nrayB, io.nthr, io.srayA, io.srayB, io.scon,
-                             io.count_out, io.sample_primary, io.sample, io.hint, io.keys_out, io.lit, io.pairs, io.pair_count, io.pair_cap);
+                             io.count_out, io.sample_primary, io.sample, io.hint);
                 // persistent = 2 (auto): pull chunks when every wave slot would otherwise own >= 1024 rays (4-frame passes at 1080p: +7...+11 % with
                 // one stream, +2.5 % with 12); one-frame launches keep the static split (384 rays per wave, no atomics: 3 frames in flight 6.5 vs 5.4 Grays/s)
                 // [r3] smaller launches pull as well when five or more passes are in flight (6 lanes x one-frame passes: 9.33 against 8.76 Grays/s; a rank of eight over 240 frames
@@ -1115,10 +1113,9 @@ int Renderer::render(int n_frames) {                                   // Render
                     const uint32_t chunk = (uint32_t)std::min<size_t>((size_t)persist_chunk, std::max<size_t>(64, slots / ((size_t)wave_slots * 4) / 64 * 64));
                     const size_t grid_slots = (!wave_slots_user && (n_frames + batch_max - 1) / batch_max >= 2 * F) ? (size_t)std::max(1, wave_slots / 2) : (size_t)wave_slots;
                     const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, chunk), grid_slots));
-                    unsigned long long *const keys = keys_of(b);
-                    // few instances: the TLAS pass without a tree — inside the shade kernel (fuse_b) or as its own launch; many: the stream walk of the 8-wide TLAS
-                    if (fuse_b) {}
-                    else if (tl_flat)
+                    unsigned long long *const keys = reinterpret_cast<unsigned long long *>(L.hits.p);
+                    // few instances: the TLAS pass without a tree; many: the stream walk of the 8-wide TLAS
+                    if (tl_flat)
                         launch_timed(timed(MRT_KERNEL_TRACE), k_tl_top_flat, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(cdiv(slots, 64), 2 * grid_slots))), dim3(64), stack_bytes + 8, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
                                      (const unsigned long long *)(bc + b), lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
                     else
@@ -1126,7 +1123,7 @@ int Renderer::render(int n_frames) {                                   // Render
                                  (const unsigned long long *)(bc + b), reinterpret_cast<uint32_t *>(bc + 32 + b), chunk, lit_b, L.pairs.p, pc, pair_cap_used, (uint32_t)(stack_bytes / 4));
                     // the pairs' count is on the device: the launch has the wave slots it may use and the surplus leaves at once
                     launch_timed(timed(MRT_KERNEL_TRACE), k_tl_blas, dim3((uint32_t)grid_slots), dim3(64), (size_t)scene->wide_depth * WIDE_STACK_LEVEL_BYTES, st, sv, L.rayA[q].p, L.rayB[q].p, keys, L.srayA.p, L.srayB.p,
-                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used, fuse_b ? 1u : 0u);
+                                 (const unsigned long long *)(bc + b), pc + 1, 256u, lit_b, (const uint4 *)L.pairs.p, (const uint32_t *)pc, pair_cap_used);
                 }
                 else if (on_wide && pull) {
                     // rays per pull: at least four pulls per wave slot on a queue of this size (so that the launch ends evenly), at most

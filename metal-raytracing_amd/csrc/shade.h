@@ -6,15 +6,11 @@
 //   k_shade_primary    bounce 0 with the primary ray generated and traced in the same launch              (:171-247 + the above)
 //   k_shade_pack       bounces >= 1: the HITS of the bounce queue compacted in LDS, shaded on full waves
 //   k_shade            one queue entry per thread (bounce 0 from hit records; A/B of the packed form; materials at bounce 0)
-//
-// Two-level scenes (scene option instancing = 1), renderer option tl_fuse: the tree-less TLAS pass of the binned walk
-// (two_level_passes.h k_tl_top_flat) runs HERE, on the two rays a lane has just emitted, while they are in registers.
 #pragma once
 #include "device_math.h"
 #include "traverse.h"
 #include "traverse_wide.h"
 #include "traverse_instanced.h"
-#include "two_level_passes.h"
 
 namespace mrt {
 namespace {
@@ -108,9 +104,6 @@ MRT_DEV void primary_ray(const FrameParams &fp, const uint32_t *__restrict__ see
 #ifndef MRT_SHADE_WIDE_WAVES
 #define MRT_SHADE_WIDE_WAVES 5     // k_shade_primary on the 8-wide layout: the walk holds a node (20 registers) and a packet (10) on top of the shading state
 #endif
-#ifndef MRT_SHADE_TL_WAVES
-#define MRT_SHADE_TL_WAVES 6      // k_shade_pack / k_shade with the TLAS pass of a two-level scene inside (TLFUSE)
-#endif
 constexpr int SHADE_THREADS = MRT_SHADE_THREADS;
 constexpr int SHADE_WAVES = SHADE_THREADS / 64;
 #ifndef MRT_SHADE_PACK_RANGE
@@ -133,19 +126,14 @@ struct ShadeIO {
     float4 *__restrict__ sample_primary;             // bounce 0: the pass's sample buffer (zeroed here unless PLANES)
     float4 *__restrict__ sample;                     // MATERIALS: emitted radiance is added here
     uint32_t *__restrict__ hint;                     // k_shade_primary: per pixel, the packet its primary ray hit last (or nullptr)
-    // TLFUSE (two-level scenes, renderer option tl_fuse): the TLAS pass of the binned walk runs on the emitted rays here
-    unsigned long long *__restrict__ keys_out;       // per next-bounce ray: what it found at the TLAS level, {t bits, global triangle id} or ~0; the BLAS pass folds its hits in
-    uint8_t *__restrict__ lit;                       // this bounce's byte of sample 0 (four bytes per sample): set for a shadow ray not occluded at the TLAS level
-    uint4 *__restrict__ pairs; uint32_t *__restrict__ pair_count; uint32_t pair_cap;      // the (ray, instance) queue of the BLAS pass (PairQueue)
 };
 #define SHADE_IO_PARAMS const uint32_t *__restrict__ seeds, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, const float4 *__restrict__ thr, \
                         const float4 *__restrict__ hits, const unsigned long long *__restrict__ count_in, uint32_t capacity,                               \
                         float4 *__restrict__ nrayA, float4 *__restrict__ nrayB, float4 *__restrict__ nthr,                                                    \
                         float4 *__restrict__ srayA, float4 *__restrict__ srayB, float4 *__restrict__ scon, unsigned long long *__restrict__ count_out,       \
-                        float4 *__restrict__ sample_primary, float4 *__restrict__ sample, uint32_t *__restrict__ hint,                                        \
-                        unsigned long long *__restrict__ keys_out, uint8_t *__restrict__ lit, uint4 *__restrict__ pairs, uint32_t *__restrict__ pair_count, uint32_t pair_cap
-#define SHADE_IO_GATHER ShadeIO{seeds, rayA, rayB, thr, hits, count_in, capacity, nrayA, nrayB, nthr, srayA, srayB, scon, count_out, sample_primary, sample, hint, keys_out, lit, pairs, pair_count, pair_cap}
-struct ShadeShared { uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES]; unsigned long long blk_base; uint32_t w_pairs[SHADE_WAVES], pair_base; };      // w_pairs, pair_base: TLFUSE, the workgroup's reservation in the pair queue
+                        float4 *__restrict__ sample_primary, float4 *__restrict__ sample, uint32_t *__restrict__ hint
+#define SHADE_IO_GATHER ShadeIO{seeds, rayA, rayB, thr, hits, count_in, capacity, nrayA, nrayB, nthr, srayA, srayB, scon, count_out, sample_primary, sample, hint}
+struct ShadeShared { uint32_t w_next[SHADE_WAVES], w_shadow[SHADE_WAVES], w_spec[SHADE_WAVES]; unsigned long long blk_base; };
 
 // PAIRS (two-level scenes, bounces >= 1, renderer option tl_pairs): a 64-bit key {t bits, global triangle id} left by the
 // TLAS / BLAS passes becomes a hit record — the barycentrics come from re-testing the winning triangle in its instance's
@@ -170,12 +158,8 @@ MRT_DEV float4 pairs_hit(const SceneView &s, const ShadeIO &io, const uint32_t i
 //              nothing is zeroed (shadow planes, Renderer::shadow_planes)
 //   B0TAB      bounce 0 inside k_shade_primary: dimensions 2 .. 6 from the Halton table when there is one; `Bprim` is the
 //              primary ray's {direction | sample index}, still in registers
-//   TLFUSE     two-level scenes with few instances (renderer option tl_fuse): the tree-less TLAS pass of the binned walk (two_level_passes.h tl_flat_ray) on the
-//              two rays the lane has just emitted, while they are in registers — the pass as a launch of its own (k_tl_top_flat) cost 0.53 ms per bounce of an
-//              8-frame pass of dragon x 4, re-reading 12 M ray records, beside shade kernels whose VALU idles 69 % of the time.
-template <bool MATERIALS, bool CHAIN, bool PLANES, bool B0TAB, bool TLFUSE = false>
+template <bool MATERIALS, bool CHAIN, bool PLANES, bool B0TAB>
 MRT_DEV void shade_entry(const SceneView &s, const FrameParams &fp, const ShadeIO &io, ShadeShared &sh, const uint32_t i, const float4 H, bool active, const float4 Bprim) {
-    static_assert(!(TLFUSE && MATERIALS), "the fused TLAS pass takes the shadow ray's origin to be the bounce ray's: the diffuse kernel");
     uint32_t gid = __float_as_uint(H.w);
     active = active && gid != 0xFFFFFFFFu;                               // :246-247 miss terminates the path
     bool want_shadow = false, want_next = false;
@@ -355,58 +339,6 @@ MRT_DEV void shade_entry(const SceneView &s, const FrameParams &fp, const ShadeI
         qstore(&io.nrayB[ns], make_float4(ndir.x, ndir.y, ndir.z, __uint_as_float(pix)));   // :391
         if (!CHAIN) qstore(&io.nthr[ns], make_float4(color.x, color.y, color.z, 0.0f));
     }
-    if constexpr (TLFUSE) {
-        // 1. both rays against every instance: the small ones tested in place, the large ones whose box the ray enters noted in a bit mask (at most 64 instances)
-        unsigned long long enter_s = 0ull, enter_n = 0ull;          // shadow ray, next-bounce ray
-        float bt_n = __builtin_inff(); uint32_t bg_n = 0xFFFFFFFFu; bool dn_s = !want_shadow;
-#pragma nounroll
-        for (int kind = 0; kind < 2; kind++) {          // the shadow ray, then the bounce ray (wave-uniform: every lane runs the instance loop, a lane without that ray as `done`)
-            const bool shk = kind == 0;
-            if ((shk ? m_sh : m_nx) == 0ull) continue;
-            float bt = shk ? ldist - 1e-3f : __builtin_inff(); uint32_t bg = 0xFFFFFFFFu; bool dn = !(shk ? want_shadow : want_next); unsigned long long en = 0ull;
-            tl_flat_ray(s, norg /* == P + nrm * 1e-3f, the shadow ray's origin too (diffuse kernel) */, shk ? ldir : ndir, shk, bt, bg, dn,
-                        [&](uint32_t id) { en |= 1ull << id; return true; }, [&](const InstanceDev &, const f3, const f3, float, TravHit &) { return false; });
-            if (shk) { enter_s = dn ? 0ull : en; dn_s = dn; } else { enter_n = en; bt_n = bt; bg_n = bg; }
-        }
-        // 2. ONE atomic per workgroup reserves exactly the pairs it has (per-wave atomics on 260 K waves of a bounce-0 launch would take longer than the launch; fixed
-        //    blocks per wave — PairQueue, the TLAS pass as its own launch — would leave most of a short wave's block unused)
-        const uint32_t mine = (uint32_t)__popcll(enter_s) + (uint32_t)__popcll(enter_n);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o_); if (lane >= (uint32_t)o_) incl += v; }
-        if (lane == 63u) sh.w_pairs[wv] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tp = 0;
-            for (int k = 0; k < SHADE_WAVES; k++) { const uint32_t a = sh.w_pairs[k]; sh.w_pairs[k] = tp; tp += a; }
-            sh.pair_base = tp ? atomicAdd(io.pair_count, tp) : 0u;
-        }
-        __syncthreads();
-        uint32_t slot = sh.pair_base + sh.w_pairs[wv] + (incl - mine);
-        // 3. the pairs; a pair beyond the queue's capacity is walked here instead (the BLAS's rope copy: no stack).  A pair names its ray by its index in the ray's own
-        //    queue (| shadow << 31) — the bounce queue's final length is not known yet (k_tl_blas `flagged`) — and what the BLAS pass reports to: the pixel's byte / the key
-#pragma nounroll
-        for (int kind = 0; kind < 2; kind++) {
-            const bool shk = kind == 0;
-            const uint32_t qi = shk ? ss | 0x80000000u : ns, tagw = shk ? pix | 0x80000000u : ns;
-            float bt = shk ? ldist - 1e-3f : bt_n; uint32_t bg = bg_n; bool dn = shk ? dn_s : false;
-            for (unsigned long long m = shk ? enter_s : enter_n; m != 0ull; m &= m - 1ull, slot++) {
-                const uint32_t id = (uint32_t)__ffsll((long long)m) - 1u;
-                if (slot < io.pair_cap) qstore(reinterpret_cast<float4 *>(&io.pairs[slot]), make_float4(__uint_as_float(qi), __uint_as_float(id), bt, __uint_as_float(tagw)));
-                else if (!dn) {
-                    const InstanceDev &I = s.inst[id];
-                    TravHit h;
-                    if (traverse_blas_rope<true>(s, I, to_object_point(I, norg), to_object_dir(I, shk ? ldir : ndir), 0.0f, bt, h, shk)) {
-                        if (shk) dn = true;
-                        else { const uint32_t gid = I.gid_base + h.gid; if (h.t < bt || gid < bg) { bt = h.t; bg = gid; } }
-                    }
-                }
-            }
-            if (shk) dn_s = dn; else { bt_n = bt; bg_n = bg; }
-        }
-        if (want_shadow && !dn_s) io.lit[4 * (size_t)pix] = 1;          // not occluded so far: lit unless one of its pairs finds an occluder
-        if (want_next) __builtin_nontemporal_store(bg_n != 0xFFFFFFFFu ? ((unsigned long long)__float_as_uint(bt_n + 0.0f) << 32) | bg_n : ~0ull, &io.keys_out[ns]);
-    }
 }
 
 // thread -> (slot, sub-frame) of a bounce-0 launch.  Plain: grid = (blocks over one sub-frame's slots, sub-frames).  frame_bundle
@@ -425,7 +357,7 @@ MRT_DEV bool bounce0_slot(const FrameParams &fp, uint32_t &slot, uint32_t &sub) 
 //   WALK 1  the rope walk (scenes without the 8-wide layout), k_trace_primary<false>'s body
 //   WALK 2  one ray per lane on the 8-wide layout (traverse_wide_lane), the wave's stack in dynamic LDS
 //   WALK 3  two-level scene: both levels on one stack (traverse_wide_lane_two_level); the hint is (packet | instance << 24)
-template <int WALK, bool TLFUSE = false>
+template <int WALK>
 __global__ void __launch_bounds__(SHADE_THREADS, WALK >= 2 ? MRT_SHADE_WIDE_WAVES : MRT_SHADE_WAVES) k_shade_primary(SceneView s, FrameParams fp, SHADE_IO_PARAMS) {
     const ShadeIO io = SHADE_IO_GATHER;
     __shared__ ShadeShared sh;
@@ -499,14 +431,14 @@ __global__ void __launch_bounds__(SHADE_THREADS, WALK >= 2 ? MRT_SHADE_WIDE_WAVE
         else hit = traverse<false>(s, org, dir, 0.0f, __builtin_inff(), h);
         if (hit) H = make_float4(h.t, h.U / h.ad, h.V / h.ad, __uint_as_float(h.gid));
     }
-    shade_entry<false, true, true, true, TLFUSE>(s, fp, io, sh, spix, H, active, Bprim);
+    shade_entry<false, true, true, true>(s, fp, io, sh, spix, H, active, Bprim);
 }
 
 // Bounces >= 1 (renderer option shade_pack): half the entries of a bounce queue are rays that missed — their lanes would sit out
 // the whole kernel (41 % of the lanes per VALU instruction, profiles/r05_summary.json).  A workgroup takes fp.pack_range
 // consecutive entries, compacts the HITS into a ring in LDS 256 entries at a time and shades 256 of them per round, every lane busy.
-template <bool MATERIALS, bool CHAIN, bool PLANES, bool PAIRS, bool TLFUSE = false>
-__global__ void __launch_bounds__(SHADE_THREADS, TLFUSE ? MRT_SHADE_TL_WAVES : MRT_SHADE_WAVES) k_shade_pack(SceneView s, FrameParams fp, SHADE_IO_PARAMS) {
+template <bool MATERIALS, bool CHAIN, bool PLANES, bool PAIRS>
+__global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade_pack(SceneView s, FrameParams fp, SHADE_IO_PARAMS) {
     const ShadeIO io = SHADE_IO_GATHER;
     __shared__ ShadeShared sh;
     __shared__ uint32_t p_idx[2 * SHADE_THREADS], p_w[SHADE_WAVES];
@@ -545,14 +477,14 @@ __global__ void __launch_bounds__(SHADE_THREADS, TLFUSE ? MRT_SHADE_TL_WAVES : M
         float4 He = act ? p_hit[pos] : miss;
         if (PAIRS && act) He = pairs_hit(s, io, ie, (unsigned long long)__float_as_uint(He.x) | ((unsigned long long)__float_as_uint(He.y) << 32));
         head += take;
-        shade_entry<MATERIALS, CHAIN, PLANES, false, TLFUSE>(s, fp, io, sh, ie, He, act, noB);
+        shade_entry<MATERIALS, CHAIN, PLANES, false>(s, fp, io, sh, ie, He, act, noB);
     }
 }
 
 // One queue entry per thread, hit or miss: bounce 0 from the hit records of a primary launch (grid = (blocks over one sub-frame's
 // slots, sub-frames)), any bounce of the general pipeline (materials, > 3 bounces, no 8-wide layout), and the A/B of the packed form.
-template <bool MATERIALS, bool CHAIN, bool PLANES, bool PAIRS, bool TLFUSE = false>
-__global__ void __launch_bounds__(SHADE_THREADS, TLFUSE ? MRT_SHADE_TL_WAVES : MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, SHADE_IO_PARAMS) {
+template <bool MATERIALS, bool CHAIN, bool PLANES, bool PAIRS>
+__global__ void __launch_bounds__(SHADE_THREADS, MRT_SHADE_WAVES) k_shade(SceneView s, FrameParams fp, SHADE_IO_PARAMS) {
     const ShadeIO io = SHADE_IO_GATHER;
     __shared__ ShadeShared sh;
     const uint32_t sub = io.sample_primary ? blockIdx.y : 0u, slot = blockIdx.x * SHADE_THREADS + threadIdx.x;
@@ -567,7 +499,7 @@ __global__ void __launch_bounds__(SHADE_THREADS, TLFUSE ? MRT_SHADE_TL_WAVES : M
     float4 H = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
     if (active && PAIRS) H = pairs_hit(s, io, i, __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(io.hits) + i));
     else if (active) H = qload(&io.hits[i]);
-    shade_entry<MATERIALS, CHAIN, PLANES, false, TLFUSE>(s, fp, io, sh, i, H, active, make_float4(0.0f, 0.0f, 1.0f, 0.0f));
+    shade_entry<MATERIALS, CHAIN, PLANES, false>(s, fp, io, sh, i, H, active, make_float4(0.0f, 0.0f, 1.0f, 0.0f));
 }
 
 }  // namespace

@@ -103,47 +103,6 @@ MRT_DEV bool traverse_instanced(const SceneView &s, f3 o, f3 d, float tmin, floa
     return h.gid != 0xFFFFFFFFu;
 }
 
-// ONE instance's BLAS on the rope layout, the ray already in that instance's object space (direction not renormalised): what the TLAS pass inside the shade kernels
-// (shade.h, renderer option tl_fuse) walks in place when the pair queue refuses a pair — no stack, so no LDS.  h.gid = the triangle's id inside its BLAS, as
-// traverse_wide leaves it from a BLAS root.  Same triangles, same tri_test: the same (t, id) as any other walk of this BLAS.
-template <bool RUNTIME_ANY>
-MRT_DEV bool traverse_blas_rope(const SceneView &s, const InstanceDev &I, const f3 oo, const f3 dd, float tmin, float tmax, TravHit &h, bool any_rt) {
-    h.t = tmax; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f; h.gid = 0xFFFFFFFFu;
-    const float jx = box_inv(dd.x), jy = box_inv(dd.y), jz = box_inv(dd.z);
-    const float mox = -(oo.x * jx), moy = -(oo.y * jy), moz = -(oo.z * jz);
-    const uint32_t oct = (dd.x < 0.0f ? 1u : 0u) | (dd.y < 0.0f ? 2u : 0u) | (dd.z < 0.0f ? 4u : 0u);
-    const uint32_t esc_off = 32u + ((oct >> 2) << 4), esc_lane = oct & 3u;
-    const char *__restrict__ bbase = reinterpret_cast<const char *>(s.bnodes);
-    const uint32_t bpk0 = (uint32_t)(reinterpret_cast<const char *>(s.bpackets) - bbase);
-    uint32_t bc = 0, tri = 0, tri_end = 0;
-    for (;;) {
-        const bool do_tri = tri < tri_end;
-        if (!do_tri && bc == NODE_TERM) break;
-        const uint32_t off = do_tri ? bpk0 + (I.packet_base + tri) * 48u : (I.node_base + bc) << 6;
-        const float4 q0 = *reinterpret_cast<const float4 *>(bbase + off);
-        const float4 q1 = *reinterpret_cast<const float4 *>(bbase + off + 16u);
-        const float4 q2 = *reinterpret_cast<const float4 *>(bbase + off + (do_tri ? 32u : esc_off));
-        if (do_tri) {
-            tri++;
-            float t, U, V, ad;
-            if (tri_test(q0, q1, q2, oo, dd, tmin, h.t, t, U, V, ad)) {
-                if (RUNTIME_ANY && any_rt) return true;
-                const uint32_t id = __float_as_uint(q0.w);
-                if (t < h.t || id < h.gid) { h.t = t; h.U = U; h.V = V; h.ad = ad; h.gid = id; }
-            }
-        } else {
-            const uint32_t a = __float_as_uint(q0.w), b = __float_as_uint(q1.w);
-            const float escf = esc_lane == 0 ? q2.x : esc_lane == 1 ? q2.y : esc_lane == 2 ? q2.z : q2.w;
-            const bool hit = rope_box_hit(q0, q1, jx, jy, jz, mox, moy, moz, tmin, h.t);
-            const bool leaf = (a & NODE_LEAF) != 0;
-            const uint32_t child = ((b >> (24 + oct)) & 1u) ? (b & NODE_INDEX_MASK) : a;
-            bc = (hit && !leaf) ? child : __float_as_uint(escf);
-            if (hit && leaf) { tri = a & 0x7FFFFFFFu; tri_end = tri + b; }
-        }
-    }
-    return h.gid != 0xFFFFFFFFu;
-}
-
 // instance of a global triangle id: the last instance whose gid_base <= gid (the rows are in instance order, gid_base ascending)
 MRT_DEV uint32_t instance_of_gid(const SceneView &s, uint32_t gid) {
     uint32_t lo = 0, hi = s.num_inst - 1;

@@ -112,14 +112,13 @@ __global__ void __launch_bounds__(64) k_tl_top_flat(SceneView s, const float4 *_
     }
     pq.close();
 }
-// `flagged` != 0: the pairs name their rays by (index in the ray's own queue | shadow << 31) — the TLAS pass inside the shade kernels, which queues pairs before the
-// bounce queue's final length is known; 0: by index in the combined queue [bounce rays | shadow rays] (k_tl_top, k_tl_top_flat).
+// The BLAS pass: the pairs name their rays by index in the combined queue [bounce rays | shadow rays].
 __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView s, const float4 *__restrict__ rayA, const float4 *__restrict__ rayB, unsigned long long *__restrict__ keys,
                                                                    const float4 *__restrict__ srayA, const float4 *__restrict__ srayB, const unsigned long long *__restrict__ counts,
-                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap, uint32_t flagged) {
+                                                                   uint32_t *__restrict__ work, uint32_t chunk, uint8_t *__restrict__ lit, const uint4 *__restrict__ pairs, const uint32_t *__restrict__ pair_count, uint32_t pair_cap) {
     extern __shared__ uint32_t stk_dyn[];
-    // whole blocks only (blocks beyond the capacity were refused — their rays walked in place — but counted); flagged: the shade kernels reserve exactly what they write
-    const uint32_t n_next = (uint32_t)*counts, np = flagged ? min(*pair_count, pair_cap) : min(*pair_count, pair_cap / PairQueue::BLOCK * PairQueue::BLOCK);
+    // whole blocks only (blocks beyond the capacity were refused — their rays walked in place — but counted)
+    const uint32_t n_next = (uint32_t)*counts, np = min(*pair_count, pair_cap / PairQueue::BLOCK * PairQueue::BLOCK);
     if (blockIdx.x * chunk >= np) return;
     traverse_wide_stream<false, false, true>(s, SharedCounter{work, np, chunk}, stk_dyn,
         [&](uint32_t k, float4 &A, float4 &B, uint32_t &tag, uint32_t &is_any, uint32_t &root) {
@@ -129,7 +128,7 @@ __global__ void __launch_bounds__(64, MRT_WIDE_STREAM_WAVES) k_tl_blas(SceneView
                 A = make_float4(0.0f, 0.0f, 0.0f, -1.0f); B = make_float4(0.0f, 0.0f, 1.0f, 0.0f); tag = k; is_any = 1u; root = 0u;
                 return;
             }
-            const bool sh = flagged ? (i >> 31) != 0u : i >= n_next; const uint32_t j = flagged ? i & 0x7FFFFFFFu : sh ? i - n_next : i;
+            const bool sh = i >= n_next; const uint32_t j = sh ? i - n_next : i;
             const float4 Aw = qload(sh ? &srayA[j] : &rayA[j]), Bw = qload(sh ? &srayB[j] : &rayB[j]);
             const InstanceDev &I = s.inst[id];
             const f3 o = to_object_point(I, mk3(Aw)), d = to_object_dir(I, mk3(Bw));        // direction not renormalised: t stays the world distance

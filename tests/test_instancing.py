@@ -284,10 +284,8 @@ def test_binned_two_level_walk_is_the_one_loop_walk(mrt, gpu_ctx, scene_name):
     w, h = (160, 96) if scene_name == "six_instances" else (256, 144)
     sc = _scene(mrt, (w, h)) if scene_name == "six_instances" else mrt.InstancedDragonScene((w, h))
     imgs = {}
-    # binned (default): the tree-less TLAS pass as its own launch; tl_fuse = 1: the same pass inside the shade kernels, on the rays they emit (a pair beyond the queue's capacity walks
-    # the BLAS's rope copy there); tl_pairs = 2: the stream walk of the 8-wide TLAS; fuse_primary = 0: bounce 0 shades hit records, its TLAS pass stays a launch
-    for name, opts in (("one_loop", {"tl_pairs": 0}), ("binned", {}), ("binned_tiny_queue", {"tl_pair_cap": 257}), ("binned_fused", {"tl_fuse": 1}), ("binned_fused_tiny_queue", {"tl_fuse": 1, "tl_pair_cap": 257}),
-                       ("binned_fused_unpacked_shade", {"tl_fuse": 1, "shade_pack": 0}), ("binned_fused_primary_launch", {"tl_fuse": 1, "fuse_primary": 0}), ("binned_fused_primary_launch_tiny_queue", {"tl_fuse": 1, "fuse_primary": 0, "tl_pair_cap": 300}),
+    # binned (default): the tree-less TLAS pass; tl_pairs = 2: the stream walk of the 8-wide TLAS; fuse_primary = 0: bounce 0 shades the hit records of a primary launch
+    for name, opts in (("one_loop", {"tl_pairs": 0}), ("binned", {}), ("binned_tiny_queue", {"tl_pair_cap": 257}), ("binned_unpacked_shade", {"shade_pack": 0}), ("binned_primary_launch", {"fuse_primary": 0}),
                        ("binned_tlas_walk", {"tl_pairs": 2}), ("binned_tlas_walk_tiny_queue", {"tl_pairs": 2, "tl_pair_cap": 600}), ("binned_one_frame_passes", {"frame_batch": 1}),
                        ("binned_three_lanes", {"frame_batch": 4, "frames_in_flight": 3})):
         r = mrt.Renderer((w, h), sc, ctx=gpu_ctx, scene_options={"instancing": 1})
