@@ -126,7 +126,8 @@ typedef struct {
     float    leaf_growth;      /* surface area of the MOVED meshes' leaf boxes against what the build gave them (1 after a build; chained over the
                                   refits since; two-level scenes: the worst BLAS).  The sharper of the two signals: a small, finely tessellated
                                   mesh in a large room hardly moves the whole tree's cost (DragonScene at a 2 % deformation: wide_cost x 1.014,
-                                  leaf_growth ~2, rate x 0.85).  "refit_max_cost_ratio" acts on whichever is larger                            */
+                                  leaf_growth ~2, rate x 0.85).  "refit_max_cost_ratio" acts on whichever is larger.  Both are measured on the
+                                  8-wide layout: a scene built without it (wide = 0) refits its rope layout and reports 0 / 1 here       */
 } MRTSceneStats;
 
 typedef struct {
