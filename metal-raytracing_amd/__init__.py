@@ -7,9 +7,9 @@ The directory name carries a hyphen (it follows the reference repository's name)
 """
 from ._ffi import (Camera, Float3, Intersection, Light, LightType, Material, MRTError, Ray, RenderStats, SceneStats, Uniforms, lib, LIB_PATH)
 from .scene import (SCENES, CornellScene, DragonScene, GardenScene, InstancedDragonScene, IrregularDragonScene, HostileDragonScene, dragon_proxy_irregular, dragon_proxy_hostile, Mesh, Model, Scene, Submesh, flatten_scene, make_transform, load_obj, dragon_proxy, bunny_proxy)
-from .renderer import Context, DeviceScene, GroupRenderer, Renderer, save_png, INTERSECTION_DTYPE
+from .renderer import Context, DeviceScene, GroupRenderer, Renderer, save_png, save_pfm, INTERSECTION_DTYPE
 
 __all__ = ["Camera", "Float3", "Intersection", "Light", "LightType", "Material", "MRTError", "Ray", "RenderStats", "SceneStats",
            "Uniforms", "lib", "LIB_PATH", "SCENES", "CornellScene", "DragonScene", "GardenScene", "InstancedDragonScene", "IrregularDragonScene", "HostileDragonScene", "dragon_proxy_irregular", "dragon_proxy_hostile", "Mesh",
            "Model", "Scene", "Submesh", "flatten_scene", "make_transform", "load_obj", "dragon_proxy", "bunny_proxy", "Context",
-           "DeviceScene", "GroupRenderer", "Renderer", "save_png", "INTERSECTION_DTYPE"]
+           "DeviceScene", "GroupRenderer", "Renderer", "save_png", "save_pfm", "INTERSECTION_DTYPE"]

@@ -419,5 +419,22 @@ class GroupRenderer:
 
 
 def save_png(path, rgba8):
-    from PIL import Image
-    Image.fromarray(rgba8, "RGBA").save(path)
+    """The tonemapped image (Renderer.tonemapped(): (h, w, 4) uint8, row 0 = top — the blit's flip, Shaders.metal:35) as an 8-bit RGBA PNG; zlib only."""
+    import struct, zlib
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4: raise ValueError("save_png: expected (h, w, 4) uint8")
+    h, w = a.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * 4)], axis=1).tobytes()          # filter byte 0 in front of every row
+    def chunk(tag, data): return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def save_pfm(path, accum):
+    """The accumulation buffer (Renderer.accumulation(): (h, w, 4) float32 radiance, row 0 = the BOTTOM of the image, SURVEY a-4) as a little-endian colour PFM —
+    whose rows are stored bottom to top as well, so the buffer goes out as it lies.  For comparing radiance, not display (no tonemap)."""
+    a = np.asarray(accum, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] not in (3, 4): raise ValueError("save_pfm: expected (h, w, 3 or 4) float32")
+    h, w = a.shape[:2]
+    with open(path, "wb") as f:
+        f.write(f"PF\n{w} {h}\n-1.0\n".encode()); f.write(np.ascontiguousarray(a[:, :, :3]).astype("<f4").tobytes())

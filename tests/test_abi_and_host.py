@@ -239,3 +239,35 @@ def test_host_sah_builder_makes_a_valid_tree_of_lower_cost_than_a_median_split(m
     mcost, _ = _sah_cost(lo4[:, :3].astype(np.float64), hi4[:, :3].astype(np.float64), m_order, m_left, m_right, m_parent)
     assert cost < 0.9 * mcost, (cost, mcost)
     assert depth < 64
+
+
+def test_image_writers_round_trip(mrt, tmp_path):
+    """SURVEY f-1: the tonemapped image as PNG (zlib only — read back here with an independent decoder when there is one, by hand otherwise) and the radiance buffer as PFM
+    (rows bottom to top, as the accumulation buffer lies: Raytracing.metal has no y-flip, SURVEY a-4)."""
+    import struct, zlib
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    p = str(tmp_path / "a.png"); mrt.save_png(p, img)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8]); data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        if tag == b"IHDR": ihdr = struct.unpack(">IIBBBBB", data)
+        if tag == b"IDAT": idat += data
+        pos += 12 + n
+    assert ihdr == (53, 37, 8, 6, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 4)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(37, 53, 4), img)
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(p)), img)
+    except ImportError:
+        pass
+    acc = rng.random((11, 7, 4), dtype=np.float32) * 3.0
+    q = str(tmp_path / "a.pfm"); mrt.save_pfm(q, acc)
+    b = open(q, "rb").read()
+    head = b"PF\n7 11\n-1.0\n"
+    assert b.startswith(head) and np.array_equal(np.frombuffer(b[len(head):], "<f4").reshape(11, 7, 3), acc[:, :, :3])
+    with pytest.raises(ValueError): mrt.save_png(p, img[:, :, :3])
