@@ -19,6 +19,8 @@ struct B3 { float lo[3], hi[3]; };
 inline void b_init(B3 &b) { for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; } }
 inline void b_add(B3 &b, const float *lo, const float *hi) { for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], lo[k]); b.hi[k] = std::max(b.hi[k], hi[k]); } }
 inline void b_add(B3 &b, const B3 &o) { b_add(b, o.lo, o.hi); }
+// bin of a centroid: clamped as a float first — a NaN or an out-of-range product (non-finite boxes, an extent that overflows) must not reach the float -> int conversion
+inline int bin_of(float c, float lo, float scale, int bins) { const float f = (c - lo) * scale; return f >= (float)(bins - 1) ? bins - 1 : f > 0.0f ? (int)f : 0; }
 inline float b_area(const B3 &b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x < 0.0f ? 0.0f : x * y + y * z + z * x; }
 
 struct Builder {
@@ -68,7 +70,7 @@ struct Builder {
                 for (int k = 0; k < BINS; k++) { b_init(bb[k]); bc[k] = 0; }
                 for (uint32_t i = b; i < e; i++) {
                     const uint32_t r = order[i];
-                    int k = (int)((c[r] - clo[a]) * scale); k = k < 0 ? 0 : k >= BINS ? BINS - 1 : k;
+                    const int k = bin_of(c[r], clo[a], scale, BINS);
                     b_add(bb[k], &lo[r].x, &hi[r].x); bc[k]++;
                 }
                 float ra[BINS]; uint32_t rc[BINS]; B3 acc; b_init(acc); uint32_t c2 = 0;
@@ -84,7 +86,7 @@ struct Builder {
             if (bbin >= 0) {
                 const float *c = cen(axis);
                 const float scale = (float)BINS / (chi[axis] - clo[axis]);
-                auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t r) { int k = (int)((c[r] - clo[axis]) * scale); k = k < 0 ? 0 : k >= BINS ? BINS - 1 : k; return k < bbin; });
+                auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t r) { return bin_of(c[r], clo[axis], scale, BINS) < bbin; });
                 mid = (uint32_t)(it - order.begin());
                 found = mid > b && mid < e;
             }
