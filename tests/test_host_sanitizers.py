@@ -1,7 +1,9 @@
 """The host-side code that parses untrusted input or runs on threads, built with AddressSanitizer + UndefinedBehaviorSanitizer and driven on the CPU (GPU sanitizers are not
 available on the pool): the OBJ / MTL reader (csrc/host_geometry.cpp, the stand-in for ModelIO's importer, Model.swift:16-21) over mutated copies of the shipped assets, and the
 host binned-SAH builder (csrc/bvh_host_sah.cpp) over random and degenerate box sets — NaN, infinities, overflowing extents, identical boxes — with its topology invariants checked.
-Round 6 found one defect this way: a NaN reaching a float -> int conversion in the builder's binning (undefined behaviour; benign on x86)."""
+Round 6 found one defect this way: a NaN reaching a float -> int conversion in the builder's binning (undefined behaviour; benign on x86).
+(The whole library with its host code instrumented runs the CPU tests clean, but cannot run on the GPU box: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and
+aborts at the first device allocation — the GPU sanitizers are not available on this pool.)"""
 import os, shutil, subprocess, sys
 import pytest
 

@@ -8,5 +8,5 @@ FL="-O3 -std=c++17 -fPIC -ffp-contract=off $2"
 for f in bvh_build two_level renderer calibrate group; do /opt/rocm/bin/hipcc --offload-arch=gfx950 $FL -c -o $V/$f.o $C/$f.hip & done
 for f in api host_geometry bvh_host_sah; do /opt/rocm/bin/hipcc $FL -c -o $V/$f.o $C/$f.cpp & done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/metal-raytracing_amd/variants/libmrt_hip_$1.so $V/*.o -ldl -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LINK_EXTRA -o $ROOT/metal-raytracing_amd/variants/libmrt_hip_$1.so $V/*.o -ldl -lpthread
 echo built $ROOT/metal-raytracing_amd/variants/libmrt_hip_$1.so
