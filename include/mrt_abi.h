@@ -183,7 +183,10 @@ int mrt_scene_destroy(MRTScene scene);
 /* One Mesh = one instance (Renderer.swift:193-200).  positions/normals: nverts vectors with the
  * given byte stride (16 for the reference's float3 buffers, 12 for packed).  transform: 16
  * floats, column-major 4x4 object→world (Mesh.swift:21-24); the last row is ignored exactly as
- * matrix4x4_drop_last_row does (Utilities.swift:92-101).  Returns the instance id in *mesh_id. */
+ * matrix4x4_drop_last_row does (Utilities.swift:92-101).  Returns the instance id in *mesh_id.
+ * Positions, normals and transforms must be finite: a NaN or an infinity is MRT_ERR_INVALID_ARGUMENT
+ * here, in mrt_scene_add_instance, mrt_scene_update_mesh and mrt_scene_set_instance_transform (the
+ * scene keeps what it had).                                                                     */
 int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride_bytes,
                        const float *normals, size_t nrm_stride_bytes, size_t nverts,
                        const float *transform_colmajor_4x4, int32_t *mesh_id);

@@ -88,6 +88,16 @@ int mrt_scene_destroy(MRTScene scene) {
     delete scene;
     return MRT_OK;
 }
+// What the device is handed must be finite: a NaN or an infinity in a position, a normal or a transform is refused here, with the call that brought it, instead of as a
+// builder that "made no progress" or as NaN radiance (the reference never sees one: ModelIO's importer produces its meshes, Model.swift:16-21).
+static bool all_finite(const float *p, size_t stride_bytes, size_t n, int comps) {
+    uint32_t bad = 0;          // exponent field all ones = NaN or infinity; integer ops, no branch and no floating-point dependency chain in the loop
+    for (size_t i = 0; i < n; i++) {
+        const char *q = (const char *)p + i * stride_bytes;
+        for (int k = 0; k < comps; k++) { uint32_t b; memcpy(&b, q + 4 * k, 4); bad |= ((b & 0x7F800000u) + 0x00800000u) >> 31; }
+    }
+    return bad == 0;
+}
 int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride, const float *normals, size_t nrm_stride,
                        size_t nverts, const float *xf, int32_t *mesh_id) {
     MRT_TRY
@@ -95,6 +105,8 @@ int mrt_scene_add_mesh(MRTScene scene, const float *positions, size_t pos_stride
     REQUIRE(nverts == 0 || (positions && normals), "mrt_scene_add_mesh: NULL vertex arrays");
     REQUIRE(pos_stride >= 12 && nrm_stride >= 12 && pos_stride % 4 == 0 && nrm_stride % 4 == 0, "mrt_scene_add_mesh: strides must be multiples of 4 and >= 12");
     REQUIRE(scene->meshes.size() < 65535, "mrt_scene_add_mesh: too many meshes");
+    REQUIRE(all_finite(xf, 64, 1, 16), "mrt_scene_add_mesh: the transform holds a NaN or an infinity");
+    REQUIRE(nverts == 0 || (all_finite(positions, pos_stride, nverts, 3) && all_finite(normals, nrm_stride, nverts, 3)), "mrt_scene_add_mesh: a position or a normal is NaN or infinite");
     mrt::HostMesh m;
     m.positions.resize(nverts * 3); m.normals.resize(nverts * 3);
     for (size_t i = 0; i < nverts; i++) {
@@ -115,6 +127,7 @@ int mrt_scene_add_instance(MRTScene scene, int32_t source_mesh_id, const float *
     REQUIRE(scene && xf, "mrt_scene_add_instance: bad argument");
     REQUIRE(source_mesh_id >= 0 && (size_t)source_mesh_id < scene->meshes.size(), "mrt_scene_add_instance: source_mesh_id out of range");
     REQUIRE(scene->meshes.size() < 65535, "mrt_scene_add_instance: too many meshes");
+    REQUIRE(all_finite(xf, 64, 1, 16), "mrt_scene_add_instance: the transform holds a NaN or an infinity");
     mrt::HostMesh m;
     const int src = scene->meshes[source_mesh_id].source;
     m.source = src >= 0 ? src : source_mesh_id;                         // instances of an instance share the original's geometry
@@ -229,6 +242,7 @@ int mrt_scene_update_mesh(MRTScene scene, int32_t mesh_id, const float *position
     mrt::HostMesh &m = scene->meshes[(size_t)mesh_id];
     REQUIRE(m.source < 0, "mrt_scene_update_mesh: an instance has no vertices of its own (update its source mesh)");
     REQUIRE(nverts * 3 == m.positions.size(), "mrt_scene_update_mesh: the vertex count must stay the same (the topology is kept)");
+    REQUIRE(all_finite(positions, pos_stride, nverts, 3) && all_finite(normals, nrm_stride, nverts, 3), "mrt_scene_update_mesh: a position or a normal is NaN or infinite (the mesh keeps what it had)");
     for (size_t i = 0; i < nverts; i++) {
         const float *p = (const float *)((const char *)positions + i * pos_stride);
         const float *n = (const float *)((const char *)normals + i * nrm_stride);
@@ -246,6 +260,7 @@ int mrt_scene_set_instance_transform(MRTScene scene, int32_t mesh_id, const floa
     MRT_TRY
     REQUIRE(scene && xf, "mrt_scene_set_instance_transform: bad argument");
     REQUIRE(mesh_id >= 0 && (size_t)mesh_id < scene->meshes.size(), "mrt_scene_set_instance_transform: mesh_id out of range");
+    REQUIRE(all_finite(xf, 64, 1, 16), "mrt_scene_set_instance_transform: the transform holds a NaN or an infinity (the instance keeps what it had)");
     float *m = scene->meshes[mesh_id].xf;
     memcpy(m, xf, 64);
     m[3] = m[7] = m[11] = 0.0f; m[15] = 1.0f;

@@ -301,6 +301,22 @@ def test_error_paths(mrt, gpu_ctx):
     r.close(); r2.close()
     with pytest.raises(mrt.MRTError):
         mrt.Context(999)
+    # a NaN or an infinity in a position, a normal or a transform is refused by the call that brings it (and leaves what was there)
+    lib = mrt.lib; ptr = mrt._ffi.ptr
+    s = C.c_void_p(); assert lib.mrt_scene_create(gpu_ctx.handle, C.byref(s)) == 0
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32); nrm = np.tile(np.array([0, 0, 1], np.float32), (3, 1)); xf = np.eye(4, dtype=np.float32); mid = C.c_int32()
+    for bad in (np.nan, np.inf, -np.inf):
+        p2 = pos.copy(); p2[1, 2] = bad; n2 = nrm.copy(); n2[2, 0] = bad; x2 = xf.copy(); x2[3, 1] = bad
+        assert lib.mrt_scene_add_mesh(s, ptr(p2), 12, ptr(nrm), 12, 3, ptr(xf), C.byref(mid)) == 1 and b"NaN or infinite" in lib.mrt_last_error()
+        assert lib.mrt_scene_add_mesh(s, ptr(pos), 12, ptr(n2), 12, 3, ptr(xf), C.byref(mid)) == 1
+        assert lib.mrt_scene_add_mesh(s, ptr(pos), 12, ptr(nrm), 12, 3, ptr(x2), C.byref(mid)) == 1 and b"transform" in lib.mrt_last_error()
+    assert lib.mrt_scene_add_mesh(s, ptr(pos), 12, ptr(nrm), 12, 3, ptr(xf), C.byref(mid)) == 0 and mid.value == 0
+    big = pos * np.float32(3e38)          # finite, however large: accepted
+    assert lib.mrt_scene_update_mesh(s, 0, ptr(big), 12, ptr(nrm), 12, 3) == 0 and lib.mrt_scene_update_mesh(s, 0, ptr(pos), 12, ptr(nrm), 12, 3) == 0
+    p2 = pos.copy(); p2[0, 0] = np.nan; x2 = xf.copy(); x2[0, 0] = np.inf
+    assert lib.mrt_scene_update_mesh(s, 0, ptr(p2), 12, ptr(nrm), 12, 3) == 1 and b"keeps what it had" in lib.mrt_last_error()
+    assert lib.mrt_scene_set_instance_transform(s, 0, ptr(x2)) == 1 and lib.mrt_scene_add_instance(s, 0, ptr(x2), C.byref(mid)) == 1
+    lib.mrt_scene_destroy(s)
 
 
 # ---------------------------------------------------------------- BASELINE full size: properties
