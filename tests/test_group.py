@@ -111,3 +111,13 @@ def test_one_device_group_through_rccl(mrt, gpu_ctx):
         img = g.gather()
         again = g.gather()
     assert np.array_equal(img, ref) and np.array_equal(again, ref)
+
+
+def test_torch_distributed_calls_of_the_ranks_path_over_rccl_with_a_world_of_one():
+    """bench.py's N > 1 path and distributed.py over backend nccl (= RCCL) — init with device_id, reduce, gather, all_gather, all_reduce, barrier, both assembles of a renderer's
+    image — with ONE rank on the box's GPU, in a process of its own (two ranks cannot share a device under RCCL; the two-rank runs of the suite use gloo)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "r06_calls", "nccl_world1.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "nccl world-1 ok" in p.stdout, (p.stdout + p.stderr)[-2000:]
