@@ -729,14 +729,14 @@ MRT_DEV void traverse_wide_stream(const SceneView &s, Chunks next_chunk, uint32_
                 const uint32_t o_tb = (uint32_t)__builtin_amdgcn_readlane((int)t_base, owner), o_tm = (uint32_t)__builtin_amdgcn_readlane((int)t_mask, owner);
                 const uint32_t f_lo = (uint32_t)m_free, f_hi = (uint32_t)(m_free >> 32), bit = lane & 31u;
                 helping = !live && !unreported && ((o_tm >> bit) & 1u) != 0u && (lane < 32u || ((f_lo >> bit) & 1u) == 0u);
-                if (helping) {
-                    o = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.y), owner)),
-                            __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.z), owner)));
-                    d = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.y), owner)),
-                            __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.z), owner)));
-                    best_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best_t), owner));
-                    help_pk = o_tb + bit;
-                }
+                // the owner's ray is read HERE, where the whole wave is on: the owner is not among the helpers, and inside `if (helping)` a register the compiler had to reload would
+                // hold the owner's lane no more (a reload covers the active lanes only — two variant builds with more scratch rendered wrong images, tests/test_kernel_resources.py)
+                const f3 o_o = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.y), owner)),
+                                   __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(o.z), owner)));
+                const f3 o_d = mk3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.x), owner)), __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.y), owner)),
+                                   __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d.z), owner)));
+                const float o_bt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best_t), owner));
+                if (helping) { o = o_o; d = o_d; best_t = o_bt; help_pk = o_tb + bit; }
                 if ((int)lane == owner) t_mask &= ~((f_lo | f_hi) & o_tm);      // these are being tested now
             }
         }

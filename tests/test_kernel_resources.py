@@ -1,9 +1,10 @@
 """The stream traversal kernels read other lanes' registers — the refill takes prefetched rays by ds_bpermute, the cooperative drain reads a straggler's ray by v_readlane — so a
 register's value must survive in lanes that are switched off.  Hardware keeps it; a spill store or reload inside divergent control flow covers the active lanes only.  Two variant
-builds of round 6 that pushed the persistent kernel from 24 to 60 / 64 bytes of scratch (7 waves per SIMD; the fp16-plane nodes at 6) rendered wrong images in the GPU suite while the
-same source at 0 bytes of scratch was bit-exact (profiles/r06_wide16_ab.txt) — which spill did it was not isolated.  The shipped build's 24 bytes are loop-invariant values stored at
-kernel entry with every lane on and reloaded behind a wave-uniform branch.  This test compiles the device code (no GPU needed) and holds that line as an early warning beside the
-parity suite: the kernels built on traverse_wide_stream spill at most 32 bytes, and never store a spill inside their loop."""
+builds of round 6 that pushed the persistent kernel from 24 to 60 / 64 bytes of scratch (7 waves per SIMD; the fp16-plane nodes at 6) rendered wrong images in the GPU suite
+(profiles/r06_wide16_ab.txt).  The cause: the drain's helpers read their owner's ray with v_readlane INSIDE `if (helping)`, where the owner's lane is off — correct only as long as
+the compiler never reloads that register there.  The reads now sit where the whole wave is on (traverse_wide.h), and the 7-wave variant passes the suite; every other cross-lane read
+of the library was already at wave-uniform level or names an active lane.  This test compiles the device code (no GPU needed) and keeps an early warning beside the parity suite:
+the kernels built on traverse_wide_stream spill at most 32 bytes — the shipped build's 24 are loop-invariant values stored at kernel entry — and never store a spill inside their loop."""
 import os, re, shutil, subprocess
 import pytest
 
