@@ -2,6 +2,7 @@
 available on the pool): the OBJ / MTL reader (csrc/host_geometry.cpp, the stand-in for ModelIO's importer, Model.swift:16-21) over mutated copies of the shipped assets, and the
 host binned-SAH builder (csrc/bvh_host_sah.cpp) over random and degenerate box sets — NaN, infinities, overflowing extents, identical boxes — with its topology invariants checked.
 Round 6 found one defect this way: a NaN reaching a float -> int conversion in the builder's binning (undefined behaviour; benign on x86).
+(The oracle built with the same two sanitizers runs its own CPU tests clean — tests/test_oracle_kat.py, test_independent_f64.py, test_fuzz_geometry.py, test_materials.py, test_instancing.py: 48 passed.)
 (The whole library with its host code instrumented runs the CPU tests clean, but cannot run on the GPU box: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and
 aborts at the first device allocation — the GPU sanitizers are not available on this pool.)"""
 import os, shutil, subprocess, sys
