@@ -131,6 +131,9 @@ struct ScratchArena {
             chunks.push_back(m); cur = (uint8_t *)m; left = c;
         }
         *out = cur; cur += bytes; left -= bytes;
+#ifdef MRT_POISON_ALLOC      // diagnostics build: no allocation starts out as zeros (every dword = 1: a counter that was assumed 0 is off by one, an index stays inside its array)
+        (void)hipDeviceSynchronize(); (void)hipMemsetD32((hipDeviceptr_t)*out, 1, bytes / 4); (void)hipDeviceSynchronize();
+#endif
         return hipSuccess;
     }
 };
@@ -147,6 +150,9 @@ template <class T> struct DevBuf {
         release();
         hipError_t e = flags ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), flags) : hipMalloc((void **)&p, count * sizeof(T));
         if (e == hipSuccess) n = count; else p = nullptr;
+#ifdef MRT_POISON_ALLOC
+        if (e == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipMemsetD32((hipDeviceptr_t)p, 1, count * sizeof(T) / 4); (void)hipDeviceSynchronize(); }
+#endif
         return e;
     }
     hipError_t alloc_in(ScratchArena &a, size_t count) {       // a piece of the arena: not freed here, gone with the arena
