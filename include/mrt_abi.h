@@ -169,6 +169,9 @@ int         mrt_abi_version(void);
  * replaces MTLCreateSystemDefaultDevice + makeCommandQueue (Renderer.swift:46-59).
  * Fails with MRT_ERR_NO_DEVICE when there is no HIP device — there is no CPU fallback.         */
 int mrt_context_create(int device_id, MRTContext *out);
+/* Handles are not reference-counted (the reference's objects are, by ARC): destroy renderers before their scene, and scenes and
+ * renderers before their context.  Out of order the call is refused — MRT_ERR_STATE, nothing is freed — instead of leaving a handle
+ * that points at freed memory.  NULL is accepted everywhere.                                                                    */
 int mrt_context_destroy(MRTContext ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int mrt_context_set_stream(MRTContext ctx, void *hip_stream);

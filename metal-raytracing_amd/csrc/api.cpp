@@ -52,6 +52,8 @@ int mrt_context_create(int device_id, MRTContext *out) {
 }
 int mrt_context_destroy(MRTContext ctx) {
     if (!ctx) return MRT_OK;
+    // the reference's objects are reference-counted (ARC); a C handle is not, so the order is checked instead: a context outlives its scenes and renderers, a scene its renderers
+    if (ctx->live != 0) { mrt::set_error("mrt_context_destroy: " + std::to_string(ctx->live) + " scene(s) / renderer(s) of this context are still alive: destroy them first"); return MRT_ERR_STATE; }
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
@@ -77,12 +79,14 @@ int mrt_context_device_name(MRTContext ctx, char *buf, size_t buflen) {
 int mrt_scene_create(MRTContext ctx, MRTScene *out) {
     MRT_TRY
     REQUIRE(ctx && out, "mrt_scene_create: bad argument");
-    MRTScene s = new MRTScene_(); s->ctx = ctx; *out = s;
+    MRTScene s = new MRTScene_(); s->ctx = ctx; *out = s; ctx->live++;
     return MRT_OK;
     MRT_CATCH
 }
 int mrt_scene_destroy(MRTScene scene) {
     if (!scene) return MRT_OK;
+    if (scene->renderers != 0) { mrt::set_error("mrt_scene_destroy: " + std::to_string(scene->renderers) + " renderer(s) still use this scene: destroy them first"); return MRT_ERR_STATE; }
+    scene->ctx->live--;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
     delete scene;
@@ -430,12 +434,13 @@ int mrt_renderer_create(MRTContext ctx, MRTScene scene, int32_t width, int32_t h
     std::unique_ptr<MRTRenderer_> r(new MRTRenderer_());
     r->ctx = ctx; r->scene = scene;
     rc = r->r.init(ctx->stream, &scene->dev, width, height, seed, max_bounces); if (rc) return rc;
-    *out = r.release();
+    *out = r.release(); scene->renderers++; ctx->live++;
     return MRT_OK;
     MRT_CATCH
 }
 int mrt_renderer_destroy(MRTRenderer r) {
     if (!r) return MRT_OK;
+    r->scene->renderers--; r->ctx->live--;
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     delete r;

@@ -7,6 +7,7 @@ struct MRTContext_ {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char name[256] = {0};
+    int live = 0;                           // scenes and renderers made on this context and not yet destroyed: mrt_context_destroy refuses while any is left
 };
 struct MRTScene_ {
     MRTContext ctx = nullptr;
@@ -17,6 +18,7 @@ struct MRTScene_ {
     bool committed = false;
     bool only_vertices_changed = false;     // since the last commit: nothing but mrt_scene_update_mesh calls — a flattened scene with the 8-wide layout refits its tree (scene option refit)
     bool only_transforms_changed = false;   // since the last commit: a two-level scene rebuilds its TLAS only, a flattened one rebuilds from the geometry already on the device
+    int renderers = 0;                      // renderers made on this scene and not yet destroyed: mrt_scene_destroy refuses while any is left (they hold a pointer to `dev`)
     size_t stage_need = 0;                  // bytes the upload staging of the meshes added so far will take (mrt_mesh_add_submesh grows the pinned area)
 };
 struct MRTRenderer_ {

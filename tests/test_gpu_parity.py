@@ -301,6 +301,15 @@ def test_error_paths(mrt, gpu_ctx):
     r.close(); r2.close()
     with pytest.raises(mrt.MRTError):
         mrt.Context(999)
+    # handles are destroyed inside out: a scene with a live renderer and a context with a live scene refuse (nothing is freed), and accept once their dependants are gone
+    c2 = C.c_void_p(); assert mrt.lib.mrt_context_create(0, C.byref(c2)) == 0
+    s2 = C.c_void_p(); assert mrt.lib.mrt_scene_create(c2, C.byref(s2)) == 0
+    assert mrt.lib.mrt_context_destroy(c2) == 5 and b"still alive" in mrt.lib.mrt_last_error()
+    assert mrt.lib.mrt_scene_commit(s2) == 0          # (an empty scene commits)
+    r3 = C.c_void_p(); assert mrt.lib.mrt_renderer_create(c2, s2, 8, 8, 1, 3, C.byref(r3)) == 0
+    assert mrt.lib.mrt_scene_destroy(s2) == 5 and b"still use this scene" in mrt.lib.mrt_last_error()
+    assert mrt.lib.mrt_renderer_destroy(r3) == 0 and mrt.lib.mrt_context_destroy(c2) == 5
+    assert mrt.lib.mrt_scene_destroy(s2) == 0 and mrt.lib.mrt_context_destroy(c2) == 0
     # a NaN or an infinity in a position, a normal or a transform is refused by the call that brings it (and leaves what was there)
     lib = mrt.lib; ptr = mrt._ffi.ptr
     s = C.c_void_p(); assert lib.mrt_scene_create(gpu_ctx.handle, C.byref(s)) == 0
