@@ -193,3 +193,25 @@ def test_refit_argument_checks_and_fallbacks(mrt, gpu_ctx):
     ds3 = mrt.DeviceScene(gpu_ctx, sc)
     ds3.update_mesh(k, pos * np.float32(1.01), nrm); ds3.commit()
     assert ds3.refits == 1
+
+
+@pytest.mark.parametrize("sopt", [{}, {"refit": 0}, {"instancing": 1}])
+def test_commit_while_a_draw_is_in_flight_is_ordered_behind_it(mrt, gpu_ctx, sopt):
+    """mrt_renderer_render returns at once; a host that deforms a mesh and commits while those frames are still on the GPU must get them on the OLD geometry and the next draw on the new
+    one — the commit's kernels (a refit in place, or a build that frees what the frames read) are ordered behind the draw on the device.  Same image as the sequence with a wait after
+    every step; 1080p so that the first draw is still running when the commit arrives."""
+    w, h = 1920, 1080
+    imgs = []
+    for asynchronous in (False, True):
+        sc0, base = (_deformed if not sopt.get("instancing") else _deformed_instanced)(mrt, (w, h), 0.0, 0.0)
+        _, moved = (_deformed if not sopt.get("instancing") else _deformed_instanced)(mrt, (w, h), 0.03, 0.9)
+        big = [k for k, m in enumerate(base) if len(m[0]) > 100000 and m[4] < 0][0]
+        r = mrt.Renderer((w, h), sc0, ctx=gpu_ctx, scene_options=sopt); ds = r.device_scene
+        r.draw(48, wait=not asynchronous)          # ~25 ms of GPU work: still running when the commit below arrives
+        ds.update_mesh(big, moved[big][0], moved[big][1]); ds.commit()
+        r.draw(48, wait=not asynchronous)
+        ds.update_mesh(big, base[big][0], base[big][1]); ds.commit()
+        r.draw(8, wait=True)
+        imgs.append((r.accumulation().copy(), r.stats.closest_rays, r.stats.shadow_rays)); r.close()
+    assert imgs[0][1:] == imgs[1][1:]
+    assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32))
