@@ -215,3 +215,24 @@ def test_commit_while_a_draw_is_in_flight_is_ordered_behind_it(mrt, gpu_ctx, sop
         imgs.append((r.accumulation().copy(), r.stats.closest_rays, r.stats.shadow_rays)); r.close()
     assert imgs[0][1:] == imgs[1][1:]
     assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32))
+
+
+def test_reads_and_light_updates_while_a_draw_is_in_flight(mrt, gpu_ctx):
+    """The other calls a host may make while frames are still on the GPU: reading the accumulation (waits for them), new lights (the frames in flight keep the old ones, the next draw
+    gets the new), a new camera (a launch parameter: captured when the draw was issued).  Same images as the sequence with a wait after every step."""
+    w, h = 1920, 1080
+    out = []
+    for asynchronous in (False, True):
+        sc = mrt.DragonScene((w, h)); r = mrt.Renderer((w, h), sc, ctx=gpu_ctx)
+        r.draw(48, wait=not asynchronous)
+        a0 = r.accumulation().copy()                       # (reads wait)
+        r.draw(24, wait=not asynchronous)
+        from metal_raytracing_amd._ffi import _f3
+        lights = list(sc.lights); lights[0].color = _f3((9.0, 1.0, 1.0)); r.device_scene.set_lights(lights)
+        cam = sc.camera; cam.position = _f3((0.2, 1.1, 5.0)); r.set_camera(cam)
+        r.draw(24, wait=not asynchronous)
+        a1 = r.accumulation().copy()
+        out.append((a0, a1)); r.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert not np.array_equal(out[0][0], out[0][1])
