@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 NEUTRAL = [("frame_batch", (1, 2, 3, 4, 8)), ("frames_in_flight", (1, 2, 3, 6)), ("persistent", (0, 1, 2)), ("persist_chunk", (64, 256, 1024)), ("wave_slots", (96, 1024, 0)), ("shade_pack", (0, 1)),
-           ("tile_groups", (0, 1, 2, 3)), ("frame_bundle", (0, 1)), ("halton_table", (0, 1)), ("hit_lds", (0, 1)), ("stream_stride", (0, 1, 2)), ("fuse_primary", (0, 1, 2)), ("xcd_counters", (0, 1))]
+           ("tile_groups", (0, 1, 2, 3)), ("frame_bundle", (0, 1)), ("halton_table", (0, 1)), ("hit_lds", (0, 1)), ("stream_stride", (0, 1, 2)), ("fuse_primary", (0, 1, 2)), ("xcd_counters", (0, 1)), ("megakernel", (0, 0, 1)), ("primary_wide", (1, 2)), ("wide_bounce", (1, 1, 0))]
 
 
 def _scene(mrt, size):
@@ -35,6 +35,7 @@ def _run(mrt, gpu_ctx, seed, two_level, fuzzed):
         if fuzzed:
             for _ in range(2):
                 k, vals = NEUTRAL[orng.integers(len(NEUTRAL))]
+                if two_level and k == "megakernel": continue          # (one launch per frame: flattened scenes only — a draw says so)
                 try: r.set_option(k, float(vals[orng.integers(len(vals))]))
                 except mrt.MRTError: pass          # (an option this scene kind does not take)
         op = rng.integers(8)
